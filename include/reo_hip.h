@@ -1,0 +1,157 @@
+/*
+ * reo_hip.h -- C ABI of libreo_hip.so, the MI355X (gfx950) implementation of
+ * RankCompV3.jl's REO pairwise-comparison hot path.
+ *
+ * The reference has no FFI: the seam this library replaces is the ordinary
+ * Julia call identify_degs(data, group, gene_names, pval_reo, pval_deg,
+ * padj_deg, ref_gene, n_iter, n_conv) at /root/reference/src/RankCompV3.jl:
+ * 339-350 (called once from reoa at :652-662).  A <=100-line Julia shim with
+ * that exact signature drives the entry points below through ccall (see
+ * INTEGRATION.md and julia/RankCompV3HIP.jl); the Python mirror in
+ * rankcompv3.jl_amd/ binds the same symbols through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative reo_status; the
+ *     message of the last failure on the calling thread is reo_last_error().
+ *     REO_EINVAL corresponds to the reference's DimensionMismatch /
+ *     ArgumentError / BoundsError paths (src/RankCompV3.jl:355-356,411).
+ *   - the caller owns every array it passes; host inputs are copied during
+ *     the call and no host pointer is retained after return; outputs are
+ *     caller-allocated.
+ *   - a context is single-owner (not thread-safe); distinct contexts may be
+ *     used from distinct threads.  All calls block until their work is done.
+ *   - matrices are column-major (the layout Julia hands over at :652).
+ */
+#ifndef REO_HIP_H
+#define REO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct reo_ctx reo_ctx;
+
+enum reo_status {
+    REO_OK = 0,
+    REO_EINVAL = -1, /* bad argument / shape mismatch / reference error path */
+    REO_EHIP = -2,   /* HIP runtime failure (including "no GPU")           */
+    REO_ECOMM = -3,  /* the all-reduce hook reported failure               */
+    REO_ENOMEM = -4  /* host or device allocation failed                   */
+};
+
+/* Library version, major*10000 + minor*100 + patch. */
+int32_t reo_version(void);
+
+/* Message of the last error on this thread (library-owned, valid until the
+ * next failing call on the same thread). */
+const char *reo_last_error(void);
+
+/* Create a context on HIP device `device` (-1 = the current device).  `seed`
+ * keys the tie coin stream that stands in for the reference's unseeded
+ * rand(Bool) in is_greater (src/RankCompV3.jl:71-77).  Fails with REO_EHIP
+ * when no gfx950 device is usable: there is no CPU fallback. */
+int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed);
+void reo_destroy(reo_ctx *ctx);
+
+/* G-sharding for multi-GPU runs (one context per GPU): this context builds
+ * and tallies only the pair tiles it owns out of `world` shards.  Default
+ * (0, 1) = everything.  Replaces nothing in the reference (it has no
+ * multi-device path); see DESIGN.md "Multi-GPU". */
+int32_t reo_set_shard(reo_ctx *ctx, int32_t rank, int32_t world);
+
+/* Hook called once per iteration between the tally kernel and the statistics
+ * kernels when world > 1: must sum `count` int32 values at device pointer
+ * `dev_buf` across all shards in place (e.g. RCCL ncclAllReduce, or
+ * torch.distributed.all_reduce on a tensor aliasing it) and return 0.  The
+ * library synchronises its stream before the call and expects the result to
+ * be complete (visible to any stream) on return. */
+typedef int32_t (*reo_allreduce_fn)(void *dev_buf, int64_t count, void *user);
+int32_t reo_set_allreduce(reo_ctx *ctx, reo_allreduce_fn fn, void *user);
+
+/* Expression matrix, G genes x S samples, column-major with leading dimension
+ * ld >= G: the `data` argument of identify_degs (src/RankCompV3.jl:340) as
+ * Matrix(df_expr) produces it (:652), eltype Float64 or Int64.  G and S must
+ * be in [2, 65535]; values must be finite.  *_host copies from host memory;
+ * *_dev uses a buffer already resident in HBM (it must stay valid until
+ * reo_build_pairs returns). */
+int32_t reo_set_matrix_f64(reo_ctx *ctx, const double *X, int64_t G, int64_t S, int64_t ld);
+int32_t reo_set_matrix_i64(reo_ctx *ctx, const int64_t *X, int64_t G, int64_t S, int64_t ld);
+int32_t reo_set_matrix_dev_f64(reo_ctx *ctx, const void *dX, int64_t G, int64_t S, int64_t ld);
+int32_t reo_set_matrix_dev_i64(reo_ctx *ctx, const void *dX, int64_t G, int64_t S, int64_t ld);
+
+/* Group of each sample: the `group` argument (src/RankCompV3.jl:341) recoded
+ * to 0-based ids in order of first appearance (unique(), :353).  Length must
+ * equal S (else REO_EINVAL = the DimensionMismatch of :355); ngroups must be
+ * >= 2 (:356).  This round only ngroups == 2 is built by reo_build_pairs. */
+int32_t reo_set_groups(reo_ctx *ctx, const int32_t *group_id, int64_t len, int32_t ngroups);
+
+/* Stable-REO thresholds: get_major_reo_lower_count (src/RankCompV3.jl:81-92)
+ * applied as at :362.  m is 2 x ngroups column-major: m[2k] for group k,
+ * m[2k+1] for the rest.  reo_compute_thresholds derives them from pval_reo,
+ * reo_set_thresholds overrides them, reo_get_thresholds reads them back. */
+int32_t reo_compute_thresholds(reo_ctx *ctx, double pval_reo);
+int32_t reo_set_thresholds(reo_ctx *ctx, const int32_t *m);
+int32_t reo_get_thresholds(reo_ctx *ctx, int32_t *m);
+/* The threshold function itself (host arithmetic), for tests. */
+int32_t reo_threshold(int32_t sample_size, double pval_reo);
+
+/* REO table build for comparison k (group k vs rest): replaces the pair loop
+ * src/RankCompV3.jl:363-392.  Runs the per-sample rank/band transform and the
+ * pair-compare kernel and leaves the 4-bit class table in HBM. */
+int32_t reo_build_pairs(reo_ctx *ctx, int32_t k);
+
+/* Parity hook: deterministic per-pair per-group counts for the ordered pairs
+ * (i, j), i in [i0,i1), j in [j0,j1): n_gt = #samples with x_i > x_j and not
+ * tied, n_eq = #tied samples (|x_i - x_j| < 0.1, src/RankCompV3.jl:72), each
+ * laid out [(i-i0)][(j-j0)][group].  Computed by the same device loop as
+ * reo_build_pairs.  Needs matrix + groups only. */
+int32_t reo_pair_counts(reo_ctx *ctx, int64_t i0, int64_t i1, int64_t j0, int64_t j1,
+                        uint16_t *n_gt, uint16_t *n_eq);
+
+/* Parity hook: class codes 3*(ic-1)+(it-1) in 0..8 of the ordered pairs of a
+ * block (255 where the table holds no pair: the diagonal, and pairs owned by
+ * another shard), row-major [(i-i0)][(j-j0)] -- the column index of the
+ * reference's R BitArray minus one (src/RankCompV3.jl:383-386). */
+int32_t reo_get_codes(reo_ctx *ctx, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *code);
+
+/* Per-gene 3x3 contingency builder, src/RankCompV3.jl:403: cont is G x 9
+ * row-major (n11 n12 n13 n21 ... n33), ref_mask has one byte per gene
+ * (non-zero = reference gene).  With world > 1 the all-reduce hook is used. */
+int32_t reo_tally(reo_ctx *ctx, const uint8_t *ref_mask, int32_t *cont);
+
+/* Iteration driver + McCullagh test, src/RankCompV3.jl:396-425 (and :225-259)
+ * for the comparison built by reo_build_pairs.  result is G x 15 column-major
+ * Float64: [pval padj n11..n33 delta1 delta2 se z1] (:398,405,415-416,665).
+ * iters_run = number of executed passes of the while loop (:400); trace is
+ * n_iter x 2 int32, (#DEG, #non-DEG) per pass (the :418 log line); either may
+ * be NULL.  REO_EINVAL when the reference would throw (G < 10: the slice of
+ * :411 is out of bounds). */
+int32_t reo_identify_degs(reo_ctx *ctx, const uint8_t *ref0, double pval_deg, double padj_deg,
+                          int32_t n_iter, int32_t n_conv, double *result,
+                          int32_t *iters_run, int32_t *trace);
+
+/* McCullagh test on 3x3 tables given as 9 tallies each (n x 9 row-major),
+ * evaluated by the device routine the iteration uses; out is n x 5 row-major
+ * (pval, delta1, delta2, se, z1) -- src/RankCompV3.jl:225-259. */
+int32_t reo_mccullagh(reo_ctx *ctx, const int32_t *cont, int64_t n, double *out);
+
+/* Stage timers (HIP events on the library's stream), milliseconds, summed
+ * since the last reo_reset_timings.  Index: 0 rank/band transform, 1 pair
+ * kernel K1, 2 tally kernel K2 (sum), 3 statistics kernels K3 (sum), 4 number
+ * of K2 launches, 5 number of K1 launches, 6 all-reduce hook wall time. */
+enum { REO_NTIMINGS = 8 };
+int32_t reo_set_profiling(reo_ctx *ctx, int32_t on);
+int32_t reo_reset_timings(reo_ctx *ctx);
+int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);
+
+/* Facts about the current problem for roofline accounting: 0 G, 1 S, 2 padded
+ * G (table row pitch in bits), 3 class-table bytes, 4 data-has-ties flag,
+ * 5 tiles owned by this shard, 6 tiles total. */
+int32_t reo_get_info(reo_ctx *ctx, int64_t *info, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REO_HIP_H */

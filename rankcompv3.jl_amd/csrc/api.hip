@@ -1,0 +1,497 @@
+// C ABI of libreo_hip.so (include/reo_hip.h): context, host-side driver of the
+// iteration loop of /root/reference/src/RankCompV3.jl:396-425, error plumbing.
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "reo_internal.h"
+
+namespace reo {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+void tic(reo_ctx *c, int slot)
+{
+    if (!c->profiling) return;
+    StageTimer t;
+    if (!c->pool.empty()) { t = c->pool.back(); c->pool.pop_back(); }
+    else { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
+    (void)hipEventRecord(t.a, c->stream);
+    c->pending.emplace_back(slot, t);
+}
+
+void toc(reo_ctx *c)
+{
+    if (!c->profiling || c->pending.empty()) return;
+    (void)hipEventRecord(c->pending.back().second.b, c->stream);
+}
+
+void collect_timings(reo_ctx *c)
+{
+    for (auto &pr : c->pending) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(pr.second.b);
+        if (hipEventElapsedTime(&ms, pr.second.a, pr.second.b) == hipSuccess) c->t_ms[pr.first] += ms;
+        c->pool.push_back(pr.second);
+    }
+    c->pending.clear();
+}
+
+// pvalue(Binomial(n, 1/2), x; tail = :both) = min(1, 2 min(ccdf(x-1), cdf(x)))
+// (HypothesisTests, call sites src/RankCompV3.jl:83,85)
+static long double binom_half_cdf(int n, int x)
+{
+    if (x < 0) return 0.0L;
+    if (x >= n) return 1.0L;
+    long double acc = 0.0L, logc = 0.0L;
+    const long double ln2 = 0.693147180559945309417232121458L;
+    for (int t = 0; t <= x; ++t) {
+        if (t > 0) logc += std::log(static_cast<long double>(n - t + 1)) - std::log(static_cast<long double>(t));
+        acc += std::exp(logc - static_cast<long double>(n) * ln2);
+    }
+    return acc > 1.0L ? 1.0L : acc;
+}
+
+static double binom_two_sided(int n, int x)
+{
+    const long double lo = binom_half_cdf(n, x), hi = 1.0L - binom_half_cdf(n, x - 1);
+    const long double p = 2.0L * (lo < hi ? lo : hi);
+    return static_cast<double>(p > 1.0L ? 1.0L : p);
+}
+
+// get_major_reo_lower_count, src/RankCompV3.jl:81-92
+static int32_t major_reo_lower_count(int32_t n, double thr)
+{
+    if (binom_two_sided(n, 0) < thr) {
+        for (int x = 0; x <= n / 2; ++x)
+            if (binom_two_sided(n, x) > thr) return n - x + 1;
+        return -1;
+    }
+    return n;  // the WARN branch (:87-90)
+}
+
+static int32_t use(reo_ctx *c)
+{
+    if (!c) { set_error("null context"); return REO_EINVAL; }
+    REO_HIP_CHECK(hipSetDevice(c->device));
+    return REO_OK;
+}
+
+static void invalidate(reo_ctx *c)
+{
+    c->transformed = false;
+    c->built_k = -1;
+}
+
+static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64_t ld, int dtype, bool on_device)
+{
+    int32_t rc = use(c);
+    if (rc) return rc;
+    if (!X) { set_error("matrix pointer is null"); return REO_EINVAL; }
+    if (G < 2 || G > 65535 || S < 2 || S > 65535) {
+        set_error("matrix is %lld x %lld; G and S must be in [2, 65535]", (long long)G, (long long)S);
+        return REO_EINVAL;
+    }
+    if (ld < G) { set_error("leading dimension %lld < G = %lld", (long long)ld, (long long)G); return REO_EINVAL; }
+    invalidate(c);
+    c->G = G; c->S = S; c->dtype = dtype;
+    if (on_device) {
+        c->dX = X; c->ld = ld;
+        c->dX_owned.release();
+    } else {
+        if ((rc = c->dX_owned.ensure(static_cast<size_t>(G) * S * 8))) return rc;
+        REO_HIP_CHECK(hipMemcpy2DAsync(c->dX_owned.p, G * 8, X, ld * 8, G * 8, S, hipMemcpyHostToDevice, c->stream));
+        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->dX = c->dX_owned.p; c->ld = G;
+    }
+    return REO_OK;
+}
+
+static int32_t ensure_transform(reo_ctx *c)
+{
+    if (c->dtype == 0) { set_error("no expression matrix set"); return REO_EINVAL; }
+    if (c->group_id.empty()) { set_error("no groups set"); return REO_EINVAL; }
+    if (static_cast<int64_t>(c->group_id.size()) != c->S) {
+        // DimensionMismatch, src/RankCompV3.jl:355
+        set_error("'data' and 'group' do not have compatible sizes (%lld columns, %zu group labels)",
+                  (long long)c->S, c->group_id.size());
+        return REO_EINVAL;
+    }
+    if (c->transformed) return REO_OK;
+    c->Gp = static_cast<int>((c->G + kTileJ - 1) / kTileJ) * kTileJ;
+    c->Wp = c->Gp / 32;
+    return run_transform(c);
+}
+
+static int32_t ensure_iter_buffers(reo_ctx *c)
+{
+    int32_t rc;
+    const size_t G = c->G;
+    for (int t = 0; t < 2; ++t) {
+        if ((rc = c->refbits[t].ensure(c->Wp))) return rc;
+        if ((rc = c->refbytes[t].ensure(c->Gp))) return rc;
+    }
+    if ((rc = c->raw.ensure(G * kRaw)) || (rc = c->cont.ensure(G * 9)) || (rc = c->result.ensure(G * 15)) ||
+        (rc = c->sorted_d.ensure(G)) || (rc = c->sorted_p.ensure(G)) || (rc = c->rank_s.ensure(G)) ||
+        (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->counters.ensure(8)))
+        return rc;
+    if (!c->host_counters) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_counters), 8 * sizeof(int32_t)));
+    return REO_OK;
+}
+
+static int32_t upload_ref(reo_ctx *c, const uint8_t *ref, int slot, int32_t *nref)
+{
+    int32_t n = 0;
+    for (int64_t i = 0; i < c->G; ++i) n += ref[i] != 0;
+    *nref = n;
+    REO_HIP_CHECK(hipMemsetAsync(c->refbytes[slot].p, 0, c->Gp, c->stream));
+    REO_HIP_CHECK(hipMemcpyAsync(c->refbytes[slot].p, ref, c->G, hipMemcpyHostToDevice, c->stream));
+    return launch_pack_ref(c, c->refbytes[slot].p, c->refbits[slot].p);
+}
+
+static int32_t allreduce_raw(reo_ctx *c)
+{
+    if (c->world <= 1) return REO_OK;
+    if (!c->ar) { set_error("world = %d but no all-reduce hook is set (reo_set_allreduce)", c->world); return REO_ECOMM; }
+    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int32_t rc = c->ar(c->raw.p, c->G * kRaw, c->ar_user);
+    c->t_ms[6] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc) { set_error("all-reduce hook failed with %d", rc); return REO_ECOMM; }
+    return REO_OK;
+}
+
+}  // namespace reo
+
+using namespace reo;
+
+extern "C" {
+
+int32_t reo_version(void) { return 100; }
+
+const char *reo_last_error(void) { return g_err.c_str(); }
+
+int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
+{
+    if (!out) { set_error("out is null"); return REO_EINVAL; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: libreo_hip has no CPU fallback");
+        return REO_EHIP;
+    }
+    if (device < 0) REO_HIP_CHECK(hipGetDevice(&device));
+    if (device >= ndev) { set_error("device %d out of range (%d visible)", device, ndev); return REO_EINVAL; }
+    hipDeviceProp_t prop;
+    REO_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return REO_EHIP;
+    }
+    REO_HIP_CHECK(hipSetDevice(device));
+    reo_ctx *c = new (std::nothrow) reo_ctx();
+    if (!c) { set_error("out of host memory"); return REO_ENOMEM; }
+    c->device = device;
+    c->seed = seed;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return REO_EHIP; }
+    *out = c;
+    return REO_OK;
+}
+
+void reo_destroy(reo_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    collect_timings(c);
+    for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
+    c->table.release();
+    for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
+    c->raw.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
+    c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->counters.release();
+    if (c->host_counters) (void)hipHostFree(c->host_counters);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int32_t reo_set_shard(reo_ctx *c, int32_t rank, int32_t world)
+{
+    if (!c) { set_error("null context"); return REO_EINVAL; }
+    if (world < 1 || rank < 0 || rank >= world) { set_error("bad shard %d of %d", rank, world); return REO_EINVAL; }
+    c->rank = rank; c->world = world;
+    c->built_k = -1;
+    return REO_OK;
+}
+
+int32_t reo_set_allreduce(reo_ctx *c, reo_allreduce_fn fn, void *user)
+{
+    if (!c) { set_error("null context"); return REO_EINVAL; }
+    c->ar = fn; c->ar_user = user;
+    return REO_OK;
+}
+
+int32_t reo_set_matrix_f64(reo_ctx *c, const double *X, int64_t G, int64_t S, int64_t ld) { return set_matrix(c, X, G, S, ld, 1, false); }
+int32_t reo_set_matrix_i64(reo_ctx *c, const int64_t *X, int64_t G, int64_t S, int64_t ld) { return set_matrix(c, X, G, S, ld, 2, false); }
+int32_t reo_set_matrix_dev_f64(reo_ctx *c, const void *dX, int64_t G, int64_t S, int64_t ld) { return set_matrix(c, dX, G, S, ld, 1, true); }
+int32_t reo_set_matrix_dev_i64(reo_ctx *c, const void *dX, int64_t G, int64_t S, int64_t ld) { return set_matrix(c, dX, G, S, ld, 2, true); }
+
+int32_t reo_set_groups(reo_ctx *c, const int32_t *group_id, int64_t len, int32_t ngroups)
+{
+    if (!c || !group_id) { set_error("null argument"); return REO_EINVAL; }
+    if (ngroups < 2) {  // DimensionMismatch, src/RankCompV3.jl:356
+        set_error("only %d level in 'group', at least 2 levels are needed", ngroups);
+        return REO_EINVAL;
+    }
+    if (ngroups > 64) { set_error("more than 64 groups"); return REO_EINVAL; }
+    std::vector<int32_t> cnt(ngroups, 0);
+    int next = 0;
+    for (int64_t s = 0; s < len; ++s) {
+        const int32_t g = group_id[s];
+        if (g < 0 || g >= ngroups) { set_error("group id %d of sample %lld outside [0,%d)", g, (long long)s, ngroups); return REO_EINVAL; }
+        if (cnt[g] == 0) {
+            if (g != next) { set_error("group ids must be numbered in order of first appearance (unique(), :353)"); return REO_EINVAL; }
+            ++next;
+        }
+        cnt[g]++;
+    }
+    if (next != ngroups) { set_error("%d groups declared but %d appear", ngroups, next); return REO_EINVAL; }
+    c->group_id.assign(group_id, group_id + len);
+    c->ngroups = ngroups;
+    c->thr_set = false;
+    invalidate(c);
+    return REO_OK;
+}
+
+int32_t reo_threshold(int32_t n, double pval_reo) { return major_reo_lower_count(n, pval_reo); }
+
+int32_t reo_compute_thresholds(reo_ctx *c, double pval_reo)
+{
+    if (!c || c->group_id.empty()) { set_error("groups must be set before thresholds"); return REO_EINVAL; }
+    const int32_t S = static_cast<int32_t>(c->group_id.size());
+    std::vector<int32_t> cnt(c->ngroups, 0);
+    for (int32_t g : c->group_id) cnt[g]++;
+    c->thr.assign(2 * c->ngroups, 0);
+    for (int k = 0; k < c->ngroups; ++k) {  // threshold = f.(hcat(gsi1,gsi2)'), :362
+        c->thr[2 * k] = major_reo_lower_count(cnt[k], pval_reo);
+        c->thr[2 * k + 1] = major_reo_lower_count(S - cnt[k], pval_reo);
+        if (c->thr[2 * k] < 0 || c->thr[2 * k + 1] < 0) {
+            set_error("no count in 0..n/2 has a two-sided binomial p above %g (the reference's findfirst returns nothing)", pval_reo);
+            return REO_EINVAL;
+        }
+    }
+    c->thr_set = true;
+    c->built_k = -1;
+    return REO_OK;
+}
+
+int32_t reo_set_thresholds(reo_ctx *c, const int32_t *m)
+{
+    if (!c || !m || c->ngroups < 2) { set_error("groups must be set before thresholds"); return REO_EINVAL; }
+    c->thr.assign(m, m + 2 * c->ngroups);
+    c->thr_set = true;
+    c->built_k = -1;
+    return REO_OK;
+}
+
+int32_t reo_get_thresholds(reo_ctx *c, int32_t *m)
+{
+    if (!c || !m || !c->thr_set) { set_error("thresholds not set"); return REO_EINVAL; }
+    memcpy(m, c->thr.data(), sizeof(int32_t) * c->thr.size());
+    return REO_OK;
+}
+
+int32_t reo_build_pairs(reo_ctx *c, int32_t k)
+{
+    int32_t rc = use(c);
+    if (rc) return rc;
+    if ((rc = ensure_transform(c))) return rc;
+    if (!c->thr_set) { set_error("thresholds not set (reo_compute_thresholds)"); return REO_EINVAL; }
+    if (c->ngroups != 2) {
+        set_error("one-vs-rest with %d groups is not built yet; two groups only", c->ngroups);
+        return REO_EINVAL;
+    }
+    if (k < 0 || k >= c->ngroups) { set_error("comparison %d outside [0,%d)", k, c->ngroups); return REO_EINVAL; }
+    if ((rc = c->table.ensure(static_cast<size_t>(c->G) * kPlanes * c->Wp))) return rc;
+    if ((rc = launch_k1(c, k))) return rc;
+    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->t_ms[5] += 1.0;
+    collect_timings(c);
+    c->built_k = k;
+    return REO_OK;
+}
+
+int32_t reo_pair_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *n_gt, uint16_t *n_eq)
+{
+    int32_t rc = use(c);
+    if (rc) return rc;
+    if ((rc = ensure_transform(c))) return rc;
+    if (!n_gt || !n_eq || i0 < 0 || j0 < 0 || i1 > c->G || j1 > c->G || i0 >= i1 || j0 >= j1) {
+        set_error("bad pair block [%lld,%lld) x [%lld,%lld)", (long long)i0, (long long)i1, (long long)j0, (long long)j1);
+        return REO_EINVAL;
+    }
+    const size_t n = static_cast<size_t>(i1 - i0) * (j1 - j0) * c->ngroups;
+    DevBuf<uint16_t> dg, de;
+    if ((rc = dg.ensure(n)) || (rc = de.ensure(n))) return rc;
+    rc = launch_counts(c, i0, i1, j0, j1, dg.p, de.p);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(n_gt, dg.p, n * 2, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(n_eq, de.p, n * 2, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { set_error("copy-back failed: %s", hipGetErrorString(e)); rc = REO_EHIP; }
+    }
+    dg.release(); de.release();
+    return rc;
+}
+
+int32_t reo_get_codes(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *code)
+{
+    int32_t rc = use(c);
+    if (rc) return rc;
+    if (c->built_k < 0) { set_error("no class table: call reo_build_pairs first"); return REO_EINVAL; }
+    if (!code || i0 < 0 || j0 < 0 || i1 > c->G || j1 > c->G || i0 >= i1 || j0 >= j1) {
+        set_error("bad pair block"); return REO_EINVAL;
+    }
+    const size_t n = static_cast<size_t>(i1 - i0) * (j1 - j0);
+    DevBuf<uint8_t> d;
+    if ((rc = d.ensure(n))) return rc;
+    rc = launch_decode(c, i0, i1, j0, j1, d.p);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(code, d.p, n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { set_error("copy-back failed: %s", hipGetErrorString(e)); rc = REO_EHIP; }
+    }
+    d.release();
+    return rc;
+}
+
+int32_t reo_tally(reo_ctx *c, const uint8_t *ref_mask, int32_t *cont)
+{
+    int32_t rc = use(c);
+    if (rc) return rc;
+    if (c->built_k < 0) { set_error("no class table: call reo_build_pairs first"); return REO_EINVAL; }
+    if (!ref_mask || !cont) { set_error("null argument"); return REO_EINVAL; }
+    if ((rc = ensure_iter_buffers(c))) return rc;
+    int32_t nref = 0;
+    if ((rc = upload_ref(c, ref_mask, 0, &nref))) return rc;
+    if ((rc = launch_k2(c, c->refbits[0].p))) return rc;
+    if ((rc = allreduce_raw(c))) return rc;
+    if ((rc = launch_derive(c, c->refbytes[0].p, nref, 0))) return rc;
+    REO_HIP_CHECK(hipMemcpyAsync(cont, c->cont.p, sizeof(int32_t) * 9 * c->G, hipMemcpyDeviceToHost, c->stream));
+    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    collect_timings(c);
+    return REO_OK;
+}
+
+int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, double padj_deg, int32_t n_iter,
+                          int32_t n_conv, double *result, int32_t *iters_run, int32_t *trace)
+{
+    int32_t rc = use(c);
+    if (rc) return rc;
+    if (c->built_k < 0) { set_error("no class table: call reo_build_pairs first"); return REO_EINVAL; }
+    if (!ref0 || !result) { set_error("null argument"); return REO_EINVAL; }
+    if ((rc = ensure_iter_buffers(c))) return rc;
+    const int64_t G = c->G;
+    // slice bounds of :411, round(Int, x) = round-half-even
+    const int64_t a = static_cast<int64_t>(std::nearbyint(static_cast<double>(G) * 0.05));
+    const int64_t b = static_cast<int64_t>(std::nearbyint(static_cast<double>(G) * 0.95));
+    if (n_iter > 0 && (a < 1 || b > G || b - a + 1 < 2)) {
+        set_error("G = %lld: the slice %lld:%lld of the sorted delta1 vector is out of bounds or too short "
+                  "(the reference throws at src/RankCompV3.jl:411-413)", (long long)G, (long long)a, (long long)b);
+        return REO_EINVAL;
+    }
+    int32_t nref = 0;
+    if ((rc = upload_ref(c, ref0, 0, &nref))) return rc;
+    REO_HIP_CHECK(hipMemsetAsync(c->result.p, 0, sizeof(double) * 15 * G, c->stream));  // zeros(r,15), :398
+    int cur = 0, i_iter = 0, passes = 0;
+    while (i_iter < n_iter) {  // :400
+        if ((rc = launch_k2(c, c->refbits[cur].p))) return rc;
+        if ((rc = allreduce_raw(c))) return rc;
+        tic(c, 3);
+        if ((rc = launch_derive(c, c->refbytes[cur].p, nref, 1))) return rc;
+        if ((rc = launch_stats(c, cur, pval_deg, padj_deg, a, b))) return rc;
+        toc(c);
+        REO_HIP_CHECK(hipMemcpyAsync(c->host_counters, c->counters.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        const int32_t nn = c->host_counters[0];  // sum(inds), :417-418
+        if (trace) { trace[2 * passes] = static_cast<int32_t>(G) - nn; trace[2 * passes + 1] = nn; }
+        ++passes;
+        if (std::abs(nref - nn) < n_conv) break;  // :419-422
+        ++i_iter;                                 // :423
+        cur = 1 - cur;                            // ref_gene_vec = inds, :424
+        nref = nn;
+    }
+    if (iters_run) *iters_run = passes;
+    REO_HIP_CHECK(hipMemcpyAsync(result, c->result.p, sizeof(double) * 15 * G, hipMemcpyDeviceToHost, c->stream));
+    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    collect_timings(c);
+    return REO_OK;
+}
+
+int32_t reo_mccullagh(reo_ctx *c, const int32_t *cont, int64_t n, double *out)
+{
+    int32_t rc = use(c);
+    if (rc) return rc;
+    if (!cont || !out || n < 1) { set_error("bad argument"); return REO_EINVAL; }
+    DevBuf<int32_t> dc;
+    DevBuf<double> dout;
+    if ((rc = dc.ensure(n * 9)) || (rc = dout.ensure(n * 5))) return rc;
+    hipError_t e = hipMemcpyAsync(dc.p, cont, sizeof(int32_t) * 9 * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = launch_mccullagh(c, dc.p, n, dout.p);
+        if (!rc) {
+            e = hipMemcpyAsync(out, dout.p, sizeof(double) * 5 * n, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    if (e != hipSuccess) { set_error("HIP failure: %s", hipGetErrorString(e)); rc = REO_EHIP; }
+    dc.release(); dout.release();
+    return rc;
+}
+
+int32_t reo_set_profiling(reo_ctx *c, int32_t on)
+{
+    if (!c) { set_error("null context"); return REO_EINVAL; }
+    c->profiling = on != 0;
+    return REO_OK;
+}
+
+int32_t reo_reset_timings(reo_ctx *c)
+{
+    if (!c) { set_error("null context"); return REO_EINVAL; }
+    collect_timings(c);
+    for (double &v : c->t_ms) v = 0.0;
+    return REO_OK;
+}
+
+int32_t reo_get_timings(reo_ctx *c, double *ms, int32_t n)
+{
+    if (!c || !ms) { set_error("null argument"); return REO_EINVAL; }
+    collect_timings(c);
+    for (int i = 0; i < n && i < REO_NTIMINGS; ++i) ms[i] = c->t_ms[i];
+    return REO_OK;
+}
+
+int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
+{
+    if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
+    const int64_t v[7] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
+                          c->tiles_owned, c->tiles_total};
+    for (int i = 0; i < n && i < 7; ++i) info[i] = v[i];
+    return REO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,614 @@
+// Hand-written gfx950 kernels of the REO hot path.
+//
+//   K1  k1_pairs    pair compare -> per-group counts -> stable-REO class ->
+//                   4 bit planes per ordered pair      (src/RankCompV3.jl:363-392)
+//   K2  k2_tally    class table x reference mask -> per-gene tallies   (:403)
+//   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask (:404-417,225-259)
+//
+// All file:line citations are relative to /root/reference.
+//
+// Data layout in HBM
+//   pos  u16 [S][Gp]   position of gene g in sample s's sorted order (lane operand)
+//   lo   u32 [S][Gp]   first position of g's tie band   (wave-uniform operand -> s_load)
+//   hi   u32 [S][Gp]   one past the last position of g's tie band
+//   table u32 [G][4][Wp]  bit planes cL cH tL tH of row i: bit j of plane cL is
+//                   set iff pair (i,j) is "i<j stable" in ctrl (ic==1), cH iff
+//                   ic==3, tL/tH likewise for treat.  4 bits per ORDERED pair,
+//                   the diagonal is all-zero (like the reference's R, :363).
+//
+// Wave = 64 lanes everywhere; no warp-32 idiom is used.
+#include "reo_internal.h"
+
+namespace reo {
+
+namespace {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// Binomial(n_eq, 1/2) draw standing in for n_eq calls of rand(Bool) in
+// is_greater (:72-73): one bit of a counter-based stream keyed by
+// (seed, i, j, group) per tied sample.
+__device__ uint32_t tie_wins(uint64_t seed, uint32_t i, uint32_t j, uint32_t g, uint32_t n_eq)
+{
+    uint64_t base = mix64(seed ^ mix64((static_cast<uint64_t>(i) << 32) | j)) + (static_cast<uint64_t>(g) << 40);
+    uint32_t wins = 0;
+    for (uint64_t w = 0; n_eq > 0; ++w) {
+        uint64_t bits = mix64(base + w);
+        uint32_t take = n_eq < 64 ? n_eq : 64;
+        if (take < 64) bits &= (1ULL << take) - 1;
+        wins += __popcll(bits);
+        n_eq -= take;
+    }
+    return wins;
+}
+
+// ---------------------------------------------------------------------------
+// K1 inner loop.  Lane = gene j, the RI genes i of the tile are wave-uniform:
+// their band edges arrive through the scalar cache (s_load_dwordx16) and each
+// comparison is one v_cmp into a lane mask plus one v_addc that consumes it
+// as carry-in -- 2 VALU ops per (pair, sample) without ties, 4 with.
+// n_gt(i,j) = #{s : pos_j < lo_i},  n_ge(i,j) = #{s : pos_j < hi_i}.
+template <int RI, bool TIES>
+__device__ __forceinline__ void count_pass(const uint16_t *__restrict__ pos, const uint32_t *__restrict__ lo,
+                                           const uint32_t *__restrict__ hi, int Gp, int i0, int j, int sb,
+                                           int se, uint32_t (&gt)[RI], uint32_t (&ge)[RI])
+{
+#pragma unroll
+    for (int ii = 0; ii < RI; ++ii) { gt[ii] = 0; ge[ii] = 0; }
+    const uint16_t *pb = pos + static_cast<size_t>(sb) * Gp + j;
+    const uint32_t *pl = lo + static_cast<size_t>(sb) * Gp + i0;
+    const uint32_t *ph = hi + static_cast<size_t>(sb) * Gp + i0;
+    for (int s = sb; s < se; ++s) {
+        const uint32_t b = *pb;
+#pragma unroll
+        for (int ii = 0; ii < RI; ++ii) {
+            gt[ii] += (b < pl[ii]) ? 1u : 0u;
+            if (TIES) ge[ii] += (b < ph[ii]) ? 1u : 0u;
+        }
+        pb += Gp; pl += Gp; ph += Gp;
+    }
+}
+
+struct K1Args {
+    const uint16_t *pos;
+    const uint32_t *lo;
+    const uint32_t *hi;
+    uint32_t *table;
+    int G, Gp, Wp;
+    int cb, ce, tb, te;  // ctrl / treat sample ranges in the sorted order
+    int gc, gt;          // their group ids (tie-stream key)
+    int nc, nt;          // group sizes gsi1, gsi2 (:358-359)
+    int m1, m2;          // threshold[1,k], threshold[2,k] (:362)
+    uint64_t seed;
+    int rank, world;
+};
+
+// state of one side: 0 = "i<j stable" (reference 1), 1 = unstable (2), 2 = "i>j stable" (3)  (:376-377)
+__device__ __forceinline__ int side_state(int n, int size, int m) { return n >= m ? 2 : ((size - n) >= m ? 0 : 1); }
+
+template <int RI, bool TIES>
+__global__ __launch_bounds__(256) void k1_pairs(K1Args a)
+{
+    static_assert(RI == 32, "one mirror word per tile");
+    const int lane = threadIdx.x & 63;
+    const int i0 = blockIdx.y * RI;
+    const int j = blockIdx.x * kTileJ + threadIdx.x;
+    const int bj = j >> 6, bi = i0 >> 6;  // 64-gene blocks; bj is wave-uniform
+    if (bj < bi) return;                  // strictly below the diagonal: the mirror of another tile
+    if (a.world > 1 && static_cast<int>((blockIdx.x + blockIdx.y) % a.world) != a.rank) return;
+
+    uint32_t gt[RI], ge[RI];
+    uint32_t cL = 0, cH = 0, tL = 0, tH = 0;
+
+    count_pass<RI, TIES>(a.pos, a.lo, a.hi, a.Gp, i0, j, a.cb, a.ce, gt, ge);
+#pragma unroll
+    for (int ii = 0; ii < RI; ++ii) {
+        int nre = gt[ii];
+        if (TIES) {
+            const uint32_t neq = ge[ii] - gt[ii];
+            if (neq) nre += tie_wins(a.seed, i0 + ii, j, a.gc, neq);
+        }
+        const int st = side_state(nre, a.nc, a.m1);
+        cL |= (st == 0 ? 1u : 0u) << ii;
+        cH |= (st == 2 ? 1u : 0u) << ii;
+    }
+    count_pass<RI, TIES>(a.pos, a.lo, a.hi, a.Gp, i0, j, a.tb, a.te, gt, ge);
+#pragma unroll
+    for (int ii = 0; ii < RI; ++ii) {
+        int nre = gt[ii];
+        if (TIES) {
+            const uint32_t neq = ge[ii] - gt[ii];
+            if (neq) nre += tie_wins(a.seed, i0 + ii, j, a.gt, neq);
+        }
+        const int st = side_state(nre, a.nt, a.m2);
+        tL |= (st == 0 ? 1u : 0u) << ii;
+        tH |= (st == 2 ? 1u : 0u) << ii;
+    }
+
+    // only pairs i < j < G are real; everything else contributes zero bits
+    uint32_t vm = 0;
+    if (j < a.G) {
+        const int d = j - i0;  // rows i0+ii with ii < d are above the diagonal
+        vm = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1u));
+    }
+    cL &= vm; cH &= vm; tL &= vm; tH &= vm;
+
+    const bool diag = (bj == bi);
+    // forward bits: row i, 64-bit word of columns [64*bj, 64*bj+64) = ballot over the lanes
+    unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+#pragma unroll
+    for (int ii = 0; ii < RI; ++ii) {
+        const unsigned long long b0 = __ballot((cL >> ii) & 1u);
+        const unsigned long long b1 = __ballot((cH >> ii) & 1u);
+        const unsigned long long b2 = __ballot((tL >> ii) & 1u);
+        const unsigned long long b3 = __ballot((tH >> ii) & 1u);
+        if (lane == ii) { f0 = b0; f1 = b1; f2 = b2; f3 = b3; }
+    }
+    if (lane < RI && i0 + lane < a.G) {
+        uint32_t *row = a.table + static_cast<size_t>(i0 + lane) * kPlanes * a.Wp + 2 * bj;
+        if (!diag) {
+            *reinterpret_cast<unsigned long long *>(row) = f0;
+            *reinterpret_cast<unsigned long long *>(row + a.Wp) = f1;
+            *reinterpret_cast<unsigned long long *>(row + 2 * a.Wp) = f2;
+            *reinterpret_cast<unsigned long long *>(row + 3 * a.Wp) = f3;
+        } else {
+            const unsigned long long f[4] = {f0, f1, f2, f3};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (static_cast<uint32_t>(f[p])) atomicOr(row + p * a.Wp, static_cast<uint32_t>(f[p]));
+                if (static_cast<uint32_t>(f[p] >> 32)) atomicOr(row + p * a.Wp + 1, static_cast<uint32_t>(f[p] >> 32));
+            }
+        }
+    }
+    // mirror bits (:386): pair (j,i) is in state 2 - state(i,j) on both sides -> L and H swap
+    if (j < a.G) {
+        uint32_t *row = a.table + static_cast<size_t>(j) * kPlanes * a.Wp + (i0 >> 5);
+        if (!diag) {
+            row[0] = cH; row[a.Wp] = cL; row[2 * a.Wp] = tH; row[3 * a.Wp] = tL;
+        } else {
+            if (cH) atomicOr(row, cH);
+            if (cL) atomicOr(row + a.Wp, cL);
+            if (tH) atomicOr(row + 2 * a.Wp, tH);
+            if (tL) atomicOr(row + 3 * a.Wp, tL);
+        }
+    }
+}
+
+// Parity hook: same inner loop, writes the raw counts of a block of ordered pairs.
+template <int RI>
+__global__ __launch_bounds__(256) void k1_counts(const uint16_t *__restrict__ pos, const uint32_t *__restrict__ lo,
+                                                 const uint32_t *__restrict__ hi, int Gp,
+                                                 const int32_t *__restrict__ goff, int ngroups, int ibase,
+                                                 int jbase, int ci0, int ci1, int cj0, int cj1,
+                                                 uint16_t *__restrict__ out_gt, uint16_t *__restrict__ out_eq)
+{
+    const int i0 = ibase + blockIdx.y * RI;
+    const int j = jbase + blockIdx.x * kTileJ + threadIdx.x;
+    uint32_t gt[RI], ge[RI];
+    const int nj = cj1 - cj0;
+    for (int g = 0; g < ngroups; ++g) {
+        count_pass<RI, true>(pos, lo, hi, Gp, i0, j, goff[g], goff[g + 1], gt, ge);
+        if (j >= cj0 && j < cj1) {
+#pragma unroll
+            for (int ii = 0; ii < RI; ++ii) {
+                const int i = i0 + ii;
+                if (i >= ci0 && i < ci1) {
+                    const size_t o = (static_cast<size_t>(i - ci0) * nj + (j - cj0)) * ngroups + g;
+                    out_gt[o] = static_cast<uint16_t>(gt[ii]);
+                    out_eq[o] = static_cast<uint16_t>(ge[ii] - gt[ii]);
+                }
+            }
+        }
+    }
+}
+
+// Parity hook: decode the bit planes of a block into class codes 0..8.
+__global__ void k_decode(const uint32_t *__restrict__ table, int Wp, int i0, int i1, int j0, int j1,
+                         uint8_t *__restrict__ code)
+{
+    const int j = j0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = i0 + blockIdx.y;
+    if (j >= j1 || i >= i1) return;
+    const uint32_t *row = table + static_cast<size_t>(i) * kPlanes * Wp + (j >> 5);
+    const uint32_t sh = j & 31;
+    const int l = (row[0] >> sh) & 1, h = (row[Wp] >> sh) & 1;
+    const int tl = (row[2 * Wp] >> sh) & 1, th = (row[3 * Wp] >> sh) & 1;
+    const int ic = l ? 0 : (h ? 2 : 1), it = tl ? 0 : (th ? 2 : 1);
+    code[static_cast<size_t>(i - i0) * (j1 - j0) + (j - j0)] = (i == j) ? 255 : static_cast<uint8_t>(3 * ic + it);
+}
+
+// bytes -> bit mask (one workgroup-wide ballot per 64 genes)
+__global__ __launch_bounds__(256) void k_pack_ref(const uint8_t *__restrict__ bytes, int Gp,
+                                                  uint32_t *__restrict__ bits)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long m = __ballot(g < Gp && bytes[g] != 0);
+    if ((threadIdx.x & 63) == 0) {
+        bits[g >> 5] = static_cast<uint32_t>(m);
+        bits[(g >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: one wave per gene row.  Streams the row's four planes (16 B per lane per
+// load, fully coalesced), ANDs with the reference mask and popcounts.  Raw
+// counters: 0 cL, 1 cH, 2 tL, 3 tH (marginals), 4 LL, 5 LH, 6 HL, 7 HH.  They
+// are linear in the table, so shards can be summed before the 9 tallies are
+// derived (k3_derive).  HBM-bound: 16 VALU ops per 32 pairs.
+__device__ __forceinline__ void tally_word(uint32_t cl, uint32_t ch, uint32_t tl, uint32_t th, uint32_t m,
+                                           uint32_t (&c)[kRaw])
+{
+    cl &= m; ch &= m; tl &= m; th &= m;
+    c[0] += __popc(cl); c[1] += __popc(ch); c[2] += __popc(tl); c[3] += __popc(th);
+    c[4] += __popc(cl & tl); c[5] += __popc(cl & th); c[6] += __popc(ch & tl); c[7] += __popc(ch & th);
+}
+
+__global__ __launch_bounds__(256) void k2_tally(const uint4 *__restrict__ table, const uint4 *__restrict__ refbits,
+                                                int G, int Wq, int32_t *__restrict__ raw)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= G) return;
+    const uint4 *r = table + static_cast<size_t>(row) * kPlanes * Wq;
+    uint32_t c[kRaw] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = lane; q < Wq; q += 64) {
+        const uint4 m = refbits[q];
+        const uint4 cl = r[q], ch = r[Wq + q], tl = r[2 * Wq + q], th = r[3 * Wq + q];
+        tally_word(cl.x, ch.x, tl.x, th.x, m.x, c);
+        tally_word(cl.y, ch.y, tl.y, th.y, m.y, c);
+        tally_word(cl.z, ch.z, tl.z, th.z, m.z, c);
+        tally_word(cl.w, ch.w, tl.w, th.w, m.w, c);
+    }
+#pragma unroll
+    for (int t = 0; t < kRaw; ++t) {
+        uint32_t v = c[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        c[t] = v;
+    }
+    if (lane == 0) {
+        int4 *o = reinterpret_cast<int4 *>(raw + static_cast<size_t>(row) * kRaw);
+        o[0] = make_int4(c[0], c[1], c[2], c[3]);
+        o[1] = make_int4(c[4], c[5], c[6], c[7]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3.  McCullagh's test for a 3x3 table, closed form of :225-259.
+//   N = [[a b][b d]], n = (a, d), R = (R1, R2); singular iff a*d == b*b (exact
+//   integer test, equivalent to abs(det(N)) <= eps() for integer N, :242).
+__device__ void mccullagh3(const int32_t *n, double *out)
+{
+    const long long n12 = n[1], n13 = n[2], n21 = n[3], n23 = n[5], n31 = n[6], n32 = n[7];
+    const long long a = n12 + n13 + n21 + n31;  // N11  (:232)
+    const long long b = n13 + n31;              // N12
+    const long long d = n13 + n23 + n31 + n32;  // N22
+    const long long R1 = n12 + n13, R2 = n13 + n23;  // :239
+    const long long det = a * d - b * b;
+    if (det == 0) { out[0] = 1.0; out[1] = out[2] = out[3] = out[4] = 0.0; return; }
+    const double fa = static_cast<double>(a), fd = static_cast<double>(d), fdet = static_cast<double>(det);
+    const double w1 = static_cast<double>(d * (a - b)) / fdet;  // omega2 = inv(N) n  (:246)
+    const double w2 = static_cast<double>(a * (d - b)) / fdet;
+    const double nu = 1.0 / (fa * w1 + fd * w2);                // :247
+    const double r1 = static_cast<double>(R1), r2 = static_cast<double>(R2);
+    const double d1 = (fa * w1 * nu) * log((r1 + 0.5) / (fa - r1 + 0.5)) +
+                      (fd * w2 * nu) * log((r2 + 0.5) / (fd - r2 + 0.5));  // :248-249
+    const double A = w1 * r1 + w2 * r2, B = w1 * (fa - r1) + w2 * (fd - r2);
+    const double d2 = log((0.5 + A) / (0.5 + B));               // :250
+    const double v1 = 4.0 * (1.0 + 0.25 * d1 * d1) * nu;        // :251
+    const double v2 = 4.0 * (1.0 + 0.25 * d2 * d2) * nu;        // :252
+    const double se = sqrt((v1 + v2) * 0.5);                    // :253
+    const double z1 = d1 / se;                                  // :254
+    double p = erfc(fabs(z1) * 0.70710678118654752440);         // 2*min(cdf, ccdf), :255
+    out[0] = p > 1.0 ? 1.0 : p;
+    out[1] = d1; out[2] = d2; out[3] = se; out[4] = z1;
+}
+
+__global__ void k_mccullagh(const int32_t *__restrict__ cont, int64_t n, double *__restrict__ out)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t c[9];
+    for (int t = 0; t < 9; ++t) c[t] = cont[i * 9 + t];
+    double o[5];
+    mccullagh3(c, o);
+    for (int t = 0; t < 5; ++t) out[i * 5 + t] = o[t];
+}
+
+// raw counters -> 9 tallies (:403) [-> McCullagh -> result columns 3..15 (:404-405)]
+__global__ __launch_bounds__(256) void k3_derive(const int32_t *__restrict__ raw,
+                                                 const uint8_t *__restrict__ refbytes, int nref, int G,
+                                                 int32_t *__restrict__ cont, double *__restrict__ result,
+                                                 int32_t *__restrict__ counters, int with_stats)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && counters) counters[0] = 0;
+    if (i >= G) return;
+    const int4 r0 = reinterpret_cast<const int4 *>(raw)[2 * i], r1 = reinterpret_cast<const int4 *>(raw)[2 * i + 1];
+    const int cLt = r0.x, cHt = r0.y, tLt = r0.z, tHt = r0.w, LL = r1.x, LH = r1.y, HL = r1.z, HH = r1.w;
+    const int total = nref - (refbytes[i] ? 1 : 0);  // the diagonal is never set (:363,385)
+    int32_t c[9];
+    c[0] = LL; c[2] = LH; c[6] = HL; c[8] = HH;
+    c[1] = cLt - LL - LH;
+    c[7] = cHt - HL - HH;
+    c[3] = tLt - LL - HL;
+    c[5] = tHt - LH - HH;
+    c[4] = total - (cLt + cHt + c[3] + c[5]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) cont[static_cast<size_t>(i) * 9 + t] = c[t];
+    if (!with_stats) return;
+    double o[5];
+    mccullagh3(c, o);
+    const size_t Gs = G;
+    result[i] = o[0];
+    result[Gs + i] = 1.0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) result[(2 + t) * Gs + i] = static_cast<double>(c[t]);
+    result[11 * Gs + i] = o[1]; result[12 * Gs + i] = o[2];
+    result[13 * Gs + i] = o[3]; result[14 * Gs + i] = o[4];
+}
+
+// Ranks by exhaustive comparison (G <= 65535: G^2 compares is microseconds on
+// 256 CUs and needs no multi-pass sort).  rs = rank of delta1 ascending (the
+// sort of :409), ra = rank of |delta1| descending = rank of pval ascending
+// (pval is a decreasing function of |delta1|, :412).  Index breaks ties, so
+// both are permutations.  Also scatters delta1 into sorted order.
+__global__ __launch_bounds__(256) void k3_rank(const double *__restrict__ d1, int G, uint32_t *__restrict__ rs,
+                                               uint32_t *__restrict__ ra, double *__restrict__ sorted_d)
+{
+    __shared__ double tile[1024];
+    const int ib = blockIdx.x * 256;
+    const int i = ib + threadIdx.x;
+    const double vi = i < G ? d1[i] : 0.0;
+    const double ai = fabs(vi);
+    uint32_t cs = 0, ca = 0;
+    for (int j0 = 0; j0 < G; j0 += 1024) {
+        const int n = min(1024, G - j0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < n; t += 256) tile[t] = d1[j0 + t];
+        __syncthreads();
+        if (j0 + n <= ib) {  // every j < i
+            for (int t = 0; t < n; ++t) {
+                const double v = tile[t];
+                cs += (v <= vi) ? 1u : 0u;
+                ca += (fabs(v) >= ai) ? 1u : 0u;
+            }
+        } else if (j0 >= ib + 256) {  // every j > i
+            for (int t = 0; t < n; ++t) {
+                const double v = tile[t];
+                cs += (v < vi) ? 1u : 0u;
+                ca += (fabs(v) > ai) ? 1u : 0u;
+            }
+        } else {
+            for (int t = 0; t < n; ++t) {
+                const double v = tile[t];
+                const bool before = (j0 + t) < i;
+                cs += (v < vi || (v == vi && before)) ? 1u : 0u;
+                ca += (fabs(v) > ai || (fabs(v) == ai && before)) ? 1u : 0u;
+            }
+        }
+    }
+    if (i < G) { rs[i] = cs; ra[i] = ca; sorted_d[cs] = vi; }
+}
+
+// std(sorted[a..b]) with the n-1 estimator (:411), fixed-order tree reduction.
+__global__ __launch_bounds__(1024) void k3_trimmed_std(const double *__restrict__ sorted_d, int a, int b,
+                                                       double *__restrict__ scal)
+{
+    __shared__ double red[1024];
+    const int n = b - a + 1;
+    double s = 0.0;
+    for (int t = a + threadIdx.x; t <= b; t += 1024) s += sorted_d[t];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (static_cast<int>(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double mean = red[0] / n;
+    __syncthreads();
+    double q = 0.0;
+    for (int t = a + threadIdx.x; t <= b; t += 1024) { const double e = sorted_d[t] - mean; q += e * e; }
+    red[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (static_cast<int>(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scal[0] = sqrt(red[0] / (n - 1));
+}
+
+// pval = pvalue(Normal(0,se), delta1, tail=:both) (:412) -> column 1, and into rank order
+__global__ __launch_bounds__(256) void k3_pvals(const double *__restrict__ d1, const double *__restrict__ scal,
+                                                const uint32_t *__restrict__ ra, int G,
+                                                double *__restrict__ pval, double *__restrict__ sorted_p)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G) return;
+    const double se = scal[0];
+    double p;
+    if (se == 0.0) {
+        p = 0.0;  // Normal(0,0): cdf/ccdf degenerate to a step, the smaller tail is 0
+    } else {
+        const double z = fabs(d1[i]) / se;
+        p = erfc(z * 0.70710678118654752440);
+        p = p > 1.0 ? 1.0 : p;
+    }
+    pval[i] = p;
+    sorted_p[ra[i]] = p;
+}
+
+// Benjamini-Hochberg step-up over the sorted p-values (:413): p_(r) * (n/r),
+// reverse cumulative minimum, in place.  One workgroup, contiguous chunk per thread.
+__global__ __launch_bounds__(1024) void k3_bh_scan(double *__restrict__ sorted_p, int G)
+{
+    __shared__ double red[1024];
+    const int chunk = (G + 1023) / 1024;
+    const int lo = threadIdx.x * chunk, hi = min(G, lo + chunk);
+    const double n = static_cast<double>(G);
+    double run = INFINITY;
+    for (int r = hi - 1; r >= lo; --r) {
+        const double a = sorted_p[r] * (n / static_cast<double>(r + 1));
+        run = a < run ? a : run;
+        sorted_p[r] = run;
+    }
+    red[threadIdx.x] = run;
+    __syncthreads();
+    // suffix minimum across threads (inclusive), Hillis-Steele
+    for (int o = 1; o < 1024; o <<= 1) {
+        double v = red[threadIdx.x];
+        if (threadIdx.x + o < 1024) { const double w = red[threadIdx.x + o]; v = w < v ? w : v; }
+        __syncthreads();
+        red[threadIdx.x] = v;
+        __syncthreads();
+    }
+    const double tail = threadIdx.x + 1 < 1024 ? red[threadIdx.x + 1] : INFINITY;
+    for (int r = lo; r < hi; ++r) {
+        const double v = sorted_p[r];
+        sorted_p[r] = tail < v ? tail : v;
+    }
+}
+
+// padj -> column 2 (:416); non-DEG mask inds (:417) as bytes and bits; count of non-DEGs
+__global__ __launch_bounds__(256) void k3_finalize(const double *__restrict__ pval,
+                                                   const double *__restrict__ sufmin,
+                                                   const uint32_t *__restrict__ ra, int G, int Gp,
+                                                   double pval_deg, double padj_deg, double *__restrict__ padj,
+                                                   uint8_t *__restrict__ nbytes, uint32_t *__restrict__ nbits,
+                                                   int32_t *__restrict__ counters)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool ind = false;
+    if (i < G) {
+        double q = sufmin[ra[i]];
+        q = q < 1.0 ? q : 1.0;
+        padj[i] = q;
+        ind = !(pval[i] <= pval_deg && q <= padj_deg);
+    }
+    if (i < Gp) nbytes[i] = ind ? 1 : 0;
+    const unsigned long long m = __ballot(ind);
+    if ((threadIdx.x & 63) == 0 && i < Gp) {
+        nbits[i >> 5] = static_cast<uint32_t>(m);
+        nbits[(i >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+        if (m) atomicAdd(counters, __popcll(m));
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+
+int32_t launch_k1(reo_ctx *c, int k)
+{
+    K1Args a;
+    a.pos = c->pos.p; a.lo = c->lo.p; a.hi = c->hi.p; a.table = c->table.p;
+    a.G = static_cast<int>(c->G); a.Gp = c->Gp; a.Wp = c->Wp;
+    const int other = 1 - k;  // two groups
+    a.cb = c->goff[k]; a.ce = c->goff[k + 1];
+    a.tb = c->goff[other]; a.te = c->goff[other + 1];
+    a.gc = k; a.gt = other;
+    a.nc = a.ce - a.cb; a.nt = a.te - a.tb;
+    a.m1 = c->thr[2 * k]; a.m2 = c->thr[2 * k + 1];
+    a.seed = c->seed; a.rank = c->rank; a.world = c->world;
+    dim3 grid(c->Gp / kTileJ, c->Gp / kTileI);
+    REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
+    tic(c, 1);
+    if (c->has_ties)
+        k1_pairs<kTileI, true><<<grid, 256, 0, c->stream>>>(a);
+    else
+        k1_pairs<kTileI, false><<<grid, 256, 0, c->stream>>>(a);
+    toc(c);
+    REO_HIP_CHECK(hipGetLastError());
+    // tile census for reporting
+    int64_t owned = 0, total = 0;
+    for (int y = 0; y < static_cast<int>(grid.y); ++y)
+        for (int x = 0; x < static_cast<int>(grid.x); ++x) {
+            if (x * 4 + 3 < (y * kTileI) / 64) continue;
+            ++total;
+            if (c->world == 1 || (x + y) % c->world == c->rank) ++owned;
+        }
+    c->tiles_owned = owned; c->tiles_total = total;
+    return REO_OK;
+}
+
+int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq)
+{
+    const int ibase = static_cast<int>(i0 / kTileI) * kTileI, jbase = static_cast<int>(j0 / kTileJ) * kTileJ;
+    dim3 grid(static_cast<unsigned>((j1 - jbase + kTileJ - 1) / kTileJ),
+              static_cast<unsigned>((i1 - ibase + kTileI - 1) / kTileI));
+    k1_counts<kTileI><<<grid, 256, 0, c->stream>>>(c->pos.p, c->lo.p, c->hi.p, c->Gp, c->goff_dev.p, c->ngroups,
+                                                   ibase, jbase, static_cast<int>(i0), static_cast<int>(i1),
+                                                   static_cast<int>(j0), static_cast<int>(j1), d_gt, d_eq);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code)
+{
+    dim3 grid(static_cast<unsigned>((j1 - j0 + 255) / 256), static_cast<unsigned>(i1 - i0));
+    k_decode<<<grid, 256, 0, c->stream>>>(c->table.p, c->Wp, static_cast<int>(i0), static_cast<int>(i1),
+                                          static_cast<int>(j0), static_cast<int>(j1), d_code);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits)
+{
+    k_pack_ref<<<c->Gp / 256, 256, 0, c->stream>>>(d_bytes, c->Gp, d_bits);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits)
+{
+    const int G = static_cast<int>(c->G);
+    tic(c, 2);
+    k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(reinterpret_cast<const uint4 *>(c->table.p),
+                                                 reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp / 4,
+                                                 c->raw.p);
+    toc(c);
+    c->t_ms[4] += 1.0;
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int32_t nref, int with_stats)
+{
+    const int G = static_cast<int>(c->G);
+    k3_derive<<<(G + 255) / 256, 256, 0, c->stream>>>(c->raw.p, d_refbytes, nref, G, c->cont.p, c->result.p,
+                                                      c->counters.p, with_stats);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int64_t a, int64_t b)
+{
+    const int G = static_cast<int>(c->G);
+    const int nb = (G + 255) / 256;
+    double *res = c->result.p;
+    k3_rank<<<nb, 256, 0, c->stream>>>(res + 11 * c->G, G, c->rank_s.p, c->rank_a.p, c->sorted_d.p);
+    k3_trimmed_std<<<1, 1024, 0, c->stream>>>(c->sorted_d.p, static_cast<int>(a - 1), static_cast<int>(b - 1),
+                                              c->scal.p);
+    k3_pvals<<<nb, 256, 0, c->stream>>>(res + 11 * c->G, c->scal.p, c->rank_a.p, G, res, c->sorted_p.p);
+    k3_bh_scan<<<1, 1024, 0, c->stream>>>(c->sorted_p.p, G);
+    k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(res, c->sorted_p.p, c->rank_a.p, G, c->Gp, pval_deg, padj_deg,
+                                                    res + c->G, c->refbytes[1 - cur].p, c->refbits[1 - cur].p,
+                                                    c->counters.p);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out)
+{
+    k_mccullagh<<<static_cast<unsigned>((n + 255) / 256), 256, 0, c->stream>>>(d_cont, n, d_out);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+}  // namespace reo

@@ -1,0 +1,131 @@
+// Internal declarations shared by the translation units of libreo_hip.so.
+// Public C ABI: include/reo_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "reo_hip.h"
+
+namespace reo {
+
+constexpr int kTileJ = 256;   // genes per workgroup along j (4 waves x 64 lanes)
+constexpr int kTileI = 32;    // gene rows per pair tile (one mirror word)
+constexpr int kPlanes = 4;    // cL cH tL tH
+constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
+
+void set_error(const char *fmt, ...);
+
+#define REO_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            ::reo::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                             __FILE__, __LINE__);                                        \
+            return e_ == hipErrorOutOfMemory ? REO_ENOMEM : REO_EHIP;                    \
+        }                                                                                \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int32_t ensure(size_t count)
+    {
+        if (count <= n && p) return REO_OK;
+        release();
+        REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        n = count;
+        return REO_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct StageTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace reo
+
+struct reo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t seed = 0;
+    int rank = 0, world = 1;
+    reo_allreduce_fn ar = nullptr;
+    void *ar_user = nullptr;
+
+    // problem
+    int64_t G = 0, S = 0, ld = 0;
+    int dtype = 0;  // 0 none, 1 f64, 2 i64
+    const void *dX = nullptr;
+    reo::DevBuf<unsigned char> dX_owned;
+    std::vector<int32_t> group_id;
+    int ngroups = 0;
+    std::vector<int32_t> thr;  // 2 x ngroups
+    bool thr_set = false;
+
+    // rank/band transform output (samples re-ordered so groups are contiguous)
+    int Gp = 0, Wp = 0;  // padded gene count, 32-bit words per bit row
+    std::vector<int32_t> goff;  // ngroups+1 offsets into the sorted sample order
+    reo::DevBuf<uint16_t> pos;  // [S][Gp] position of gene in its sample's sorted order
+    reo::DevBuf<uint32_t> lo;   // [S][Gp] first position of the tie band
+    reo::DevBuf<uint32_t> hi;   // [S][Gp] one past the last position of the tie band
+    reo::DevBuf<int32_t> goff_dev;
+    bool transformed = false;
+    int has_ties = 0;
+
+    // class table: [G][4 planes][Wp] 32-bit words
+    reo::DevBuf<uint32_t> table;
+    int built_k = -1;
+    int64_t tiles_owned = 0, tiles_total = 0;
+
+    // iteration state
+    reo::DevBuf<uint32_t> refbits[2];   // [Wp]
+    reo::DevBuf<uint8_t> refbytes[2];   // [Gp]
+    reo::DevBuf<int32_t> raw;           // [G][8]
+    reo::DevBuf<int32_t> cont;          // [G][9]
+    reo::DevBuf<double> result;         // [15][G]
+    reo::DevBuf<double> sorted_d;       // [G]
+    reo::DevBuf<double> sorted_p;       // [G]
+    reo::DevBuf<uint32_t> rank_s, rank_a;  // [G]
+    reo::DevBuf<double> scal;           // [8] device scalars (se, ...)
+    reo::DevBuf<int32_t> counters;      // [8]
+    int32_t *host_counters = nullptr;   // pinned
+
+    // timing
+    bool profiling = false;
+    double t_ms[REO_NTIMINGS] = {0};
+    std::vector<std::pair<int, reo::StageTimer>> pending;  // (slot, events)
+    std::vector<reo::StageTimer> pool;
+};
+
+namespace reo {
+
+// transform.hip
+int32_t run_transform(reo_ctx *c);
+
+// kernels.hip
+int32_t launch_k1(reo_ctx *c, int k);
+int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq);
+int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
+int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
+int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits);
+int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int32_t nref, int with_stats);
+int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int64_t a, int64_t b);
+int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
+
+// timing helpers (api.hip)
+void tic(reo_ctx *c, int slot);
+void toc(reo_ctx *c);
+void collect_timings(reo_ctx *c);
+
+}  // namespace reo

@@ -1,0 +1,203 @@
+// Per-sample rank/band transform.
+//
+// The reference compares raw values pair by pair with is_greater
+// (/root/reference/src/RankCompV3.jl:71-77): tie iff abs(x - y) < 0.1, else
+// x > y.  For one sample, sort the genes by value; fl(x - y) is monotone in y,
+// so the genes tied with a gene form a contiguous band [lo, hi] around its
+// position p in that order, and every gene outside the band is ordered by
+// position.  Hence for genes i, j of one sample
+//     tie(i, j)            <=>  lo_i <= pos_j <= hi_i
+//     x_i > x_j, not tied  <=>  pos_j <  lo_i
+// which turns the float (0.1-band) and the integer (equality) comparators
+// into the same two 16-bit integer compares for the pair kernel.  The band
+// edges are found with the reference's own predicate evaluated in the input's
+// arithmetic, so the result is exact, not approximate.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <numeric>
+
+#include "reo_internal.h"
+
+namespace reo {
+
+namespace {
+
+template <class T>
+struct Codec;
+
+template <>
+struct Codec<double> {
+    __device__ static uint64_t enc(double x)
+    {
+        uint64_t u = __double_as_longlong(x);
+        return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+    }
+    __device__ static double dec(uint64_t k)
+    {
+        uint64_t u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+        return __longlong_as_double(u);
+    }
+    __device__ static bool tie(double x, double y) { return fabs(x - y) < 0.1; }
+    __device__ static bool finite(double x) { return isfinite(x); }
+};
+
+template <>
+struct Codec<int64_t> {
+    __device__ static uint64_t enc(int64_t x) { return static_cast<uint64_t>(x) ^ 0x8000000000000000ULL; }
+    __device__ static int64_t dec(uint64_t k) { return static_cast<int64_t>(k ^ 0x8000000000000000ULL); }
+    // abs(x - y) < 0.1 on Int64 <=> x == y
+    __device__ static bool tie(int64_t x, int64_t y) { return x == y; }
+    __device__ static bool finite(int64_t) { return true; }
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void t_keys(const T *__restrict__ X, int64_t ld,
+                                              const int32_t *__restrict__ colmap, int G, int cb0,
+                                              uint64_t *__restrict__ keys, uint16_t *__restrict__ idx,
+                                              int32_t *__restrict__ bad)
+{
+    int g = blockIdx.x * 256 + threadIdx.x;
+    int c = blockIdx.y;
+    if (g >= G) return;
+    T x = X[static_cast<int64_t>(g) + static_cast<int64_t>(colmap[cb0 + c]) * ld];
+    if (!Codec<T>::finite(x)) atomicOr(bad, 1);
+    size_t o = static_cast<size_t>(c) * G + g;
+    keys[o] = Codec<T>::enc(x);
+    idx[o] = static_cast<uint16_t>(g);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys,
+                                               const uint16_t *__restrict__ idx, int G, int Gp, int cb0,
+                                               uint16_t *__restrict__ pos, uint32_t *__restrict__ lo,
+                                               uint32_t *__restrict__ hi, int32_t *__restrict__ anytie)
+{
+    int p = blockIdx.x * 256 + threadIdx.x;
+    int c = blockIdx.y;
+    if (p >= G) return;
+    const uint64_t *col = keys + static_cast<size_t>(c) * G;
+    T v = Codec<T>::dec(col[p]);
+    // first position of the band: smallest q <= p with tie(v_q, v)
+    int l = p;
+    if (p > 0 && Codec<T>::tie(Codec<T>::dec(col[p - 1]), v)) {
+        int a = 0, b = p - 1;  // tie holds at b; search the first tied position
+        while (a < b) {
+            int m = (a + b) >> 1;
+            if (Codec<T>::tie(Codec<T>::dec(col[m]), v)) b = m; else a = m + 1;
+        }
+        l = a;
+    }
+    int h = p;
+    if (p + 1 < G && Codec<T>::tie(Codec<T>::dec(col[p + 1]), v)) {
+        int a = p + 1, b = G - 1;  // tie holds at a; search the last tied position
+        while (a < b) {
+            int m = (a + b + 1) >> 1;
+            if (Codec<T>::tie(Codec<T>::dec(col[m]), v)) a = m; else b = m - 1;
+        }
+        h = a;
+    }
+    if (l != p || h != p) {
+        if (*anytie == 0) atomicOr(anytie, 1);
+    }
+    int g = idx[static_cast<size_t>(c) * G + p];
+    size_t o = static_cast<size_t>(cb0 + c) * Gp + g;
+    pos[o] = static_cast<uint16_t>(p);
+    lo[o] = static_cast<uint32_t>(l);
+    hi[o] = static_cast<uint32_t>(h + 1);
+}
+
+struct SegOff {
+    unsigned G;
+    __host__ __device__ unsigned operator()(unsigned i) const { return i * G; }
+};
+
+template <class T>
+int32_t transform_impl(reo_ctx *c)
+{
+    const int G = static_cast<int>(c->G), S = static_cast<int>(c->S), Gp = c->Gp;
+    hipStream_t st = c->stream;
+
+    // sorted sample order: groups contiguous, original order inside a group
+    std::vector<int32_t> order(S);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return c->group_id[a] < c->group_id[b]; });
+    c->goff.assign(c->ngroups + 1, 0);
+    for (int s = 0; s < S; ++s) c->goff[c->group_id[s] + 1]++;
+    for (int g = 0; g < c->ngroups; ++g) c->goff[g + 1] += c->goff[g];
+
+    DevBuf<int32_t> d_order, d_flags;
+    int32_t rc;
+    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(2))) return rc;
+    REO_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+    REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 2 * sizeof(int32_t), st));
+    if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
+    REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, c->goff.data(), sizeof(int32_t) * (c->ngroups + 1),
+                                 hipMemcpyHostToDevice, st));
+
+    const size_t n = static_cast<size_t>(S) * Gp;
+    if ((rc = c->pos.ensure(n)) || (rc = c->lo.ensure(n)) || (rc = c->hi.ensure(n))) return rc;
+    REO_HIP_CHECK(hipMemsetAsync(c->pos.p, 0, n * sizeof(uint16_t), st));
+    REO_HIP_CHECK(hipMemsetAsync(c->lo.p, 0, n * sizeof(uint32_t), st));
+    REO_HIP_CHECK(hipMemsetAsync(c->hi.p, 0, n * sizeof(uint32_t), st));
+
+    // column batches: rocprim takes a 32-bit element count
+    const int CB = std::max(1, std::min(S, static_cast<int>((1u << 27) / static_cast<unsigned>(G))));
+    DevBuf<uint64_t> k_in, k_out;
+    DevBuf<uint16_t> v_in, v_out;
+    const size_t bn = static_cast<size_t>(CB) * G;
+    if ((rc = k_in.ensure(bn)) || (rc = k_out.ensure(bn)) || (rc = v_in.ensure(bn)) || (rc = v_out.ensure(bn)))
+        return rc;
+
+    auto seg_begin = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned>(0),
+                                                      SegOff{static_cast<unsigned>(G)});
+    size_t temp_bytes = 0;
+    REO_HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, k_in.p, k_out.p, v_in.p, v_out.p,
+                                                      static_cast<unsigned>(bn), static_cast<unsigned>(CB),
+                                                      seg_begin, seg_begin + 1, 0, 64, st));
+    DevBuf<unsigned char> temp;
+    if ((rc = temp.ensure(std::max<size_t>(temp_bytes, 16)))) return rc;
+
+    const T *X = static_cast<const T *>(c->dX);
+    for (int cb0 = 0; cb0 < S; cb0 += CB) {
+        const int nc = std::min(CB, S - cb0);
+        dim3 grid((G + 255) / 256, nc);
+        t_keys<T><<<grid, 256, 0, st>>>(X, c->ld, d_order.p, G, cb0, k_in.p, v_in.p, d_flags.p);
+        size_t tb = temp_bytes;
+        REO_HIP_CHECK(rocprim::segmented_radix_sort_pairs(temp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p,
+                                                          static_cast<unsigned>(static_cast<size_t>(nc) * G),
+                                                          static_cast<unsigned>(nc), seg_begin, seg_begin + 1,
+                                                          0, 64, st));
+        t_bands<T><<<grid, 256, 0, st>>>(k_out.p, v_out.p, G, Gp, cb0, c->pos.p, c->lo.p, c->hi.p,
+                                         d_flags.p + 1);
+    }
+    REO_HIP_CHECK(hipGetLastError());
+    int32_t flags[2] = {0, 0};
+    REO_HIP_CHECK(hipMemcpyAsync(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost, st));
+    REO_HIP_CHECK(hipStreamSynchronize(st));
+    k_in.release(); k_out.release(); v_in.release(); v_out.release(); temp.release();
+    d_order.release(); d_flags.release();
+    if (flags[0]) {
+        set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
+                  "src/RankCompV3.jl:601)");
+        return REO_EINVAL;
+    }
+    c->has_ties = flags[1];
+    c->transformed = true;
+    return REO_OK;
+}
+
+}  // namespace
+
+int32_t run_transform(reo_ctx *c)
+{
+    tic(c, 0);
+    int32_t rc = c->dtype == 1 ? transform_impl<double>(c) : transform_impl<int64_t>(c);
+    toc(c);
+    return rc;
+}
+
+}  // namespace reo

@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference's hot-path interface.
+
+`identify_degs` has the reference's positional signature
+(/root/reference/src/RankCompV3.jl:339-350) and returns the same G x 17
+matrix of [gene_name, 15 Float64 statistics, label] (:430,437); everything
+numeric happens in libreo_hip.so on the GPU.  The Julia shim a maintainer
+would drop into the reference (julia/RankCompV3HIP.jl) is the same ~60 lines
+in Julia.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _ffi
+
+HEADER = ["pval", "padj", "n11", "n12", "n13", "n21", "n22", "n23", "n31", "n32", "n33",
+          "Δ1", "Δ2", "se", "z1", "up_down"]  # src/RankCompV3.jl:665
+
+
+def encode_groups(group):
+    """unique(group) in first-appearance order (src/RankCompV3.jl:353,357) -> (ids, levels)."""
+    levels: list = []
+    index: dict = {}
+    ids = np.empty(len(group), dtype=np.int32)
+    for s, g in enumerate(group):
+        key = g.item() if isinstance(g, np.generic) else g
+        if key not in index:
+            index[key] = len(levels)
+            levels.append(key)
+        ids[s] = index[key]
+    return ids, levels
+
+
+def label_genes(result: np.ndarray, pval_deg: float, padj_deg: float) -> np.ndarray:
+    """up / down / no change, src/RankCompV3.jl:426-429."""
+    sig = (result[:, 0] <= pval_deg) & (result[:, 1] <= padj_deg)
+    out = np.full(result.shape[0], "no change", dtype=object)
+    out[sig & (result[:, 14] > 0)] = "up"
+    out[sig & (result[:, 14] < 0)] = "down"
+    return out
+
+
+@dataclass
+class DegRun:
+    """Everything one comparison produced (the reference only keeps `res`)."""
+    res: np.ndarray                 # G x 17 object matrix, the reference's return value (:437)
+    result: np.ndarray              # G x 15 Float64
+    labels: np.ndarray
+    levels: list
+    thresholds: np.ndarray          # 2 x ngroups (:362)
+    iters_run: int
+    trace: list = field(default_factory=list)   # (#DEG, #non-DEG) per pass (:418)
+    timings: dict = field(default_factory=dict)
+    info: dict = field(default_factory=dict)
+
+
+def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, *,
+                      seed: int = 0, device: int = -1, shard=(0, 1), allreduce=None, profile: bool = False) -> DegRun:
+    """identify_degs with the extras (trace, timings) kept.  Two groups (the
+    reference's `gnum == 2` path, :387-389,431-434); one-vs-rest is the next row."""
+    data = np.asarray(data)
+    if data.ndim != 2:
+        raise _ffi.DimensionMismatch(_ffi.REO_EINVAL, "'data' must be a genes x samples matrix")
+    r, c = data.shape
+    if c != len(group):  # :355
+        raise _ffi.DimensionMismatch(_ffi.REO_EINVAL, "'data' and 'group' do not have compatiable sizes")
+    gid, levels = encode_groups(group)
+    if len(levels) < 2:  # :356
+        raise _ffi.DimensionMismatch(_ffi.REO_EINVAL, "Only 1 level in 'group1, at least 2 levels!")
+    if len(gene_names) != r or len(ref_gene) != r:
+        raise _ffi.DimensionMismatch(_ffi.REO_EINVAL, "gene_names / ref_gene length != number of rows of 'data'")
+    with _ffi.Context(device=device, seed=seed) as ctx:
+        ctx.set_profiling(profile)
+        ctx.set_matrix(data)
+        ctx.set_groups(gid, len(levels))
+        thr = ctx.compute_thresholds(pval_reo)
+        if shard[1] > 1:
+            ctx.set_shard(*shard)
+            ctx.set_allreduce(allreduce)
+        ctx.build_pairs(0)
+        result, iters, trace = ctx.identify_degs(np.asarray(ref_gene, dtype=bool), pval_deg, padj_deg, n_iter, n_conv)
+        timings = ctx.timings() if profile else {}
+        info = ctx.info()
+    labels = label_genes(result, pval_deg, padj_deg)
+    res = np.empty((r, 17), dtype=object)  # hcat(gene_names, result, gene_up_down), :430
+    res[:, 0] = np.asarray(gene_names, dtype=object)
+    res[:, 1:16] = result
+    res[:, 16] = labels
+    return DegRun(res=res, result=result, labels=labels, levels=levels, thresholds=thr, iters_run=iters, trace=trace,
+                  timings=timings, info=info)
+
+
+def identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, **kw) -> np.ndarray:
+    """Drop-in for identify_degs (src/RankCompV3.jl:339-350): same arguments in
+    the same order, same G x 17 return.  `seed=` keys the tie coins that the
+    reference draws from its unseeded global RNG (:73)."""
+    return run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, **kw).res

@@ -1,0 +1,243 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Integer outputs (pair counts, class codes, tallies, iteration trace) must be
+bit-exact; floating-point statistics within the tolerances written below
+(north star: p-values within 1e-6).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P_ATOL = 1e-6      # north-star tolerance on pval / padj
+STAT_RTOL = 1e-7   # delta1, delta2, se, z1 (fp64 log/sqrt, closed-form vs Gauss-Jordan 2x2 inverse)
+
+
+def _setup(pkg, X, group, seed=0, pval_reo=0.01):
+    gid, lev = pkg.encode_groups(group)
+    ctx = pkg.Context(device=0, seed=seed)
+    ctx.set_matrix(X)
+    ctx.set_groups(gid, len(lev))
+    ctx.compute_thresholds(pval_reo)
+    return ctx, gid, len(lev)
+
+
+def _check_result(res, exp):
+    assert np.array_equal(res[:, 2:11], exp[:, 2:11]), "tallies differ"
+    assert np.allclose(res[:, :2], exp[:, :2], rtol=0, atol=P_ATOL), np.abs(res[:, :2] - exp[:, :2]).max()
+    assert np.allclose(res[:, 11:], exp[:, 11:], rtol=STAT_RTOL, atol=1e-9), np.abs(res[:, 11:] - exp[:, 11:]).max()
+
+
+@pytest.mark.parametrize("name", ["bundled_slice64.json", "hand12.json"])
+def test_golden_fixtures(pkg, golden, name):
+    g = golden(name)
+    X = np.array(g["X"], dtype=np.float64)
+    G = X.shape[0]
+    for dtype in (np.float64, np.int64):
+        with pkg.Context(device=0, seed=g["seed"]) as ctx:
+            ctx.set_matrix(X.astype(dtype))
+            ctx.set_groups(g["gid"], g["ngroups"])
+            thr = ctx.compute_thresholds(g["pval_reo"])
+            assert thr[:, 0].tolist() == g["thr"]
+            gt, eq = ctx.pair_counts(0, G, 0, G)
+            assert np.array_equal(gt, g["n_gt"]) and np.array_equal(eq, g["n_eq"])
+            ctx.build_pairs(0)
+            assert np.array_equal(ctx.get_codes(0, G, 0, G), g["code"])
+            assert np.array_equal(ctx.tally(np.array(g["ref0"])), g["cont"])
+            res, iters, trace = ctx.identify_degs(np.array(g["ref0"]), g["pval_deg"], g["padj_deg"], g["n_iter"], g["n_conv"])
+            assert iters == g["iters_run"] and [list(t) for t in trace] == g["trace"]
+            _check_result(res, np.array(g["result"]))
+            assert pkg.label_genes(res, g["pval_deg"], g["padj_deg"]).tolist() == g["labels"]
+
+
+def test_mccullagh_device_routine(pkg, oracle, golden):
+    """Device McCullagh (3x3) against the oracle's general k x k routine, incl. the singular branch."""
+    rng = np.random.default_rng(3)
+    cont = rng.integers(0, 400, size=(2000, 9)).astype(np.int32)
+    cont[:50, [1, 2, 3, 5, 6, 7]] = 0           # N == 0 -> singular
+    cont[50:60] = [5, 3, 0, 3, 9, 0, 0, 0, 7]   # a*d == b*b with a = d = b? (n13 = n31 = 0 -> b = 0, d = 0)
+    cont[60:70] = [0, 0, 4, 0, 1, 0, 4, 0, 0]   # a = d = b = 8
+    with pkg.Context(device=0) as ctx:
+        out = ctx.mccullagh(cont)
+    sing = 0
+    for i in range(cont.shape[0]):
+        exp, _, _ = oracle.mccullagh(cont[i].reshape(3, 3))
+        if exp[0] == 1.0 and exp[1] == 0.0:
+            sing += 1
+            assert out[i].tolist() == [1.0, 0.0, 0.0, 0.0, 0.0]
+        else:
+            assert abs(out[i, 0] - exp[0]) <= P_ATOL
+            assert np.allclose(out[i, 1:], exp[1:], rtol=STAT_RTOL, atol=1e-12)
+    assert sing >= 70
+
+
+@pytest.mark.parametrize("family,G,S", [("t0", 700, 40), ("t1", 700, 40), ("float", 500, 31), ("t1", 333, 9)])
+def test_counts_codes_tallies_bit_exact(pkg, oracle, family, G, S):
+    seed = 0x5EED0002
+    X = {"t0": pkg.synth.t0_ranks, "t1": pkg.synth.t1_counts, "float": pkg.synth.float_expr}[family](G, S, seed)
+    group = pkg.synth.groups(S)
+    ctx, gid, ng = _setup(pkg, X, group, seed)
+    with ctx:
+        Xf = X.astype(np.float64)
+        # blocks on and off the diagonal, ragged edges, i > j
+        for (i0, i1, j0, j1) in [(0, 70, 0, 70), (0, 33, G - 300, G), (G - 37, G, 5, 130), (250, 290, 250, 330)]:
+            gt, eq = ctx.pair_counts(i0, i1, j0, j1)
+            egt, eeq = oracle.pair_counts(Xf, gid, ng, i0, i1, j0, j1)
+            assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), (family, i0, i1, j0, j1)
+        info_ties = (family != "t0")
+        ctx.build_pairs(0)
+        assert bool(ctx.info()["has_ties"]) == info_ties
+        thr = ctx.get_thresholds()[:, 0]
+        code = oracle.build_codes(Xf, gid, ng, 0, thr, seed)
+        assert np.array_equal(ctx.get_codes(0, G, 0, G), code)
+        rng = np.random.default_rng(1)
+        for frac in (0.0, 0.3, 1.0):
+            ref = rng.random(G) < frac
+            assert np.array_equal(ctx.tally(ref), oracle.tally(code, ref))
+
+
+@pytest.mark.parametrize("family,G,S,n_conv", [("t0", 900, 60, 1), ("t1", 900, 60, 5), ("float", 400, 24, 1)])
+def test_identify_degs_matches_oracle(pkg, oracle, family, G, S, n_conv):
+    seed = 0x5EED0003
+    X = {"t0": pkg.synth.t0_ranks, "t1": pkg.synth.t1_counts, "float": pkg.synth.float_expr}[family](G, S, seed)
+    group = pkg.synth.groups(S)
+    ref0 = pkg.synth.ref_mask(G, 150, seed)
+    names = [f"g{i}" for i in range(G)]
+    run = pkg.run_identify_degs(X, group, names, 0.01, 1.0, 0.05, ref0, 16, n_conv, seed=seed, device=0)
+    gid, lev = pkg.encode_groups(group)
+    exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, len(lev), 0.01, 1.0, 0.05, ref0, 16, n_conv, seed)
+    assert run.iters_run == iters and run.trace == trace
+    _check_result(run.result, exp)
+    assert run.res.shape == (G, 17) and run.res[0, 0] == "g0"
+    from oracle import reo_numpy as rn
+    assert run.labels.tolist() == rn.labels(exp, 1.0, 0.05).tolist()
+
+
+def test_forced_iterations_and_zero_iterations(pkg, oracle):
+    G, S, seed = 500, 30, 11
+    X = pkg.synth.t1_counts(G, S, seed)
+    group = pkg.synth.groups(S)
+    ref0 = pkg.synth.ref_mask(G, 80, seed)
+    gid, lev = pkg.encode_groups(group)
+    names = list(range(G))
+    # n_conv = 0 makes :419 never true -> exactly n_iter passes
+    run = pkg.run_identify_degs(X, group, names, 0.01, 1.0, 0.05, ref0, 7, 0, seed=seed, device=0)
+    exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, 7, 0, seed)
+    assert run.iters_run == iters == 7 and run.trace == trace
+    _check_result(run.result, exp)
+    # n_iter = 0: the loop never runs, result stays zeros(r,15) (:398) and every label is "no change"
+    run0 = pkg.run_identify_degs(X, group, names, 0.01, 1.0, 0.05, ref0, 0, 5, seed=seed, device=0)
+    assert run0.iters_run == 0 and not run0.result.any() and set(run0.labels) == {"no change"}
+
+
+def test_group_order_and_interleaved_samples(pkg, oracle):
+    """Groups need not be contiguous; ctrl is the group of the FIRST sample (:353,358)."""
+    G, S, seed = 300, 22, 21
+    X = pkg.synth.t1_counts(G, S, seed)
+    rng = np.random.default_rng(5)
+    group = np.array(["B", "A"])[rng.integers(0, 2, S)]
+    group[0] = "B"
+    ref0 = pkg.synth.ref_mask(G, 60, seed)
+    gid, lev = pkg.encode_groups(group)
+    assert lev[0] == "B"
+    run = pkg.run_identify_degs(X, group, list(range(G)), 0.05, 1.0, 0.05, ref0, 6, 1, seed=seed, device=0)
+    exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.05, 1.0, 0.05, ref0, 6, 1, seed)
+    assert run.iters_run == iters and run.trace == trace
+    _check_result(run.result, exp)
+
+
+def test_error_paths(pkg):
+    X = pkg.synth.t1_counts(9, 10, 1)
+    group = pkg.synth.groups(10)
+    with pytest.raises(pkg.DimensionMismatch):  # G < 10: slice of :411 starts at index 0 (BoundsError)
+        pkg.identify_degs(X, group, list(range(9)), 0.01, 1.0, 0.05, np.ones(9, bool), 4, 1, device=0)
+    Xn = pkg.synth.float_expr(50, 10, 1)
+    Xn[3, 4] = np.nan
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.identify_degs(Xn, group, list(range(50)), 0.01, 1.0, 0.05, np.ones(50, bool), 4, 1, device=0)
+    with pkg.Context(device=0) as ctx:
+        with pytest.raises(pkg.DimensionMismatch):
+            ctx.build_pairs(0)  # nothing set
+        ctx.set_matrix(pkg.synth.t1_counts(40, 10, 1))
+        with pytest.raises(pkg.DimensionMismatch):
+            ctx.set_groups([0, 1, 0], 2) or ctx.pair_counts(0, 4, 0, 4)  # 3 labels for 10 columns (:355)
+        with pytest.raises(pkg.DimensionMismatch):
+            ctx.set_groups([1, 0] * 5, 2)  # ids must follow first appearance
+
+
+def test_all_unstable_degenerate_se_zero(pkg, oracle):
+    """Every pair unstable -> every N singular -> all delta1 = 0 -> trimmed std = 0 -> p = 0 (Normal(0,0))."""
+    rng = np.random.default_rng(9)
+    G, S = 60, 16
+    X = rng.integers(0, 1000, size=(G, S))
+    group = pkg.synth.groups(S)
+    gid, lev = pkg.encode_groups(group)
+    ref0 = np.ones(G, bool)
+    run = pkg.run_identify_degs(X, group, list(range(G)), 1e-9, 1.0, 0.05, ref0, 3, 1, seed=1, device=0)
+    exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, 2, 1e-9, 1.0, 0.05, ref0, 3, 1, 1)
+    assert run.iters_run == iters and run.trace == trace
+    _check_result(run.result, exp)
+
+
+def test_config2_5000x200_one_iteration(pkg, oracle):
+    """BASELINE config 2: synthetic 5,000 x 200, 2 groups, 1 REO iteration, bit-exact counts/codes/tallies."""
+    G, S, seed = 5000, 200, 0x5EED0002
+    for family in ("t0", "t1"):
+        X = (pkg.synth.t0_ranks if family == "t0" else pkg.synth.t1_counts)(G, S, seed)
+        group = pkg.synth.groups(S)
+        ref0 = pkg.synth.ref_mask(G, 3000, seed)
+        ctx, gid, ng = _setup(pkg, X, group, seed)
+        with ctx:
+            Xf = X.astype(np.float64)
+            assert ctx.get_thresholds()[:, 0].tolist() == [64, 64]
+            for (i0, i1, j0, j1) in [(0, 64, 0, 256), (4900, 5000, 4700, 5000), (2500, 2532, 100, 400)]:
+                gt, eq = ctx.pair_counts(i0, i1, j0, j1)
+                egt, eeq = oracle.pair_counts(Xf, gid, ng, i0, i1, j0, j1)
+                assert np.array_equal(gt, egt) and np.array_equal(eq, eeq)
+            ctx.build_pairs(0)
+            code = oracle.build_codes(Xf, gid, ng, 0, [64, 64], seed)
+            got = ctx.get_codes(0, G, 0, G)
+            assert np.array_equal(got, code)
+            assert np.array_equal(ctx.tally(ref0), oracle.tally(code, ref0))
+            res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, 1, 5)
+            exp, eit, etr = oracle.iterate(code, ref0, 1.0, 0.05, 1, 5)
+            assert iters == eit == 1 and trace == etr
+            _check_result(res, exp)
+
+
+def test_full_size_properties_20000x1000(pkg):
+    """BASELINE config 3 size: properties that need no oracle (which would take hours here)."""
+    G, S, seed = 20000, 1000, 0x5EED0003
+    X = pkg.synth.t0_ranks(G, S, seed)
+    group = pkg.synth.groups(S)
+    ref0 = pkg.synth.ref_mask(G, 3000, seed)
+    ctx, gid, ng = _setup(pkg, X, group, seed)
+    with ctx:
+        assert ctx.get_thresholds()[:, 0].tolist() == [280, 280]
+        ctx.build_pairs(0)
+        # mirror rule (:386) across distant blocks and on the diagonal
+        for (a, b) in [(0, 19000), (5000, 5000), (12345, 300), (19744, 19744)]:
+            n = 256
+            c1 = ctx.get_codes(a, a + n, b, b + n).astype(np.int16)
+            c2 = ctx.get_codes(b, b + n, a, a + n).astype(np.int16)
+            off = (np.arange(a, a + n)[:, None] != np.arange(b, b + n)[None, :])
+            assert np.array_equal(c1[off], (8 - c2.T)[off])
+            assert ((c1 == 255) == ~off).all()
+        # tallies of gene i sum to |ref| - [i in ref] (:403)
+        cont = ctx.tally(ref0)
+        assert np.array_equal(cont.sum(axis=1), ref0.sum() - ref0.astype(np.int64))
+        assert cont.min() >= 0
+        # counts of a sample of pairs: n_gt(i,j) + n_gt(j,i) = group size when there are no ties
+        gt, eq = ctx.pair_counts(100, 164, 9000, 9300)
+        gt2, eq2 = ctx.pair_counts(9000, 9300, 100, 164)
+        assert not eq.any() and np.array_equal(gt + gt2.transpose(1, 0, 2), np.full(gt.shape, 500))
+        # a direct numpy count on a few pairs
+        for (i, j) in [(100, 9000), (163, 9299), (120, 9123)]:
+            for g, sl in enumerate((slice(0, 500), slice(500, 1000))):
+                assert gt[i - 100, j - 9000, g] == int((X[i, sl] > X[j, sl]).sum())
+        res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, 128, 5)
+        assert 1 <= iters <= 128 and all(d + n == G for d, n in trace)
+        assert np.isfinite(res).all() and (res[:, 0] >= 0).all() and (res[:, 1] <= 1).all()
+        # BH monotonicity: padj is a non-decreasing function of pval
+        o = np.argsort(res[:, 0], kind="stable")
+        assert (np.diff(res[o, 1]) >= -1e-15).all() and (res[:, 1] >= res[:, 0] - 1e-15).all()

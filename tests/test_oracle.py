@@ -1,0 +1,116 @@
+"""The CPU oracle against the reference's known answers, the committed goldens,
+and an independent numpy restatement.  No GPU."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+
+def test_mccullagh_kat_reference_numbers(oracle, rn, golden):
+    """src/RankCompV3.jl:207-221: the one known-answer test the reference holds."""
+    g = golden("mccullagh_kat.json")
+    for impl in (oracle.mccullagh, rn.mccullagh):
+        out, N, R = impl(np.array(g["mat"]))
+        assert np.allclose(out, g["expected"], rtol=1e-15, atol=0)
+        assert np.array_equal(N, g["N"]) and np.array_equal(R, g["R"])
+    out, _, _ = oracle.mccullagh(np.array(g["mat"]))
+    assert round(out[1], 2) == g["paper_rounded"]["delta1"] and round(out[2], 2) == g["paper_rounded"]["delta2"]
+
+
+def test_threshold_table(oracle, rn, golden):
+    tab = golden("thresholds.json")
+    for p, row in tab.items():
+        for n, m in row.items():
+            assert oracle.threshold(int(n), float(p)) == m
+    # fallback branch (:87-90): even n/n identical REOs is not significant
+    assert oracle.threshold(7, 0.01) == 7 and oracle.threshold(5, 0.01) == 5
+    for n in (6, 9, 13, 21, 40, 77, 128, 333):
+        assert oracle.threshold(n, 0.01) == rn.threshold(n, 0.01)
+
+
+@pytest.mark.parametrize("name", ["bundled_slice64.json", "hand12.json"])
+def test_goldens(oracle, golden, name):
+    g = golden(name)
+    X = np.array(g["X"], dtype=np.float64)
+    gid = np.array(g["gid"], dtype=np.int32)
+    G = X.shape[0]
+    gt, eq = oracle.pair_counts(X, gid, g["ngroups"], 0, G, 0, G)
+    assert np.array_equal(gt, g["n_gt"]) and np.array_equal(eq, g["n_eq"])
+    code = oracle.build_codes(X, gid, g["ngroups"], 0, g["thr"], g["seed"])
+    assert np.array_equal(code, g["code"])
+    assert np.array_equal(oracle.tally(code, np.array(g["ref0"])), g["cont"])
+    res, iters, trace = oracle.identify_degs(X, gid, g["ngroups"], g["pval_reo"], g["pval_deg"], g["padj_deg"],
+                                             np.array(g["ref0"]), g["n_iter"], g["n_conv"], g["seed"])
+    assert iters == g["iters_run"] and [list(t) for t in trace] == g["trace"]
+    assert np.allclose(res, g["result"], rtol=1e-12, atol=1e-14)
+
+
+def test_hand_example_covers_all_classes(golden):
+    g = golden("hand12.json")
+    code = np.array(g["code"])
+    assert set(code[code < 9].tolist()) == set(range(9))
+    assert g["singular_rows"]
+    # B (row 1) vs A (row 0): B > A in every sample of both groups -> n33 for B, n11 for A
+    assert code[1, 0] == 8 and code[0, 1] == 0
+    # C vs B: high in ctrl (3), low in treat (1) -> class 3*(3-1)+(1-1) = 6
+    assert code[2, 1] == 6 and code[1, 2] == 2
+
+
+def test_bh_and_trimmed_std_goldens(oracle, rn, golden):
+    vec = golden("bh_trimmed_std.json")
+    for G, e in vec.items():
+        assert np.allclose(oracle.bh(np.array(e["p"])), e["bh"], rtol=1e-14, atol=0)
+        if e["trimmed_std"] is None:
+            with pytest.raises(IndexError):
+                oracle.trimmed_std(np.array(e["d"]))
+        else:
+            assert abs(oracle.trimmed_std(np.array(e["d"])) - e["trimmed_std"]) < 1e-14
+    assert rn.jl_round(30 * 0.05) == 2 and rn.jl_round(50 * 0.05) == 2 and rn.jl_round(70 * 0.05) == 4
+
+
+def test_c_and_numpy_agree_on_random_cases(oracle, rn):
+    rng = np.random.default_rng(7)
+    for G, S1, S2, hi in ((30, 6, 9, 4), (45, 11, 8, 50)):
+        X = rng.integers(0, hi, size=(G, S1 + S2)).astype(np.float64)
+        X[rng.random(X.shape) < 0.2] += 0.05  # inside the 0.1 band of the integer below
+        gid = np.array([0] * S1 + [1] * S2, dtype=np.int32)
+        thr = (oracle.threshold(S1), oracle.threshold(S2))
+        c1 = oracle.build_codes(X, gid, 2, 0, thr, 99)
+        assert np.array_equal(c1, rn.build_codes(X, gid, 2, 0, thr, 99))
+        ref = rng.random(G) < 0.6
+        r1, i1, t1 = oracle.iterate(c1, ref, 1.0, 0.05, 6, 1)
+        r2, i2, t2 = rn.iterate(c1, ref, 1.0, 0.05, 6, 1)
+        assert i1 == i2 and t1 == t2 and np.allclose(r1, r2, rtol=1e-9, atol=1e-12)
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(8, 24), st.integers(3, 7), st.integers(3, 7), st.integers(2, 9), st.integers(0, 2 ** 32))
+def test_properties(G, S1, S2, hi, seed):
+    import __graft_entry__ as ge
+    oracle = ge.load_oracle()
+    rng = np.random.default_rng(seed)
+    X = rng.integers(0, hi, size=(G, S1 + S2)).astype(np.float64)
+    gid = np.array([0] * S1 + [1] * S2, dtype=np.int32)
+    thr = (oracle.threshold(S1), oracle.threshold(S2))
+    code = oracle.build_codes(X, gid, 2, 0, thr, seed)
+    off = ~np.eye(G, dtype=bool)
+    # mirror rule (:385-386): code(j,i) = 8 - code(i,j); the diagonal is never set
+    assert np.array_equal(code[off], (8 - code.T)[off]) and (np.diag(code) == 255).all()
+    ref = rng.random(G) < 0.5
+    cont = oracle.tally(code, ref)
+    # tallies of gene i sum to |ref| - [i in ref] (:403, diagonal unset)
+    assert np.array_equal(cont.sum(axis=1), ref.sum() - ref.astype(int))
+    # permutation invariance within a group
+    perm = np.concatenate([rng.permutation(S1), S1 + rng.permutation(S2)])
+    gt, eq = oracle.pair_counts(X, gid, 2, 0, G, 0, G)
+    gt2, eq2 = oracle.pair_counts(X[:, perm], gid, 2, 0, G, 0, G)
+    assert np.array_equal(gt, gt2) and np.array_equal(eq, eq2)
+    # a triple per pair: n_gt(i,j) + n_eq(i,j) + n_gt(j,i) = group size
+    sizes = np.array([S1, S2])
+    assert np.array_equal((gt + eq + gt.transpose(1, 0, 2))[off], np.broadcast_to(sizes, (G, G, 2))[off])
+
+
+def test_tie_coins_are_fair_and_keyed(oracle, rn):
+    streams = [tuple(oracle.tie_wins(sd, 3, 9, g, n) for n in (64, 128, 1000)) for sd, g in ((1, 0), (1, 1), (2, 0))]
+    assert len(set(streams)) == 3 and all(400 < s[2] < 600 for s in streams)
+    for n in (0, 1, 63, 64, 65, 200):
+        assert oracle.tie_wins(5, 1, 2, 0, n) == rn.tie_wins(5, 1, 2, 0, n) <= n
