@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: gene-pair·sample comparisons/s of the REO hot path.
+
+One "step" = one full pass of the hot path over the BASELINE.json config-3
+workload (synthetic 20,000 genes x 1,000 samples, tie-free T0 family, 2 groups,
+3,000 initial reference genes, n_iter = 128): rank/band transform + pair kernel
+K1 + 128 iterations of (tally K2 + statistics K3), with the expression matrix
+already resident in HBM when the timed region starts and the G x 15 result
+copied back to the host inside it.  The primary `value` uses n_conv = 0, which
+makes the convergence test of src/RankCompV3.jl:419 never true, i.e. exactly
+128 iterations (deterministic, worst case); the run with the default
+n_conv = 5 is reported beside it as `converged`.
+
+python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with
+torch.distributed.run (one rank per GPU; the G dimension is sharded by pair
+tile and the per-gene tallies are all-reduced over RCCL every iteration).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s measured copy)
+VALU_CMP_PEAK = 3.9e13     # comparisons/s at 2 VALU ops per comparison: 256 CU x 4 SIMD x 2.4 GHz / 2 cyc x 64 lanes / 2
+
+
+class _RawDev:
+    """Zero-copy view of a raw device pointer for torch (cuda array interface)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genes", type=int, default=20000)
+    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--family", default="t0", choices=["t0", "t1"])
+    ap.add_argument("--n-iter", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-genes", type=int, default=6000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = ge.load_pkg()
+    G, S, seed = args.genes, args.samples, 0x5EED0003
+    gen = pkg.synth.t0_ranks if args.family == "t0" else pkg.synth.t1_counts
+    X = gen(G, S, seed)                                   # Int64, like Matrix(df_expr) of count data
+    group = pkg.synth.groups(S)
+    gid, lev = pkg.encode_groups(group)
+    ref0 = pkg.synth.ref_mask(G, 3000, seed)              # ref_gene_max = 3000
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)  # (S, G) row-major == G x S column-major, ld = G
+    torch.cuda.synchronize()
+
+    ctx = pkg.Context(device=local, seed=seed)
+    ctx.set_profiling(True)
+    if world > 1:
+        ctx.set_shard(rank, world)
+
+        def allreduce(ptr: int, count: int) -> None:
+            t = torch.as_tensor(_RawDev(ptr, count), device=dev)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+
+        ctx.set_allreduce(allreduce)
+
+    def step(n_conv: int):
+        ctx.set_matrix_device(Xd.data_ptr(), G, S, G, "i64", keepalive=Xd)
+        ctx.set_groups(gid, len(lev))
+        ctx.compute_thresholds(0.01)
+        ctx.build_pairs(0)
+        return ctx.identify_degs(ref0, 1.0, 0.05, args.n_iter, n_conv)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(n_conv: int, steps: int):
+        ctx.reset_timings()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res, iters, trace = step(n_conv)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, iters, trace, ctx.timings(), res
+
+    for _ in range(args.warmup):
+        step(0)
+    dt, iters, trace, tm, res = timed(0, args.steps)
+    dtc, iters_c, trace_c, tmc, _ = timed(5, max(1, args.steps))
+    info = ctx.info()
+
+    P = G * (G - 1) // 2
+    units = P * S                                          # comparisons per step (whole job, all ranks together)
+    value = units * args.steps / dt
+    k1_ms = tm["k1_ms"] / max(tm["k1_launches"], 1)
+    k2_ms = tm["k2_ms"] / max(tm["k2_launches"], 1)
+    share = info["tiles_owned"] / max(info["tiles_total"], 1)
+    # algorithmic bytes: K1 reads G*S*2 B of u16 ranks and writes the 4-bit class table,
+    # K2 streams the class table + mask and writes int32[9] per gene
+    k1_bytes = (G * S * 2 + G * G / 2) * share
+    k2_bytes = G * G / 2 + G / 8 + 36 * G
+    k1_cmp_rate = units * share / (k1_ms * 1e-3)
+    k1 = {"bound": "valu", "achieved": k1_cmp_rate / 1e12, "peak": VALU_CMP_PEAK / 1e12, "unit": "Tcmp/s",
+          "frac": k1_cmp_rate / VALU_CMP_PEAK, "hbm_achieved_GBps": k1_bytes / (k1_ms * 1e-3) / 1e9,
+          "hbm_frac": k1_bytes / (k1_ms * 1e-3) / HBM_PEAK, "ms_per_launch": k1_ms, "traffic": None,
+          "kernel": "k1_pairs"}
+    k2 = {"bound": "hbm", "achieved": k2_bytes / (k2_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+          "frac": k2_bytes / (k2_ms * 1e-3) / HBM_PEAK, "ms_per_launch": k2_ms, "launches": tm["k2_launches"],
+          "traffic": None, "kernel": "k2_tally"}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            tr = json.load(f)
+        k1["traffic"], k2["traffic"] = tr.get("k1_pairs"), tr.get("k2_tally")
+    dominant = k1 if tm["k1_ms"] >= tm["k2_ms"] else k2
+
+    out = {
+        "metric": "gene-pair·sample comparisons/sec at 20k genes × 1k samples",
+        "value": value, "unit": "comparisons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u16",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3: synthetic {G} genes x {S} samples ({args.family.upper()} family, Int64 input), "
+                               f"2 groups, ref_gene_max=3000, n_iter={args.n_iter}, n_conv=0 (exactly {iters} iterations)",
+                   "genes": G, "samples": S, "iterations": iters, "sharding": f"pair tiles over {world} GPU(s)"},
+        "converged": {"value": units * max(1, args.steps) / dtc, "ms_per_step": dtc / max(1, args.steps) * 1e3,
+                      "n_conv": 5, "iterations": iters_c, "final_trace": list(trace_c[-1]) if trace_c else None},
+        "stages_ms_per_step": {k: tm[k] / args.steps for k in ("transform_ms", "k1_ms", "k2_ms", "k3_ms", "iter_ms", "allreduce_ms")},
+        "roofline": dominant, "roofline_k1": k1, "roofline_k2": k2,
+        "final_trace": list(trace[-1]) if trace else None,
+        "has_ties": info["has_ties"],
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        oracle = ge.load_oracle()
+        Gs = min(args.cpu_genes, G)
+        Xs = X[:Gs].astype(np.float64)
+        refs = ref0[:Gs].copy()
+        refs[:10] = True
+        t0 = time.perf_counter()
+        oracle.identify_degs(Xs, gid, len(lev), 0.01, 1.0, 0.05, refs, args.n_iter, 0, seed)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": (Gs * (Gs - 1) // 2) * S / tc, "unit": "comparisons/s",
+                               "cores": oracle.num_threads(), "kind": "port", "seconds": tc,
+                               "sample": f"first {Gs} genes x {S} samples of the same matrix, full identify_degs "
+                                         f"(n_iter={args.n_iter}, n_conv=0), C restatement with OpenMP"}
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,8 +111,8 @@ int32_t reo_pair_counts(reo_ctx *ctx, int64_t i0, int64_t i1, int64_t j0, int64_
                         uint16_t *n_gt, uint16_t *n_eq);
 
 /* Parity hook: class codes 3*(ic-1)+(it-1) in 0..8 of the ordered pairs of a
- * block (255 where the table holds no pair: the diagonal, and pairs owned by
- * another shard), row-major [(i-i0)][(j-j0)] -- the column index of the
+ * block (255 on the diagonal, which the table never sets; pairs owned by
+ * another shard read as class 4 = all four bits clear), row-major [(i-i0)][(j-j0)] -- the column index of the
  * reference's R BitArray minus one (src/RankCompV3.jl:383-386). */
 int32_t reo_get_codes(reo_ctx *ctx, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *code);
 
@@ -139,8 +139,10 @@ int32_t reo_mccullagh(reo_ctx *ctx, const int32_t *cont, int64_t n, double *out)
 
 /* Stage timers (HIP events on the library's stream), milliseconds, summed
  * since the last reo_reset_timings.  Index: 0 rank/band transform, 1 pair
- * kernel K1, 2 tally kernel K2 (sum), 3 statistics kernels K3 (sum), 4 number
- * of K2 launches, 5 number of K1 launches, 6 all-reduce hook wall time. */
+ * kernel K1, 2 tally kernel K2 (sum), 3 iteration passes in total (K2 + the
+ * statistics kernels K3, sum), 4 number of K2 launches (passes enqueued after
+ * convergence return at once and are counted too), 5 number of K1 launches,
+ * 6 all-reduce hook wall time. */
 enum { REO_NTIMINGS = 8 };
 int32_t reo_set_profiling(reo_ctx *ctx, int32_t on);
 int32_t reo_reset_timings(reo_ctx *ctx);

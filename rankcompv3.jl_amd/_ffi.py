@@ -257,7 +257,7 @@ class Context:
     def timings(self) -> dict:
         ms = np.zeros(NTIMINGS, dtype=np.float64)
         check(self._L.reo_get_timings(self._h, _ptr(ms), NTIMINGS))
-        return {"transform_ms": ms[0], "k1_ms": ms[1], "k2_ms": ms[2], "k3_ms": ms[3], "k2_launches": int(ms[4]),
+        return {"transform_ms": ms[0], "k1_ms": ms[1], "k2_ms": ms[2], "iter_ms": ms[3], "k3_ms": max(ms[3] - ms[2], 0.0), "k2_launches": int(ms[4]),
                 "k1_launches": int(ms[5]), "allreduce_ms": ms[6]}
 
     def info(self) -> dict:

@@ -1,5 +1,6 @@
 // C ABI of libreo_hip.so (include/reo_hip.h): context, host-side driver of the
 // iteration loop of /root/reference/src/RankCompV3.jl:396-425, error plumbing.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -30,12 +31,14 @@ void tic(reo_ctx *c, int slot)
     else { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
     (void)hipEventRecord(t.a, c->stream);
     c->pending.emplace_back(slot, t);
+    c->open.push_back(c->pending.size() - 1);
 }
 
 void toc(reo_ctx *c)
 {
-    if (!c->profiling || c->pending.empty()) return;
-    (void)hipEventRecord(c->pending.back().second.b, c->stream);
+    if (!c->profiling || c->open.empty()) return;
+    (void)hipEventRecord(c->pending[c->open.back()].second.b, c->stream);
+    c->open.pop_back();
 }
 
 void collect_timings(reo_ctx *c)
@@ -47,6 +50,7 @@ void collect_timings(reo_ctx *c)
         c->pool.push_back(pr.second);
     }
     c->pending.clear();
+    c->open.clear();
 }
 
 // pvalue(Binomial(n, 1/2), x; tail = :both) = min(1, 2 min(ccdf(x-1), cdf(x)))
@@ -145,9 +149,10 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
     }
     if ((rc = c->raw.ensure(G * kRaw)) || (rc = c->cont.ensure(G * 9)) || (rc = c->result.ensure(G * 15)) ||
         (rc = c->sorted_d.ensure(G)) || (rc = c->sorted_p.ensure(G)) || (rc = c->rank_s.ensure(G)) ||
-        (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->counters.ensure(8)))
+        (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(64)) ||
+        (rc = c->state.ensure(1)))
         return rc;
-    if (!c->host_counters) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_counters), 8 * sizeof(int32_t)));
+    if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
 }
 
@@ -159,6 +164,16 @@ static int32_t upload_ref(reo_ctx *c, const uint8_t *ref, int slot, int32_t *nre
     REO_HIP_CHECK(hipMemsetAsync(c->refbytes[slot].p, 0, c->Gp, c->stream));
     REO_HIP_CHECK(hipMemcpyAsync(c->refbytes[slot].p, ref, c->G, hipMemcpyHostToDevice, c->stream));
     return launch_pack_ref(c, c->refbytes[slot].p, c->refbits[slot].p);
+}
+
+static int32_t init_state(reo_ctx *c, int32_t nref)
+{
+    IterState st;
+    memset(&st, 0, sizeof st);
+    st.nref = nref;
+    *c->host_state = st;
+    REO_HIP_CHECK(hipMemcpyAsync(c->state.p, c->host_state, sizeof st, hipMemcpyHostToDevice, c->stream));
+    return REO_OK;
 }
 
 static int32_t allreduce_raw(reo_ctx *c)
@@ -222,8 +237,9 @@ void reo_destroy(reo_ctx *c)
     c->table.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
-    c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->counters.release();
-    if (c->host_counters) (void)hipHostFree(c->host_counters);
+    c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
+    c->state.release(); c->trace.release();
+    if (c->host_state) (void)hipHostFree(c->host_state);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -387,9 +403,10 @@ int32_t reo_tally(reo_ctx *c, const uint8_t *ref_mask, int32_t *cont)
     if ((rc = ensure_iter_buffers(c))) return rc;
     int32_t nref = 0;
     if ((rc = upload_ref(c, ref_mask, 0, &nref))) return rc;
+    if ((rc = init_state(c, nref))) return rc;
     if ((rc = launch_k2(c, c->refbits[0].p))) return rc;
     if ((rc = allreduce_raw(c))) return rc;
-    if ((rc = launch_derive(c, c->refbytes[0].p, nref, 0))) return rc;
+    if ((rc = launch_derive(c, c->refbytes[0].p, 0))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(cont, c->cont.p, sizeof(int32_t) * 9 * c->G, hipMemcpyDeviceToHost, c->stream));
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));
     collect_timings(c);
@@ -415,25 +432,34 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     }
     int32_t nref = 0;
     if ((rc = upload_ref(c, ref0, 0, &nref))) return rc;
+    if ((rc = init_state(c, nref))) return rc;
+    if ((rc = c->trace.ensure(2 * static_cast<size_t>(n_iter > 0 ? n_iter : 1)))) return rc;
     REO_HIP_CHECK(hipMemsetAsync(c->result.p, 0, sizeof(double) * 15 * G, c->stream));  // zeros(r,15), :398
-    int cur = 0, i_iter = 0, passes = 0;
-    while (i_iter < n_iter) {  // :400
-        if ((rc = launch_k2(c, c->refbits[cur].p))) return rc;
-        if ((rc = allreduce_raw(c))) return rc;
+    // The loop control of :400,418-424 lives in device memory (IterState): passes are
+    // enqueued in batches and every kernel of a pass returns at once after convergence,
+    // so the host only looks at the state once per batch.  With more than one shard the
+    // all-reduce hook runs on the host between K2 and K3, i.e. batches of one pass.
+    const int batch = c->world > 1 ? 1 : 8;
+    int enq = 0, passes = 0;
+    while (enq < n_iter) {  // :400
+        const int nb = std::min(batch, n_iter - enq);
         tic(c, 3);
-        if ((rc = launch_derive(c, c->refbytes[cur].p, nref, 1))) return rc;
-        if ((rc = launch_stats(c, cur, pval_deg, padj_deg, a, b))) return rc;
+        for (int t = enq; t < enq + nb; ++t) {
+            const int cur = t & 1;  // pass t reads mask buffer t&1 and writes the other (ref_gene_vec = inds, :424)
+            if ((rc = launch_k2(c, c->refbits[cur].p))) return rc;
+            if ((rc = allreduce_raw(c))) return rc;
+            if ((rc = launch_derive(c, c->refbytes[cur].p, 1))) return rc;
+            if ((rc = launch_stats(c, cur, pval_deg, padj_deg, n_conv, a, b))) return rc;
+        }
         toc(c);
-        REO_HIP_CHECK(hipMemcpyAsync(c->host_counters, c->counters.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));
-        const int32_t nn = c->host_counters[0];  // sum(inds), :417-418
-        if (trace) { trace[2 * passes] = static_cast<int32_t>(G) - nn; trace[2 * passes + 1] = nn; }
-        ++passes;
-        if (std::abs(nref - nn) < n_conv) break;  // :419-422
-        ++i_iter;                                 // :423
-        cur = 1 - cur;                            // ref_gene_vec = inds, :424
-        nref = nn;
+        enq += nb;
+        passes = c->host_state->passes;
+        if (c->host_state->done) break;  // :419-422
     }
+    if (trace && passes > 0)
+        REO_HIP_CHECK(hipMemcpyAsync(trace, c->trace.p, sizeof(int32_t) * 2 * passes, hipMemcpyDeviceToHost, c->stream));
     if (iters_run) *iters_run = passes;
     REO_HIP_CHECK(hipMemcpyAsync(result, c->result.p, sizeof(double) * 15 * G, hipMemcpyDeviceToHost, c->stream));
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));

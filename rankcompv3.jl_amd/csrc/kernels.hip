@@ -249,9 +249,11 @@ __device__ __forceinline__ void tally_word(uint32_t cl, uint32_t ch, uint32_t tl
     c[4] += __popc(cl & tl); c[5] += __popc(cl & th); c[6] += __popc(ch & tl); c[7] += __popc(ch & th);
 }
 
-__global__ __launch_bounds__(256) void k2_tally(const uint4 *__restrict__ table, const uint4 *__restrict__ refbits,
-                                                int G, int Wq, int32_t *__restrict__ raw)
+__global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st, const uint4 *__restrict__ table,
+                                                const uint4 *__restrict__ refbits, int G, int Wq,
+                                                int32_t *__restrict__ raw)
 {
+    if (st->done) return;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= G) return;
@@ -322,17 +324,20 @@ __global__ void k_mccullagh(const int32_t *__restrict__ cont, int64_t n, double 
 }
 
 // raw counters -> 9 tallies (:403) [-> McCullagh -> result columns 3..15 (:404-405)]
-__global__ __launch_bounds__(256) void k3_derive(const int32_t *__restrict__ raw,
-                                                 const uint8_t *__restrict__ refbytes, int nref, int G,
+// Also clears the rank accumulators of this pass.  nref comes from the
+// device-side iteration state so that passes can be enqueued back to back.
+__global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ st, const int32_t *__restrict__ raw,
+                                                 const uint8_t *__restrict__ refbytes, int G,
                                                  int32_t *__restrict__ cont, double *__restrict__ result,
-                                                 int32_t *__restrict__ counters, int with_stats)
+                                                 uint32_t *__restrict__ rs, uint32_t *__restrict__ ra,
+                                                 int with_stats)
 {
+    if (st->done) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && counters) counters[0] = 0;
     if (i >= G) return;
     const int4 r0 = reinterpret_cast<const int4 *>(raw)[2 * i], r1 = reinterpret_cast<const int4 *>(raw)[2 * i + 1];
     const int cLt = r0.x, cHt = r0.y, tLt = r0.z, tHt = r0.w, LL = r1.x, LH = r1.y, HL = r1.z, HH = r1.w;
-    const int total = nref - (refbytes[i] ? 1 : 0);  // the diagonal is never set (:363,385)
+    const int total = st->nref - (refbytes[i] ? 1 : 0);  // the diagonal is never set (:363,385)
     int32_t c[9];
     c[0] = LL; c[2] = LH; c[6] = HL; c[8] = HH;
     c[1] = cLt - LL - LH;
@@ -343,6 +348,7 @@ __global__ __launch_bounds__(256) void k3_derive(const int32_t *__restrict__ raw
 #pragma unroll
     for (int t = 0; t < 9; ++t) cont[static_cast<size_t>(i) * 9 + t] = c[t];
     if (!with_stats) return;
+    rs[i] = 0; ra[i] = 0;
     double o[5];
     mccullagh3(c, o);
     const size_t Gs = G;
@@ -354,84 +360,93 @@ __global__ __launch_bounds__(256) void k3_derive(const int32_t *__restrict__ raw
     result[13 * Gs + i] = o[3]; result[14 * Gs + i] = o[4];
 }
 
-// Ranks by exhaustive comparison (G <= 65535: G^2 compares is microseconds on
-// 256 CUs and needs no multi-pass sort).  rs = rank of delta1 ascending (the
-// sort of :409), ra = rank of |delta1| descending = rank of pval ascending
-// (pval is a decreasing function of |delta1|, :412).  Index breaks ties, so
-// both are permutations.  Also scatters delta1 into sorted order.
-__global__ __launch_bounds__(256) void k3_rank(const double *__restrict__ d1, int G, uint32_t *__restrict__ rs,
-                                               uint32_t *__restrict__ ra, double *__restrict__ sorted_d)
+// Ranks by exhaustive comparison, parallel over (256 genes i) x (1024 genes j)
+// tiles; partial counts are summed with integer atomics (order-independent).
+// rs = rank of delta1 ascending (the sort of :409), ra = rank of |delta1|
+// descending = rank of pval ascending (pval is a decreasing function of
+// |delta1|, :412).  The gene index breaks ties, so both are permutations.
+__global__ __launch_bounds__(256) void k3_rank(const IterState *__restrict__ st, const double *__restrict__ d1,
+                                               int G, uint32_t *__restrict__ rs, uint32_t *__restrict__ ra)
 {
-    __shared__ double tile[1024];
+    if (st->done) return;
+    __shared__ double tile[kRankTile];
     const int ib = blockIdx.x * 256;
     const int i = ib + threadIdx.x;
+    const int j0 = blockIdx.y * kRankTile;
+    const int n = min(kRankTile, G - j0);
+    for (int t = threadIdx.x; t < kRankTile; t += 256) tile[t] = t < n ? d1[j0 + t] : 0.0;
+    __syncthreads();
     const double vi = i < G ? d1[i] : 0.0;
     const double ai = fabs(vi);
     uint32_t cs = 0, ca = 0;
-    for (int j0 = 0; j0 < G; j0 += 1024) {
-        const int n = min(1024, G - j0);
-        __syncthreads();
-        for (int t = threadIdx.x; t < n; t += 256) tile[t] = d1[j0 + t];
-        __syncthreads();
-        if (j0 + n <= ib) {  // every j < i
-            for (int t = 0; t < n; ++t) {
-                const double v = tile[t];
-                cs += (v <= vi) ? 1u : 0u;
-                ca += (fabs(v) >= ai) ? 1u : 0u;
-            }
-        } else if (j0 >= ib + 256) {  // every j > i
-            for (int t = 0; t < n; ++t) {
-                const double v = tile[t];
-                cs += (v < vi) ? 1u : 0u;
-                ca += (fabs(v) > ai) ? 1u : 0u;
-            }
-        } else {
-            for (int t = 0; t < n; ++t) {
-                const double v = tile[t];
-                const bool before = (j0 + t) < i;
-                cs += (v < vi || (v == vi && before)) ? 1u : 0u;
-                ca += (fabs(v) > ai || (fabs(v) == ai && before)) ? 1u : 0u;
-            }
+    if (j0 + n <= ib) {  // every j < i: equal values of j sort first
+#pragma unroll 8
+        for (int t = 0; t < n; ++t) {
+            const double v = tile[t];
+            cs += (v <= vi) ? 1u : 0u;
+            ca += (fabs(v) >= ai) ? 1u : 0u;
+        }
+    } else if (j0 >= ib + 256) {  // every j > i
+#pragma unroll 8
+        for (int t = 0; t < n; ++t) {
+            const double v = tile[t];
+            cs += (v < vi) ? 1u : 0u;
+            ca += (fabs(v) > ai) ? 1u : 0u;
+        }
+    } else {
+        for (int t = 0; t < n; ++t) {
+            const double v = tile[t];
+            const bool before = (j0 + t) < i;
+            cs += (v < vi || (v == vi && before)) ? 1u : 0u;
+            ca += (fabs(v) > ai || (fabs(v) == ai && before)) ? 1u : 0u;
         }
     }
-    if (i < G) { rs[i] = cs; ra[i] = ca; sorted_d[cs] = vi; }
+    if (i < G) { atomicAdd(&rs[i], cs); atomicAdd(&ra[i], ca); }
 }
 
-// std(sorted[a..b]) with the n-1 estimator (:411), fixed-order tree reduction.
-__global__ __launch_bounds__(1024) void k3_trimmed_std(const double *__restrict__ sorted_d, int a, int b,
-                                                       double *__restrict__ scal)
+__device__ __forceinline__ double block_sum_256(double v, double *red)
 {
-    __shared__ double red[1024];
-    const int n = b - a + 1;
+    red[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int o = 128; o > 0; o >>= 1) {
+        if (static_cast<int>(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// se = std of the delta1 values whose ascending rank lies in [a0, b0] (the
+// 5 %-95 % slice of the sorted vector, n-1 estimator, :409-411), then
+// pval = pvalue(Normal(0,se), delta1, tail=:both) (:412) -> column 1, and into
+// rank order for the BH step.  Every workgroup recomputes se with the same
+// fixed-order reduction (G values from L2), which saves a launch and a
+// grid-wide dependency and keeps the result deterministic.
+__global__ __launch_bounds__(256) void k3_pvals(const IterState *__restrict__ st, const double *__restrict__ d1,
+                                                const uint32_t *__restrict__ rs, const uint32_t *__restrict__ ra,
+                                                int G, int a0, int b0, double *__restrict__ pval,
+                                                double *__restrict__ sorted_p, double *__restrict__ scal)
+{
+    if (st->done) return;
+    __shared__ double red[256];
+    const int cnt = b0 - a0 + 1;
     double s = 0.0;
-    for (int t = a + threadIdx.x; t <= b; t += 1024) s += sorted_d[t];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (static_cast<int>(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
+    for (int t = threadIdx.x; t < G; t += 256) {
+        const uint32_t r = rs[t];
+        if (r >= static_cast<uint32_t>(a0) && r <= static_cast<uint32_t>(b0)) s += d1[t];
     }
-    const double mean = red[0] / n;
-    __syncthreads();
+    const double mean = block_sum_256(s, red) / cnt;
     double q = 0.0;
-    for (int t = a + threadIdx.x; t <= b; t += 1024) { const double e = sorted_d[t] - mean; q += e * e; }
-    red[threadIdx.x] = q;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (static_cast<int>(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
+    for (int t = threadIdx.x; t < G; t += 256) {
+        const uint32_t r = rs[t];
+        if (r >= static_cast<uint32_t>(a0) && r <= static_cast<uint32_t>(b0)) { const double e = d1[t] - mean; q += e * e; }
     }
-    if (threadIdx.x == 0) scal[0] = sqrt(red[0] / (n - 1));
-}
-
-// pval = pvalue(Normal(0,se), delta1, tail=:both) (:412) -> column 1, and into rank order
-__global__ __launch_bounds__(256) void k3_pvals(const double *__restrict__ d1, const double *__restrict__ scal,
-                                                const uint32_t *__restrict__ ra, int G,
-                                                double *__restrict__ pval, double *__restrict__ sorted_p)
-{
+    const double se = sqrt(block_sum_256(q, red) / (cnt - 1));
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = se;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= G) return;
-    const double se = scal[0];
     double p;
     if (se == 0.0) {
         p = 0.0;  // Normal(0,0): cdf/ccdf degenerate to a step, the smaller tail is 0
@@ -444,49 +459,55 @@ __global__ __launch_bounds__(256) void k3_pvals(const double *__restrict__ d1, c
     sorted_p[ra[i]] = p;
 }
 
-// Benjamini-Hochberg step-up over the sorted p-values (:413): p_(r) * (n/r),
-// reverse cumulative minimum, in place.  One workgroup, contiguous chunk per thread.
-__global__ __launch_bounds__(1024) void k3_bh_scan(double *__restrict__ sorted_p, int G)
+// Benjamini-Hochberg step-up (:413), part 1: p_(r) * (n/r) and the reverse
+// cumulative minimum inside blocks of 1024 ranks (in place) + the block minima.
+__global__ __launch_bounds__(1024) void k3_bh_local(const IterState *__restrict__ st, double *__restrict__ sorted_p,
+                                                    int G, double *__restrict__ blockmin)
 {
+    if (st->done) return;
     __shared__ double red[1024];
-    const int chunk = (G + 1023) / 1024;
-    const int lo = threadIdx.x * chunk, hi = min(G, lo + chunk);
-    const double n = static_cast<double>(G);
-    double run = INFINITY;
-    for (int r = hi - 1; r >= lo; --r) {
-        const double a = sorted_p[r] * (n / static_cast<double>(r + 1));
-        run = a < run ? a : run;
-        sorted_p[r] = run;
-    }
-    red[threadIdx.x] = run;
+    const int r = blockIdx.x * 1024 + threadIdx.x;
+    double v = r < G ? sorted_p[r] * (static_cast<double>(G) / static_cast<double>(r + 1)) : INFINITY;
+    red[threadIdx.x] = v;
     __syncthreads();
-    // suffix minimum across threads (inclusive), Hillis-Steele
     for (int o = 1; o < 1024; o <<= 1) {
-        double v = red[threadIdx.x];
-        if (threadIdx.x + o < 1024) { const double w = red[threadIdx.x + o]; v = w < v ? w : v; }
+        const double w = threadIdx.x + o < 1024 ? red[threadIdx.x + o] : INFINITY;
         __syncthreads();
+        v = w < v ? w : v;
         red[threadIdx.x] = v;
         __syncthreads();
     }
-    const double tail = threadIdx.x + 1 < 1024 ? red[threadIdx.x + 1] : INFINITY;
-    for (int r = lo; r < hi; ++r) {
-        const double v = sorted_p[r];
-        sorted_p[r] = tail < v ? tail : v;
-    }
+    if (r < G) sorted_p[r] = v;
+    if (threadIdx.x == 0) blockmin[blockIdx.x] = v;
 }
 
-// padj -> column 2 (:416); non-DEG mask inds (:417) as bytes and bits; count of non-DEGs
-__global__ __launch_bounds__(256) void k3_finalize(const double *__restrict__ pval,
+// BH part 2 + mask update.  padj -> column 2 (:416); non-DEG mask inds (:417)
+// as bytes and bits for the next pass; the last workgroup to finish applies
+// the loop control of :418-424 to the device-side iteration state.
+__global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, const double *__restrict__ pval,
                                                    const double *__restrict__ sufmin,
+                                                   const double *__restrict__ blockmin,
                                                    const uint32_t *__restrict__ ra, int G, int Gp,
-                                                   double pval_deg, double padj_deg, double *__restrict__ padj,
-                                                   uint8_t *__restrict__ nbytes, uint32_t *__restrict__ nbits,
-                                                   int32_t *__restrict__ counters)
+                                                   double pval_deg, double padj_deg, int n_conv,
+                                                   double *__restrict__ padj, uint8_t *__restrict__ nbytes,
+                                                   uint32_t *__restrict__ nbits, int32_t *__restrict__ trace)
 {
+    if (st->done) return;
+    __shared__ double tail[65];
+    const int nb = (G + 1023) / 1024;
+    if (threadIdx.x == 0) {
+        double run = INFINITY;
+        tail[nb] = run;
+        for (int b = nb - 1; b >= 0; --b) { tail[b] = run; const double m = blockmin[b]; run = m < run ? m : run; }
+    }
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool ind = false;
     if (i < G) {
-        double q = sufmin[ra[i]];
+        const uint32_t r = ra[i];
+        double q = sufmin[r];
+        const double t = tail[r >> 10];
+        q = t < q ? t : q;
         q = q < 1.0 ? q : 1.0;
         padj[i] = q;
         ind = !(pval[i] <= pval_deg && q <= padj_deg);
@@ -496,7 +517,29 @@ __global__ __launch_bounds__(256) void k3_finalize(const double *__restrict__ pv
     if ((threadIdx.x & 63) == 0 && i < Gp) {
         nbits[i >> 5] = static_cast<uint32_t>(m);
         nbits[(i >> 5) + 1] = static_cast<uint32_t>(m >> 32);
-        if (m) atomicAdd(counters, __popcll(m));
+        if (m) atomicAdd(&st->nn_acc, __popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int t = atomicAdd(&st->ticket, 1);
+        if (t == static_cast<int>(gridDim.x) - 1) {
+            __threadfence();
+            const int nn = atomicAdd(&st->nn_acc, 0);  // sum(inds), :417-418
+            const int pass = st->passes;
+            trace[2 * pass] = G - nn;
+            trace[2 * pass + 1] = nn;
+            st->passes = pass + 1;
+            const int diff = st->nref - nn;
+            if ((diff < 0 ? -diff : diff) < n_conv) {
+                st->done = 1;       // :419-422
+            } else {
+                st->i_iter += 1;    // :423
+                st->nref = nn;      // ref_gene_vec = inds, :424
+            }
+            st->nn_acc = 0;
+            st->ticket = 0;
+        }
     }
 }
 
@@ -569,7 +612,7 @@ int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits)
 {
     const int G = static_cast<int>(c->G);
     tic(c, 2);
-    k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(reinterpret_cast<const uint4 *>(c->table.p),
+    k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(c->state.p, reinterpret_cast<const uint4 *>(c->table.p),
                                                  reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp / 4,
                                                  c->raw.p);
     toc(c);
@@ -578,28 +621,28 @@ int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits)
     return REO_OK;
 }
 
-int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int32_t nref, int with_stats)
+int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int with_stats)
 {
     const int G = static_cast<int>(c->G);
-    k3_derive<<<(G + 255) / 256, 256, 0, c->stream>>>(c->raw.p, d_refbytes, nref, G, c->cont.p, c->result.p,
-                                                      c->counters.p, with_stats);
+    k3_derive<<<(G + 255) / 256, 256, 0, c->stream>>>(c->state.p, c->raw.p, d_refbytes, G, c->cont.p, c->result.p,
+                                                      c->rank_s.p, c->rank_a.p, with_stats);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
 
-int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int64_t a, int64_t b)
+int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int n_conv, int64_t a, int64_t b)
 {
     const int G = static_cast<int>(c->G);
     const int nb = (G + 255) / 256;
     double *res = c->result.p;
-    k3_rank<<<nb, 256, 0, c->stream>>>(res + 11 * c->G, G, c->rank_s.p, c->rank_a.p, c->sorted_d.p);
-    k3_trimmed_std<<<1, 1024, 0, c->stream>>>(c->sorted_d.p, static_cast<int>(a - 1), static_cast<int>(b - 1),
-                                              c->scal.p);
-    k3_pvals<<<nb, 256, 0, c->stream>>>(res + 11 * c->G, c->scal.p, c->rank_a.p, G, res, c->sorted_p.p);
-    k3_bh_scan<<<1, 1024, 0, c->stream>>>(c->sorted_p.p, G);
-    k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(res, c->sorted_p.p, c->rank_a.p, G, c->Gp, pval_deg, padj_deg,
-                                                    res + c->G, c->refbytes[1 - cur].p, c->refbits[1 - cur].p,
-                                                    c->counters.p);
+    const double *d1 = res + 11 * c->G;
+    k3_rank<<<dim3(nb, (G + kRankTile - 1) / kRankTile), 256, 0, c->stream>>>(c->state.p, d1, G, c->rank_s.p, c->rank_a.p);
+    k3_pvals<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->rank_a.p, G, static_cast<int>(a - 1),
+                                        static_cast<int>(b - 1), res, c->sorted_p.p, c->scal.p);
+    k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(c->state.p, c->sorted_p.p, G, c->blockmin.p);
+    k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(c->state.p, res, c->sorted_p.p, c->blockmin.p, c->rank_a.p, G,
+                                                    c->Gp, pval_deg, padj_deg, n_conv, res + c->G,
+                                                    c->refbytes[1 - cur].p, c->refbits[1 - cur].p, c->trace.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

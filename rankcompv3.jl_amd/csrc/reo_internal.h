@@ -16,6 +16,19 @@ constexpr int kTileJ = 256;   // genes per workgroup along j (4 waves x 64 lanes
 constexpr int kTileI = 32;    // gene rows per pair tile (one mirror word)
 constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
+constexpr int kRankTile = 1024;  // genes j per workgroup of the ranking kernel
+
+// Device-resident loop state of the iteration driver (src/RankCompV3.jl:396-425),
+// so that passes can be enqueued back to back without a host round trip.
+struct IterState {
+    int32_t done;     // convergence reached (:419-422): later launches return at once
+    int32_t passes;   // executed passes of the while loop
+    int32_t nref;     // sum(ref_gene_vec) of the current pass
+    int32_t i_iter;   // :397,423
+    int32_t ticket;   // finished workgroups of k3_finalize
+    int32_t nn_acc;   // running sum(inds)
+    int32_t pad[2];
+};
 
 void set_error(const char *fmt, ...);
 
@@ -98,14 +111,17 @@ struct reo_ctx {
     reo::DevBuf<double> sorted_p;       // [G]
     reo::DevBuf<uint32_t> rank_s, rank_a;  // [G]
     reo::DevBuf<double> scal;           // [8] device scalars (se, ...)
-    reo::DevBuf<int32_t> counters;      // [8]
-    int32_t *host_counters = nullptr;   // pinned
+    reo::DevBuf<double> blockmin;       // [<= 64]
+    reo::DevBuf<reo::IterState> state;  // [1]
+    reo::DevBuf<int32_t> trace;         // [n_iter][2]
+    reo::IterState *host_state = nullptr;  // pinned
 
     // timing
     bool profiling = false;
     double t_ms[REO_NTIMINGS] = {0};
     std::vector<std::pair<int, reo::StageTimer>> pending;  // (slot, events)
     std::vector<reo::StageTimer> pool;
+    std::vector<size_t> open;  // indices into pending of timers not yet closed (tic/toc nest)
 };
 
 namespace reo {
@@ -119,8 +135,8 @@ int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
 int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
 int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits);
-int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int32_t nref, int with_stats);
-int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int64_t a, int64_t b);
+int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int with_stats);
+int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int n_conv, int64_t a, int64_t b);
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
 
 // timing helpers (api.hip)
