@@ -88,12 +88,22 @@ def main() -> None:
 
         ctx.set_allreduce(allreduce)
 
+    verbose = bool(os.environ.get("REO_BENCH_VERBOSE"))
+
     def step(n_conv: int):
-        ctx.set_matrix_device(Xd.data_ptr(), G, S, G, "i64", keepalive=Xd)
+        t = [time.perf_counter()]
+        ctx.set_matrix_device(Xd.data_ptr(), G, S, G, "i64")
         ctx.set_groups(gid, len(lev))
         ctx.compute_thresholds(0.01)
+        t.append(time.perf_counter())
         ctx.build_pairs(0)
-        return ctx.identify_degs(ref0, 1.0, 0.05, args.n_iter, n_conv)
+        t.append(time.perf_counter())
+        out = ctx.identify_degs(ref0, 1.0, 0.05, args.n_iter, n_conv)
+        t.append(time.perf_counter())
+        if verbose and rank == 0:
+            print("step wall ms: setup %.2f build_pairs %.2f identify_degs %.2f" %
+                  tuple((b - a) * 1e3 for a, b in zip(t, t[1:])), file=sys.stderr)
+        return out
 
     def barrier():
         if world > 1:

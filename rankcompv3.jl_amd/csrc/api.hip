@@ -53,37 +53,31 @@ void collect_timings(reo_ctx *c)
     c->open.clear();
 }
 
+// get_major_reo_lower_count, src/RankCompV3.jl:81-92, with
 // pvalue(Binomial(n, 1/2), x; tail = :both) = min(1, 2 min(ccdf(x-1), cdf(x)))
-// (HypothesisTests, call sites src/RankCompV3.jl:83,85)
-static long double binom_half_cdf(int n, int x)
-{
-    if (x < 0) return 0.0L;
-    if (x >= n) return 1.0L;
-    long double acc = 0.0L, logc = 0.0L;
-    const long double ln2 = 0.693147180559945309417232121458L;
-    for (int t = 0; t <= x; ++t) {
-        if (t > 0) logc += std::log(static_cast<long double>(n - t + 1)) - std::log(static_cast<long double>(t));
-        acc += std::exp(logc - static_cast<long double>(n) * ln2);
-    }
-    return acc > 1.0L ? 1.0L : acc;
-}
-
-static double binom_two_sided(int n, int x)
-{
-    const long double lo = binom_half_cdf(n, x), hi = 1.0L - binom_half_cdf(n, x - 1);
-    const long double p = 2.0L * (lo < hi ? lo : hi);
-    return static_cast<double>(p > 1.0L ? 1.0L : p);
-}
-
-// get_major_reo_lower_count, src/RankCompV3.jl:81-92
+// (HypothesisTests, call sites :83,85).  The cdf is accumulated term by term in
+// long double, pmf(t) = exp(log C(n,t) - n ln 2), so the scan over x is O(n).
 static int32_t major_reo_lower_count(int32_t n, double thr)
 {
-    if (binom_two_sided(n, 0) < thr) {
-        for (int x = 0; x <= n / 2; ++x)
-            if (binom_two_sided(n, x) > thr) return n - x + 1;
-        return -1;
+    const long double ln2 = 0.693147180559945309417232121458L;
+    long double logc = 0.0L, cdf_prev = 0.0L;  // cdf(x-1)
+    int32_t first_above = -1;
+    double pmin = 1.0;
+    for (int x = 0; x <= n / 2; ++x) {
+        if (x > 0) logc += std::log(static_cast<long double>(n - x + 1)) - std::log(static_cast<long double>(x));
+        long double cdf = x >= n ? 1.0L : cdf_prev + std::exp(logc - static_cast<long double>(n) * ln2);
+        if (cdf > 1.0L) cdf = 1.0L;
+        const long double hi = 1.0L - cdf_prev;
+        long double p = 2.0L * (cdf < hi ? cdf : hi);
+        if (p > 1.0L) p = 1.0L;
+        if (x == 0) {
+            pmin = static_cast<double>(p);
+            if (!(pmin < thr)) return n;  // the WARN branch (:87-90)
+        }
+        if (static_cast<double>(p) > thr) { first_above = x; break; }
+        cdf_prev = cdf;
     }
-    return n;  // the WARN branch (:87-90)
+    return first_above < 0 ? -1 : n - first_above + 1;  // -idx + 2 + n with idx = x + 1
 }
 
 static int32_t use(reo_ctx *c)
@@ -150,7 +144,9 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
     if ((rc = c->raw.ensure(G * kRaw)) || (rc = c->cont.ensure(G * 9)) || (rc = c->result.ensure(G * 15)) ||
         (rc = c->sorted_d.ensure(G)) || (rc = c->sorted_p.ensure(G)) || (rc = c->rank_s.ensure(G)) ||
         (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(64)) ||
-        (rc = c->state.ensure(1)))
+        (rc = c->state.ensure(1)) ||
+        (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) ||
+        (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * 256)))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
@@ -235,10 +231,12 @@ void reo_destroy(reo_ctx *c)
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
     c->table.release();
+    c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
+    c->t_order.release(); c->t_flags.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release();
+    c->state.release(); c->trace.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -324,12 +324,11 @@ __global__ void k_mccullagh(const int32_t *__restrict__ cont, int64_t n, double 
 }
 
 // raw counters -> 9 tallies (:403) [-> McCullagh -> result columns 3..15 (:404-405)]
-// Also clears the rank accumulators of this pass.  nref comes from the
+// nref comes from the
 // device-side iteration state so that passes can be enqueued back to back.
 __global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ st, const int32_t *__restrict__ raw,
                                                  const uint8_t *__restrict__ refbytes, int G,
                                                  int32_t *__restrict__ cont, double *__restrict__ result,
-                                                 uint32_t *__restrict__ rs, uint32_t *__restrict__ ra,
                                                  int with_stats)
 {
     if (st->done) return;
@@ -348,7 +347,6 @@ __global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ s
 #pragma unroll
     for (int t = 0; t < 9; ++t) cont[static_cast<size_t>(i) * 9 + t] = c[t];
     if (!with_stats) return;
-    rs[i] = 0; ra[i] = 0;
     double o[5];
     mccullagh3(c, o);
     const size_t Gs = G;
@@ -358,50 +356,6 @@ __global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ s
     for (int t = 0; t < 9; ++t) result[(2 + t) * Gs + i] = static_cast<double>(c[t]);
     result[11 * Gs + i] = o[1]; result[12 * Gs + i] = o[2];
     result[13 * Gs + i] = o[3]; result[14 * Gs + i] = o[4];
-}
-
-// Ranks by exhaustive comparison, parallel over (256 genes i) x (1024 genes j)
-// tiles; partial counts are summed with integer atomics (order-independent).
-// rs = rank of delta1 ascending (the sort of :409), ra = rank of |delta1|
-// descending = rank of pval ascending (pval is a decreasing function of
-// |delta1|, :412).  The gene index breaks ties, so both are permutations.
-__global__ __launch_bounds__(256) void k3_rank(const IterState *__restrict__ st, const double *__restrict__ d1,
-                                               int G, uint32_t *__restrict__ rs, uint32_t *__restrict__ ra)
-{
-    if (st->done) return;
-    __shared__ double tile[kRankTile];
-    const int ib = blockIdx.x * 256;
-    const int i = ib + threadIdx.x;
-    const int j0 = blockIdx.y * kRankTile;
-    const int n = min(kRankTile, G - j0);
-    for (int t = threadIdx.x; t < kRankTile; t += 256) tile[t] = t < n ? d1[j0 + t] : 0.0;
-    __syncthreads();
-    const double vi = i < G ? d1[i] : 0.0;
-    const double ai = fabs(vi);
-    uint32_t cs = 0, ca = 0;
-    if (j0 + n <= ib) {  // every j < i: equal values of j sort first
-#pragma unroll 8
-        for (int t = 0; t < n; ++t) {
-            const double v = tile[t];
-            cs += (v <= vi) ? 1u : 0u;
-            ca += (fabs(v) >= ai) ? 1u : 0u;
-        }
-    } else if (j0 >= ib + 256) {  // every j > i
-#pragma unroll 8
-        for (int t = 0; t < n; ++t) {
-            const double v = tile[t];
-            cs += (v < vi) ? 1u : 0u;
-            ca += (fabs(v) > ai) ? 1u : 0u;
-        }
-    } else {
-        for (int t = 0; t < n; ++t) {
-            const double v = tile[t];
-            const bool before = (j0 + t) < i;
-            cs += (v < vi || (v == vi && before)) ? 1u : 0u;
-            ca += (fabs(v) > ai || (fabs(v) == ai && before)) ? 1u : 0u;
-        }
-    }
-    if (i < G) { atomicAdd(&rs[i], cs); atomicAdd(&ra[i], ca); }
 }
 
 __device__ __forceinline__ double block_sum_256(double v, double *red)
@@ -418,32 +372,157 @@ __device__ __forceinline__ double block_sum_256(double v, double *red)
     return r;
 }
 
-// se = std of the delta1 values whose ascending rank lies in [a0, b0] (the
-// 5 %-95 % slice of the sorted vector, n-1 estimator, :409-411), then
-// pval = pvalue(Normal(0,se), delta1, tail=:both) (:412) -> column 1, and into
-// rank order for the BH step.  Every workgroup recomputes se with the same
-// fixed-order reduction (G values from L2), which saves a launch and a
-// grid-wide dependency and keeps the result deterministic.
+// ---- ranking: the sort of :409 and the order BH needs (:413) ---------------
+// (1) k3_sort_chunks: bitonic sort of 2048-gene chunks in LDS by (delta1, gene);
+// (2) k3_merge_rank: rank of a gene = its position in its own chunk + the
+//     number of smaller elements of every other chunk (binary searches; chunks
+//     hold contiguous gene ranges, so "smaller gene index" is "earlier chunk");
+//     this also scatters delta1 into globally sorted order;
+// (3) k3_abs_rank: rank of |delta1| descending (= rank of pval ascending, pval
+//     being a decreasing function of |delta1|, :412) from three binary searches
+//     in the sorted array, plus per-block moments of the 5 %-95 % slice.
+// Ties are broken consistently, so both ranks are permutations.
+
+__device__ __forceinline__ int lower_bound_d(const double *__restrict__ a, int n, double v)
+{  // number of elements < v
+    int lo = 0, hi = n;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+__device__ __forceinline__ int upper_bound_d(const double *__restrict__ a, int n, double v)
+{  // number of elements <= v
+    int lo = 0, hi = n;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] <= v) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+__global__ __launch_bounds__(1024) void k3_sort_chunks(const IterState *__restrict__ st,
+                                                       const double *__restrict__ d1, int G,
+                                                       double *__restrict__ cv, uint16_t *__restrict__ ci)
+{
+    if (st->done) return;
+    __shared__ double v[kSortChunk];
+    __shared__ uint16_t id[kSortChunk];
+    const int base = blockIdx.x * kSortChunk;
+    for (int t = threadIdx.x; t < kSortChunk; t += 1024) {
+        const int g = base + t;
+        v[t] = g < G ? d1[g] : INFINITY;  // padding sorts to the end of the last chunk
+        id[t] = static_cast<uint16_t>(t);
+    }
+    for (int k = 2; k <= kSortChunk; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            const int t = threadIdx.x;
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // low element of pair t
+            const int l = i + j;
+            const bool up = (i & k) == 0;
+            const double va = v[i], vb = v[l];
+            const uint16_t ia = id[i], ib = id[l];
+            const bool gt = va > vb || (va == vb && ia > ib);
+            if (gt == up) { v[i] = vb; v[l] = va; id[i] = ib; id[l] = ia; }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kSortChunk; t += 1024) {
+        cv[base + t] = v[t];
+        ci[base + t] = id[t];
+    }
+}
+
+__global__ __launch_bounds__(256) void k3_merge_rank(const IterState *__restrict__ st, const double *__restrict__ cv,
+                                                     const uint16_t *__restrict__ ci, int G, int nchunk,
+                                                     uint32_t *__restrict__ rs, double *__restrict__ sorted_d)
+{
+    if (st->done) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int c = e / kSortChunk, p = e % kSortChunk;  // c is uniform in the workgroup
+    const int gene = c * kSortChunk + ci[e];
+    if (gene >= G) return;
+    const double v = cv[e];
+    int rank = p;
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {  // eight independent searches in flight
+        int lo[8], hi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cc = c0 + u;
+            lo[u] = 0;
+            hi[u] = (cc < nchunk && cc != c) ? min(kSortChunk, G - cc * kSortChunk) : 0;
+        }
+#pragma unroll 1
+        for (int step = 0; step < 12; ++step) {  // 2^11 = kSortChunk: 12 halvings empty every interval
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (lo[u] < hi[u]) {
+                    const int cc = c0 + u;
+                    const int m = (lo[u] + hi[u]) >> 1;
+                    const double w = cv[cc * kSortChunk + m];
+                    const bool less = cc < c ? (w <= v) : (w < v);  // equal values of earlier genes sort first
+                    if (less) lo[u] = m + 1; else hi[u] = m;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += lo[u];
+    }
+    rs[gene] = rank;
+    sorted_d[rank] = v;
+}
+
+__global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__ st, const double *__restrict__ d1,
+                                                   const uint32_t *__restrict__ rs,
+                                                   const double *__restrict__ sorted_d, int G, int a0, int b0,
+                                                   uint32_t *__restrict__ ra, double *__restrict__ part)
+{
+    if (st->done) return;
+    __shared__ double red[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < G) {
+        const double v = d1[i];
+        const int r = rs[i];
+        const int lbv = lower_bound_d(sorted_d, G, v);
+        const int ubn = upper_bound_d(sorted_d, G, -v);
+        int rank;
+        if (v > 0.0) {  // larger |w|: w > v or w < -v; ties: the negatives -v first, then equals of v in sorted order
+            const int ubv = upper_bound_d(sorted_d, G, v);
+            rank = (G - ubv) + ubn + (r - lbv);
+        } else {        // larger |w|: w < v or w > -v
+            rank = lbv + (G - ubn) + (r - lbv);
+        }
+        ra[i] = rank;
+    }
+    // moments of this block's part of the slice [a0, b0] of the sorted vector (merged in k3_pvals)
+    const bool in = i >= a0 && i <= b0;  // i doubles as a position in sorted order here
+    const double x = in ? sorted_d[i] : 0.0;
+    const double cnt = block_sum_256(in ? 1.0 : 0.0, red);
+    const double sum = block_sum_256(x, red);
+    const double mean = cnt > 0.0 ? sum / cnt : 0.0;
+    const double e = in ? x - mean : 0.0;
+    const double m2 = block_sum_256(e * e, red);
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = cnt; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = m2; }
+}
+
+// se = std of the 5 %-95 % slice of the sorted delta1 (n-1 estimator, :409-411)
+// from the per-block moments (every workgroup combines them the same way);
+// then pval = pvalue(Normal(0,se), delta1, tail=:both) (:412) -> column 1, and
+// into rank order for the BH step.
 __global__ __launch_bounds__(256) void k3_pvals(const IterState *__restrict__ st, const double *__restrict__ d1,
-                                                const uint32_t *__restrict__ rs, const uint32_t *__restrict__ ra,
-                                                int G, int a0, int b0, double *__restrict__ pval,
+                                                const uint32_t *__restrict__ ra, const double *__restrict__ part,
+                                                int nblk, int G, double *__restrict__ pval,
                                                 double *__restrict__ sorted_p, double *__restrict__ scal)
 {
     if (st->done) return;
     __shared__ double red[256];
-    const int cnt = b0 - a0 + 1;
-    double s = 0.0;
-    for (int t = threadIdx.x; t < G; t += 256) {
-        const uint32_t r = rs[t];
-        if (r >= static_cast<uint32_t>(a0) && r <= static_cast<uint32_t>(b0)) s += d1[t];
-    }
-    const double mean = block_sum_256(s, red) / cnt;
-    double q = 0.0;
-    for (int t = threadIdx.x; t < G; t += 256) {
-        const uint32_t r = rs[t];
-        if (r >= static_cast<uint32_t>(a0) && r <= static_cast<uint32_t>(b0)) { const double e = d1[t] - mean; q += e * e; }
-    }
-    const double se = sqrt(block_sum_256(q, red) / (cnt - 1));
+    // combine the per-block moments around the global mean: n = sum n_b, mean = sum n_b mean_b / n,
+    // M2 = sum [ M2_b + n_b (mean_b - mean)^2 ]  (one partial per thread, fixed-order tree sums)
+    const bool has = static_cast<int>(threadIdx.x) < nblk;
+    const double nb = has ? part[3 * threadIdx.x] : 0.0;
+    const double mb = has ? part[3 * threadIdx.x + 1] : 0.0;
+    const double qb = has ? part[3 * threadIdx.x + 2] : 0.0;
+    const double n = block_sum_256(nb, red);
+    const double mean = block_sum_256(nb * mb, red) / n;
+    const double m2 = block_sum_256(qb + nb * (mb - mean) * (mb - mean), red);
+    const double se = sqrt(m2 / (n - 1.0));
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = se;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= G) return;
@@ -495,10 +574,13 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
     if (st->done) return;
     __shared__ double tail[65];
     const int nb = (G + 1023) / 1024;
-    if (threadIdx.x == 0) {
+    __shared__ double bm[64];
+    if (static_cast<int>(threadIdx.x) < nb) bm[threadIdx.x] = blockmin[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {  // tail[b] = minimum over the blocks after b
         double run = INFINITY;
         tail[nb] = run;
-        for (int b = nb - 1; b >= 0; --b) { tail[b] = run; const double m = blockmin[b]; run = m < run ? m : run; }
+        for (int b = nb - 1; b >= 0; --b) { tail[b] = run; const double m = bm[b]; run = m < run ? m : run; }
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -625,7 +707,7 @@ int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int with_stats)
 {
     const int G = static_cast<int>(c->G);
     k3_derive<<<(G + 255) / 256, 256, 0, c->stream>>>(c->state.p, c->raw.p, d_refbytes, G, c->cont.p, c->result.p,
-                                                      c->rank_s.p, c->rank_a.p, with_stats);
+                                                      with_stats);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -636,9 +718,13 @@ int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int 
     const int nb = (G + 255) / 256;
     double *res = c->result.p;
     const double *d1 = res + 11 * c->G;
-    k3_rank<<<dim3(nb, (G + kRankTile - 1) / kRankTile), 256, 0, c->stream>>>(c->state.p, d1, G, c->rank_s.p, c->rank_a.p);
-    k3_pvals<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->rank_a.p, G, static_cast<int>(a - 1),
-                                        static_cast<int>(b - 1), res, c->sorted_p.p, c->scal.p);
+    const int nchunk = (G + kSortChunk - 1) / kSortChunk;
+    k3_sort_chunks<<<nchunk, 1024, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p);
+    k3_merge_rank<<<nchunk * kSortChunk / 256, 256, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
+                                                                   c->rank_s.p, c->sorted_d.p);
+    k3_abs_rank<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->sorted_d.p, G, static_cast<int>(a - 1),
+                                           static_cast<int>(b - 1), c->rank_a.p, c->part.p);
+    k3_pvals<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_a.p, c->part.p, nb, G, res, c->sorted_p.p, c->scal.p);
     k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(c->state.p, c->sorted_p.p, G, c->blockmin.p);
     k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(c->state.p, res, c->sorted_p.p, c->blockmin.p, c->rank_a.p, G,
                                                     c->Gp, pval_deg, padj_deg, n_conv, res + c->G,

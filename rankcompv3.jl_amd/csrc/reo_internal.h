@@ -16,7 +16,7 @@ constexpr int kTileJ = 256;   // genes per workgroup along j (4 waves x 64 lanes
 constexpr int kTileI = 32;    // gene rows per pair tile (one mirror word)
 constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
-constexpr int kRankTile = 1024;  // genes j per workgroup of the ranking kernel
+constexpr int kSortChunk = 2048; // genes per LDS bitonic sort in the ranking stage
 
 // Device-resident loop state of the iteration driver (src/RankCompV3.jl:396-425),
 // so that passes can be enqueued back to back without a host round trip.
@@ -93,6 +93,11 @@ struct reo_ctx {
     reo::DevBuf<uint32_t> lo;   // [S][Gp] first position of the tie band
     reo::DevBuf<uint32_t> hi;   // [S][Gp] one past the last position of the tie band
     reo::DevBuf<int32_t> goff_dev;
+    // transform scratch (grow-only, freed with the context)
+    reo::DevBuf<uint64_t> t_kin, t_kout;
+    reo::DevBuf<uint16_t> t_vin, t_vout;
+    reo::DevBuf<unsigned char> t_temp;
+    reo::DevBuf<int32_t> t_order, t_flags;
     bool transformed = false;
     int has_ties = 0;
 
@@ -112,6 +117,9 @@ struct reo_ctx {
     reo::DevBuf<uint32_t> rank_s, rank_a;  // [G]
     reo::DevBuf<double> scal;           // [8] device scalars (se, ...)
     reo::DevBuf<double> blockmin;       // [<= 64]
+    reo::DevBuf<double> chunk_v;        // [nchunk][kSortChunk] chunk-sorted delta1
+    reo::DevBuf<uint16_t> chunk_i;      // [nchunk][kSortChunk] gene offsets inside the chunk
+    reo::DevBuf<double> part;           // [<= 256][3] slice moments per block
     reo::DevBuf<reo::IterState> state;  // [1]
     reo::DevBuf<int32_t> trace;         // [n_iter][2]
     reo::IterState *host_state = nullptr;  // pinned

@@ -129,7 +129,8 @@ int32_t transform_impl(reo_ctx *c)
     for (int s = 0; s < S; ++s) c->goff[c->group_id[s] + 1]++;
     for (int g = 0; g < c->ngroups; ++g) c->goff[g + 1] += c->goff[g];
 
-    DevBuf<int32_t> d_order, d_flags;
+    // scratch lives in the context (grow-only): hipMalloc/hipFree per call cost milliseconds
+    DevBuf<int32_t> &d_order = c->t_order, &d_flags = c->t_flags;
     int32_t rc;
     if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(2))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
@@ -140,14 +141,16 @@ int32_t transform_impl(reo_ctx *c)
 
     const size_t n = static_cast<size_t>(S) * Gp;
     if ((rc = c->pos.ensure(n)) || (rc = c->lo.ensure(n)) || (rc = c->hi.ensure(n))) return rc;
-    REO_HIP_CHECK(hipMemsetAsync(c->pos.p, 0, n * sizeof(uint16_t), st));
-    REO_HIP_CHECK(hipMemsetAsync(c->lo.p, 0, n * sizeof(uint32_t), st));
-    REO_HIP_CHECK(hipMemsetAsync(c->hi.p, 0, n * sizeof(uint32_t), st));
+    if (Gp > G) {  // padding genes compare as position 0 with an empty band; their table bits are masked out
+        REO_HIP_CHECK(hipMemset2DAsync(c->pos.p + G, Gp * sizeof(uint16_t), 0, (Gp - G) * sizeof(uint16_t), S, st));
+        REO_HIP_CHECK(hipMemset2DAsync(c->lo.p + G, Gp * sizeof(uint32_t), 0, (Gp - G) * sizeof(uint32_t), S, st));
+        REO_HIP_CHECK(hipMemset2DAsync(c->hi.p + G, Gp * sizeof(uint32_t), 0, (Gp - G) * sizeof(uint32_t), S, st));
+    }
 
     // column batches: rocprim takes a 32-bit element count
     const int CB = std::max(1, std::min(S, static_cast<int>((1u << 27) / static_cast<unsigned>(G))));
-    DevBuf<uint64_t> k_in, k_out;
-    DevBuf<uint16_t> v_in, v_out;
+    DevBuf<uint64_t> &k_in = c->t_kin, &k_out = c->t_kout;
+    DevBuf<uint16_t> &v_in = c->t_vin, &v_out = c->t_vout;
     const size_t bn = static_cast<size_t>(CB) * G;
     if ((rc = k_in.ensure(bn)) || (rc = k_out.ensure(bn)) || (rc = v_in.ensure(bn)) || (rc = v_out.ensure(bn)))
         return rc;
@@ -158,7 +161,7 @@ int32_t transform_impl(reo_ctx *c)
     REO_HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, k_in.p, k_out.p, v_in.p, v_out.p,
                                                       static_cast<unsigned>(bn), static_cast<unsigned>(CB),
                                                       seg_begin, seg_begin + 1, 0, 64, st));
-    DevBuf<unsigned char> temp;
+    DevBuf<unsigned char> &temp = c->t_temp;
     if ((rc = temp.ensure(std::max<size_t>(temp_bytes, 16)))) return rc;
 
     const T *X = static_cast<const T *>(c->dX);
@@ -178,8 +181,6 @@ int32_t transform_impl(reo_ctx *c)
     int32_t flags[2] = {0, 0};
     REO_HIP_CHECK(hipMemcpyAsync(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost, st));
     REO_HIP_CHECK(hipStreamSynchronize(st));
-    k_in.release(); k_out.release(); v_in.release(); v_out.release(); temp.release();
-    d_order.release(); d_flags.release();
     if (flags[0]) {
         set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
                   "src/RankCompV3.jl:601)");
