@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s measured copy)
-VALU_CMP_PEAK = 3.9e13     # comparisons/s at 2 VALU ops per comparison: 256 CU x 4 SIMD x 2.4 GHz / 2 cyc x 64 lanes / 2
+VALU_CMP_PEAK = 3.93e13    # comparisons/s: 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4 cycles per comparison (one v_pk_add_f32
+                           # clamp + one v_pk_add_f32, 4 cycles each, per TWO comparisons; tools/microbench_cmp3.hip measures
+                           # 36.5e12/s for that pair at the clock the chip holds)
 
 
 class _RawDev:

@@ -128,7 +128,7 @@ static int32_t ensure_transform(reo_ctx *c)
         return REO_EINVAL;
     }
     if (c->transformed) return REO_OK;
-    c->Gp = static_cast<int>((c->G + kTileJ - 1) / kTileJ) * kTileJ;
+    c->Gp = static_cast<int>((c->G + kTileJ * kRJ - 1) / (kTileJ * kRJ)) * (kTileJ * kRJ);  // every lane's genes exist
     c->Wp = c->Gp / 32;
     return run_transform(c);
 }
@@ -232,7 +232,7 @@ void reo_destroy(reo_ctx *c)
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
     c->table.release();
     c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
-    c->t_order.release(); c->t_flags.release();
+    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();

@@ -8,15 +8,18 @@
 // All file:line citations are relative to /root/reference.
 //
 // Data layout in HBM
-//   pos  u16 [S][Gp]   position of gene g in sample s's sorted order (lane operand)
-//   lo   u32 [S][Gp]   first position of g's tie band   (wave-uniform operand -> s_load)
-//   hi   u32 [S][Gp]   one past the last position of g's tie band
+//   pos  u16 [S8/8][Gp][8]  position of gene g in its sample's sorted order, 8 sample slots per
+//                   16 bytes (lane operand; groups padded to multiples of 8 slots with 0xFFFF)
+//   lo   f32 [S8][Gp]  first position of g's tie band   (wave-uniform operand -> s_load)
+//   hi   f32 [S8][Gp]  one past the last position of g's tie band (both exact integers < 2^16)
 //   table u32 [G][4][Wp]  bit planes cL cH tL tH of row i: bit j of plane cL is
 //                   set iff pair (i,j) is "i<j stable" in ctrl (ic==1), cH iff
 //                   ic==3, tL/tH likewise for treat.  4 bits per ORDERED pair,
 //                   the diagonal is all-zero (like the reference's R, :363).
 //
 // Wave = 64 lanes everywhere; no warp-32 idiom is used.
+#include <algorithm>
+
 #include "reo_internal.h"
 
 namespace reo {
@@ -50,158 +53,259 @@ __device__ uint32_t tie_wins(uint64_t seed, uint32_t i, uint32_t j, uint32_t g, 
 
 // ---------------------------------------------------------------------------
 // K1 inner loop.  Lane = gene j, the RI genes i of the tile are wave-uniform:
-// their band edges arrive through the scalar cache (s_load_dwordx16) and each
-// comparison is one v_cmp into a lane mask plus one v_addc that consumes it
-// as carry-in -- 2 VALU ops per (pair, sample) without ties, 4 with.
+// their band edges arrive through the scalar cache (s_load) as floats.  All
+// values are integers below 2^16, exact in fp32, so
+//     [pos_j < lo_i] = clamp(lo_i - pos_j, 0, 1)
+// is ONE v_sub_f32 with the clamp output modifier, and the count is one
+// v_add_f32: two full-rate VALU ops per (pair, sample) without ties, four with.
+// Measured on MI355X (tools/microbench_cmp*.hip): this pair issues in 2.04 ns
+// per 64 comparisons per SIMD, against 3.50 ns for v_cmp + v_addc (every VALU op
+// that writes or reads a lane mask in SGPRs issues at half rate) and 3.8 ns for
+// v_cmp + s_bcnt1 + s_add (the ballot/popcount form).
 // n_gt(i,j) = #{s : pos_j < lo_i},  n_ge(i,j) = #{s : pos_j < hi_i}.
-template <int RI, bool TIES>
-__device__ __forceinline__ void count_pass(const uint16_t *__restrict__ pos, const uint32_t *__restrict__ lo,
-                                           const uint32_t *__restrict__ hi, int Gp, int i0, int j, int sb,
-                                           int se, uint32_t (&gt)[RI], uint32_t (&ge)[RI])
+// The lane operand comes 8 samples at a time (one coalesced 16-byte load per
+// lane, 1 KiB per wave) and the next group is fetched while this one is used.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// acc[0..3] += clamp(a[0..3] - b, 0, 1) for four wave-uniform a (two SGPR pairs) and the per-lane b
+// held in the LOW (HI = false) or HIGH (HI = true) half of the VGPR pair bb.  One v_pk_add_f32 with
+// negated, half-broadcast second operand and the clamp modifier makes two flags; a second one adds
+// them to the counts.  Two independent chains per block so that no result is consumed by the very
+// next instruction.  Kept in asm because hipcc, left alone, hoists a whole sample group of flags
+// and then spills; non-volatile so that the loads that feed it remain scalar (s_load).
+template <bool HI>
+__device__ __forceinline__ void acc4(float2v &c0, float2v &c1, float2v a0, float2v a1, float2v bb)
+{
+    float2v t0, t1;
+    if (HI)
+        asm("v_pk_add_f32 %2, %4, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %3, %5, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3"
+            : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
+            : "s"(a0), "s"(a1), "v"(bb));
+    else
+        asm("v_pk_add_f32 %2, %4, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %3, %5, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3"
+            : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
+            : "s"(a0), "s"(a1), "v"(bb));
+}
+
+template <int RI, int RJ, bool TIES>
+__device__ __forceinline__ void count_pass(const uint4 *__restrict__ pos8, const float *__restrict__ lo,
+                                           const float *__restrict__ hi, int Gp, int i0, int j, int s8b,
+                                           int s8e, float2v (&gt)[RJ][RI / 2], float2v (&ge)[RJ][RI / 2])
 {
 #pragma unroll
-    for (int ii = 0; ii < RI; ++ii) { gt[ii] = 0; ge[ii] = 0; }
-    const uint16_t *pb = pos + static_cast<size_t>(sb) * Gp + j;
-    const uint32_t *pl = lo + static_cast<size_t>(sb) * Gp + i0;
-    const uint32_t *ph = hi + static_cast<size_t>(sb) * Gp + i0;
-    for (int s = sb; s < se; ++s) {
-        const uint32_t b = *pb;
+    for (int r = 0; r < RJ; ++r)
 #pragma unroll
-        for (int ii = 0; ii < RI; ++ii) {
-            gt[ii] += (b < pl[ii]) ? 1u : 0u;
-            if (TIES) ge[ii] += (b < ph[ii]) ? 1u : 0u;
+        for (int ii = 0; ii < RI / 2; ++ii) { gt[r][ii] = float2v{0.f, 0.f}; ge[r][ii] = float2v{0.f, 0.f}; }
+    if (s8b >= s8e) return;
+    const uint4 *pb = pos8 + static_cast<size_t>(s8b) * Gp + j;  // lane's genes: j, j + 256, ...
+    const float2v *pl = reinterpret_cast<const float2v *>(lo + static_cast<size_t>(s8b) * 8 * Gp + i0);
+    const float2v *ph = reinterpret_cast<const float2v *>(hi + static_cast<size_t>(s8b) * 8 * Gp + i0);
+    const int row = Gp / 2;  // float2 per sample row
+    uint4 cur[RJ], nxt[RJ];
+#pragma unroll
+    for (int r = 0; r < RJ; ++r) cur[r] = pb[r * 256];
+    for (int s8 = s8b; s8 < s8e; ++s8) {
+        pb += Gp;
+#pragma unroll
+        for (int r = 0; r < RJ; ++r) nxt[r] = (s8 + 1 < s8e) ? pb[r * 256] : cur[r];  // wave-uniform condition
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {  // two samples per dword of the lane operand
+            float2v bb[RJ];
+#pragma unroll
+            for (int r = 0; r < RJ; ++r) {
+                const uint32_t w = kk == 0 ? cur[r].x : kk == 1 ? cur[r].y : kk == 2 ? cur[r].z : cur[r].w;
+                bb[r] = float2v{static_cast<float>(w & 0xFFFFu), static_cast<float>(w >> 16)};
+            }
+#pragma unroll
+            for (int ii = 0; ii < RI / 2; ii += 2) {
+#pragma unroll
+                for (int r = 0; r < RJ; ++r) {
+                    acc4<false>(gt[r][ii], gt[r][ii + 1], pl[ii], pl[ii + 1], bb[r]);
+                    if (TIES) acc4<false>(ge[r][ii], ge[r][ii + 1], ph[ii], ph[ii + 1], bb[r]);
+                }
+            }
+            pl += row; ph += row;
+#pragma unroll
+            for (int ii = 0; ii < RI / 2; ii += 2) {
+#pragma unroll
+                for (int r = 0; r < RJ; ++r) {
+                    acc4<true>(gt[r][ii], gt[r][ii + 1], pl[ii], pl[ii + 1], bb[r]);
+                    if (TIES) acc4<true>(ge[r][ii], ge[r][ii + 1], ph[ii], ph[ii + 1], bb[r]);
+                }
+            }
+            pl += row; ph += row;
         }
-        pb += Gp; pl += Gp; ph += Gp;
+#pragma unroll
+        for (int r = 0; r < RJ; ++r) cur[r] = nxt[r];
     }
 }
 
 struct K1Args {
-    const uint16_t *pos;
-    const uint32_t *lo;
-    const uint32_t *hi;
+    const uint4 *pos8;
+    const float *lo;
+    const float *hi;
     uint32_t *table;
+    const uint32_t *unit_map;  // work unit -> panel << 16 | i-range
     int G, Gp, Wp;
-    int cb, ce, tb, te;  // ctrl / treat sample ranges in the sorted order
+    int cb, ce, tb, te;  // ctrl / treat ranges in units of 8 sample slots
     int gc, gt;          // their group ids (tie-stream key)
     int nc, nt;          // group sizes gsi1, gsi2 (:358-359)
     int m1, m2;          // threshold[1,k], threshold[2,k] (:362)
     uint64_t seed;
-    int rank, world;
+    int n_units, Q;      // units owned by this shard; j-chunks per panel
 };
 
 // state of one side: 0 = "i<j stable" (reference 1), 1 = unstable (2), 2 = "i>j stable" (3)  (:376-377)
 __device__ __forceinline__ int side_state(int n, int size, int m) { return n >= m ? 2 : ((size - n) >= m ? 0 : 1); }
 
-template <int RI, bool TIES>
-__global__ __launch_bounds__(256) void k1_pairs(K1Args a)
+template <int RI, int RJ, bool TIES>
+__global__ __launch_bounds__(256, (TIES || RJ > 1) ? 4 : 5) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap 128 / 64
 {
     static_assert(RI == 32, "one mirror word per tile");
     const int lane = threadIdx.x & 63;
-    const int i0 = blockIdx.y * RI;
-    const int j = blockIdx.x * kTileJ + threadIdx.x;
-    const int bj = j >> 6, bi = i0 >> 6;  // 64-gene blocks; bj is wave-uniform
-    if (bj < bi) return;                  // strictly below the diagonal: the mirror of another tile
-    if (a.world > 1 && static_cast<int>((blockIdx.x + blockIdx.y) % a.world) != a.rank) return;
+    // Work order (speed only, never correctness): a unit = kUnitH i-tiles x Q j-chunks.  Workgroups
+    // are dealt round-robin over the 8 XCDs, so workgroup b belongs to "XCD slot" b & 7; each slot
+    // walks whole units, i-tile-major inside a unit, which keeps the unit's pos panel (Q chunks of
+    // 256*RJ genes x S samples x 2 B) in that XCD's L2 while the band-edge rows stream past once.
+    const int slot = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int bu = kUnitH * a.Q;
+    const int u = (q / bu) * 8 + slot;
+    if (u >= a.n_units) return;
+    const uint32_t um = a.unit_map[u];
+    const int wq = q % bu;
+    const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + wq / a.Q;
+    const int jc = static_cast<int>(um >> 16) * a.Q + wq % a.Q;
+    const int i0 = it * RI;
+    constexpr int CJ = kTileJ * RJ;  // genes j per workgroup
+    if (i0 >= a.Gp || jc * CJ >= a.Gp) return;
+    const int j0 = jc * CJ + threadIdx.x;  // this lane's genes are j0 + 256 r
+    const int bi = i0 >> 6;                // 64-gene blocks
+    if (((j0 + 256 * (RJ - 1)) >> 6) < bi) return;  // every gene of this wave is strictly below the diagonal
 
-    uint32_t gt[RI], ge[RI];
-    uint32_t cL = 0, cH = 0, tL = 0, tH = 0;
+    float2v gt[RJ][RI / 2], ge[RJ][RI / 2];
+    uint32_t cL[RJ], cH[RJ], tL[RJ], tH[RJ];
 
-    count_pass<RI, TIES>(a.pos, a.lo, a.hi, a.Gp, i0, j, a.cb, a.ce, gt, ge);
+    count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge);
 #pragma unroll
-    for (int ii = 0; ii < RI; ++ii) {
-        int nre = gt[ii];
-        if (TIES) {
-            const uint32_t neq = ge[ii] - gt[ii];
-            if (neq) nre += tie_wins(a.seed, i0 + ii, j, a.gc, neq);
+    for (int r = 0; r < RJ; ++r) {
+        cL[r] = 0; cH[r] = 0;
+#pragma unroll
+        for (int ii = 0; ii < RI; ++ii) {
+            const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
+            int nre = static_cast<int>(fgt);
+            if (TIES) {
+                const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
+                const uint32_t neq = static_cast<uint32_t>(fge - fgt);
+                if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, a.gc, neq);
+            }
+            const int st = side_state(nre, a.nc, a.m1);
+            cL[r] |= (st == 0 ? 1u : 0u) << ii;
+            cH[r] |= (st == 2 ? 1u : 0u) << ii;
         }
-        const int st = side_state(nre, a.nc, a.m1);
-        cL |= (st == 0 ? 1u : 0u) << ii;
-        cH |= (st == 2 ? 1u : 0u) << ii;
     }
-    count_pass<RI, TIES>(a.pos, a.lo, a.hi, a.Gp, i0, j, a.tb, a.te, gt, ge);
+    count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge);
 #pragma unroll
-    for (int ii = 0; ii < RI; ++ii) {
-        int nre = gt[ii];
-        if (TIES) {
-            const uint32_t neq = ge[ii] - gt[ii];
-            if (neq) nre += tie_wins(a.seed, i0 + ii, j, a.gt, neq);
+    for (int r = 0; r < RJ; ++r) {
+        tL[r] = 0; tH[r] = 0;
+#pragma unroll
+        for (int ii = 0; ii < RI; ++ii) {
+            const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
+            int nre = static_cast<int>(fgt);
+            if (TIES) {
+                const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
+                const uint32_t neq = static_cast<uint32_t>(fge - fgt);
+                if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, a.gt, neq);
+            }
+            const int st = side_state(nre, a.nt, a.m2);
+            tL[r] |= (st == 0 ? 1u : 0u) << ii;
+            tH[r] |= (st == 2 ? 1u : 0u) << ii;
         }
-        const int st = side_state(nre, a.nt, a.m2);
-        tL |= (st == 0 ? 1u : 0u) << ii;
-        tH |= (st == 2 ? 1u : 0u) << ii;
     }
 
-    // only pairs i < j < G are real; everything else contributes zero bits
-    uint32_t vm = 0;
-    if (j < a.G) {
-        const int d = j - i0;  // rows i0+ii with ii < d are above the diagonal
-        vm = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1u));
-    }
-    cL &= vm; cH &= vm; tL &= vm; tH &= vm;
-
-    const bool diag = (bj == bi);
-    // forward bits: row i, 64-bit word of columns [64*bj, 64*bj+64) = ballot over the lanes
-    unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
 #pragma unroll
-    for (int ii = 0; ii < RI; ++ii) {
-        const unsigned long long b0 = __ballot((cL >> ii) & 1u);
-        const unsigned long long b1 = __ballot((cH >> ii) & 1u);
-        const unsigned long long b2 = __ballot((tL >> ii) & 1u);
-        const unsigned long long b3 = __ballot((tH >> ii) & 1u);
-        if (lane == ii) { f0 = b0; f1 = b1; f2 = b2; f3 = b3; }
-    }
-    if (lane < RI && i0 + lane < a.G) {
-        uint32_t *row = a.table + static_cast<size_t>(i0 + lane) * kPlanes * a.Wp + 2 * bj;
-        if (!diag) {
-            *reinterpret_cast<unsigned long long *>(row) = f0;
-            *reinterpret_cast<unsigned long long *>(row + a.Wp) = f1;
-            *reinterpret_cast<unsigned long long *>(row + 2 * a.Wp) = f2;
-            *reinterpret_cast<unsigned long long *>(row + 3 * a.Wp) = f3;
-        } else {
-            const unsigned long long f[4] = {f0, f1, f2, f3};
+    for (int r = 0; r < RJ; ++r) {
+        const int j = j0 + 256 * r;
+        const int bj = j >> 6;  // wave-uniform
+        if (j >= a.Gp || bj < bi) continue;
+        // only pairs i < j < G are real; everything else contributes zero bits
+        uint32_t vm = 0;
+        if (j < a.G) {
+            const int d = j - i0;  // rows i0+ii with ii < d are above the diagonal
+            vm = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1u));
+        }
+        const uint32_t wcL = cL[r] & vm, wcH = cH[r] & vm, wtL = tL[r] & vm, wtH = tH[r] & vm;
+        const bool diag = (bj == bi);
+        // forward bits: row i, 64-bit word of columns [64*bj, 64*bj+64) = ballot over the lanes
+        unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (static_cast<uint32_t>(f[p])) atomicOr(row + p * a.Wp, static_cast<uint32_t>(f[p]));
-                if (static_cast<uint32_t>(f[p] >> 32)) atomicOr(row + p * a.Wp + 1, static_cast<uint32_t>(f[p] >> 32));
+        for (int ii = 0; ii < RI; ++ii) {
+            const unsigned long long b0 = __ballot((wcL >> ii) & 1u);
+            const unsigned long long b1 = __ballot((wcH >> ii) & 1u);
+            const unsigned long long b2 = __ballot((wtL >> ii) & 1u);
+            const unsigned long long b3 = __ballot((wtH >> ii) & 1u);
+            if (lane == ii) { f0 = b0; f1 = b1; f2 = b2; f3 = b3; }
+        }
+        if (lane < RI && i0 + lane < a.G) {
+            uint32_t *row = a.table + static_cast<size_t>(i0 + lane) * kPlanes * a.Wp + 2 * bj;
+            if (!diag) {
+                *reinterpret_cast<unsigned long long *>(row) = f0;
+                *reinterpret_cast<unsigned long long *>(row + a.Wp) = f1;
+                *reinterpret_cast<unsigned long long *>(row + 2 * a.Wp) = f2;
+                *reinterpret_cast<unsigned long long *>(row + 3 * a.Wp) = f3;
+            } else {
+                const unsigned long long f[4] = {f0, f1, f2, f3};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (static_cast<uint32_t>(f[p])) atomicOr(row + p * a.Wp, static_cast<uint32_t>(f[p]));
+                    if (static_cast<uint32_t>(f[p] >> 32)) atomicOr(row + p * a.Wp + 1, static_cast<uint32_t>(f[p] >> 32));
+                }
             }
         }
-    }
-    // mirror bits (:386): pair (j,i) is in state 2 - state(i,j) on both sides -> L and H swap
-    if (j < a.G) {
-        uint32_t *row = a.table + static_cast<size_t>(j) * kPlanes * a.Wp + (i0 >> 5);
-        if (!diag) {
-            row[0] = cH; row[a.Wp] = cL; row[2 * a.Wp] = tH; row[3 * a.Wp] = tL;
-        } else {
-            if (cH) atomicOr(row, cH);
-            if (cL) atomicOr(row + a.Wp, cL);
-            if (tH) atomicOr(row + 2 * a.Wp, tH);
-            if (tL) atomicOr(row + 3 * a.Wp, tL);
+        // mirror bits (:386): pair (j,i) is in state 2 - state(i,j) on both sides -> L and H swap
+        if (j < a.G) {
+            uint32_t *row = a.table + static_cast<size_t>(j) * kPlanes * a.Wp + (i0 >> 5);
+            if (!diag) {
+                row[0] = wcH; row[a.Wp] = wcL; row[2 * a.Wp] = wtH; row[3 * a.Wp] = wtL;
+            } else {
+                if (wcH) atomicOr(row, wcH);
+                if (wcL) atomicOr(row + a.Wp, wcL);
+                if (wtH) atomicOr(row + 2 * a.Wp, wtH);
+                if (wtL) atomicOr(row + 3 * a.Wp, wtL);
+            }
         }
     }
 }
 
 // Parity hook: same inner loop, writes the raw counts of a block of ordered pairs.
 template <int RI>
-__global__ __launch_bounds__(256) void k1_counts(const uint16_t *__restrict__ pos, const uint32_t *__restrict__ lo,
-                                                 const uint32_t *__restrict__ hi, int Gp,
+__global__ __launch_bounds__(256) void k1_counts(const uint4 *__restrict__ pos, const float *__restrict__ lo,
+                                                 const float *__restrict__ hi, int Gp,
                                                  const int32_t *__restrict__ goff, int ngroups, int ibase,
                                                  int jbase, int ci0, int ci1, int cj0, int cj1,
                                                  uint16_t *__restrict__ out_gt, uint16_t *__restrict__ out_eq)
 {
     const int i0 = ibase + blockIdx.y * RI;
     const int j = jbase + blockIdx.x * kTileJ + threadIdx.x;
-    uint32_t gt[RI], ge[RI];
+    float2v gt[1][RI / 2], ge[1][RI / 2];
     const int nj = cj1 - cj0;
     for (int g = 0; g < ngroups; ++g) {
-        count_pass<RI, true>(pos, lo, hi, Gp, i0, j, goff[g], goff[g + 1], gt, ge);
+        count_pass<RI, 1, true>(pos, lo, hi, Gp, i0, j, goff[g], goff[g + 1], gt, ge);
         if (j >= cj0 && j < cj1) {
 #pragma unroll
             for (int ii = 0; ii < RI; ++ii) {
                 const int i = i0 + ii;
                 if (i >= ci0 && i < ci1) {
                     const size_t o = (static_cast<size_t>(i - ci0) * nj + (j - cj0)) * ngroups + g;
-                    out_gt[o] = static_cast<uint16_t>(gt[ii]);
-                    out_eq[o] = static_cast<uint16_t>(ge[ii] - gt[ii]);
+                    const float fgt = (ii & 1) ? gt[0][ii >> 1].y : gt[0][ii >> 1].x;
+                    const float fge = (ii & 1) ? ge[0][ii >> 1].y : ge[0][ii >> 1].x;
+                    out_gt[o] = static_cast<uint16_t>(fgt);
+                    out_eq[o] = static_cast<uint16_t>(fge - fgt);
                 }
             }
         }
@@ -632,33 +736,58 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
 int32_t launch_k1(reo_ctx *c, int k)
 {
     K1Args a;
-    a.pos = c->pos.p; a.lo = c->lo.p; a.hi = c->hi.p; a.table = c->table.p;
+    a.pos8 = reinterpret_cast<const uint4 *>(c->pos.p); a.lo = c->lo.p; a.hi = c->hi.p; a.table = c->table.p;
     a.G = static_cast<int>(c->G); a.Gp = c->Gp; a.Wp = c->Wp;
     const int other = 1 - k;  // two groups
-    a.cb = c->goff[k]; a.ce = c->goff[k + 1];
-    a.tb = c->goff[other]; a.te = c->goff[other + 1];
+    a.cb = c->goff8[k] / 8; a.ce = c->goff8[k + 1] / 8;
+    a.tb = c->goff8[other] / 8; a.te = c->goff8[other + 1] / 8;
     a.gc = k; a.gt = other;
-    a.nc = a.ce - a.cb; a.nt = a.te - a.tb;
+    a.nc = c->goff[k + 1] - c->goff[k]; a.nt = c->goff[other + 1] - c->goff[other];
     a.m1 = c->thr[2 * k]; a.m2 = c->thr[2 * k + 1];
-    a.seed = c->seed; a.rank = c->rank; a.world = c->world;
-    dim3 grid(c->Gp / kTileJ, c->Gp / kTileI);
+    a.seed = c->seed;
+
+    // work units: panel p = Q consecutive j-chunks, cut into i-ranges of kUnitH tiles.  Q keeps the
+    // panel's pos slice (Q x 256 genes x S8 slots x 2 B) within about 2 MiB of the 4 MiB L2 of an XCD.
+    const int RJ = c->has_ties ? 1 : kRJ;  // genes j per lane
+    const int CJ = kTileJ * RJ;
+    const int NJ = (c->Gp + CJ - 1) / CJ, NIT = c->Gp / kTileI;
+    const size_t chunk_bytes = static_cast<size_t>(CJ) * c->goff8[c->ngroups] * 2;
+    const int Q = chunk_bytes * 4 <= (2u << 20) ? 4 : (chunk_bytes * 2 <= (2u << 20) ? 2 : 1);
+    const int NP = (NJ + Q - 1) / Q;
+    std::vector<uint32_t> units;
+    int64_t owned = 0, total = 0;
+    uint32_t gu = 0;
+    for (int p = 0; p < NP; ++p) {
+        const int ni = std::min(NIT, (CJ / kTileI) * Q * (p + 1));  // i-tiles that reach this panel's columns
+        for (int r = 0; r * kUnitH < ni; ++r, ++gu) {
+            const bool mine = c->world == 1 || static_cast<int>(gu % c->world) == c->rank;
+            if (mine) units.push_back(static_cast<uint32_t>(p) << 16 | static_cast<uint32_t>(r));
+            for (int t = r * kUnitH; t < std::min(ni, (r + 1) * kUnitH); ++t)
+                for (int jc = p * Q; jc < std::min(NJ, (p + 1) * Q); ++jc) {
+                    if ((jc * CJ + CJ - 1) / 64 < (t * kTileI) / 64) continue;
+                    ++total;
+                    if (mine) ++owned;
+                }
+        }
+    }
+    c->tiles_owned = owned; c->tiles_total = total;
+    a.n_units = static_cast<int>(units.size()); a.Q = Q;
+    int32_t rc;
+    if ((rc = c->unit_map.ensure(std::max<size_t>(units.size(), 1)))) return rc;
+    if (!units.empty())
+        REO_HIP_CHECK(hipMemcpyAsync(c->unit_map.p, units.data(), units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    a.unit_map = c->unit_map.p;
     REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
+    if (units.empty()) return REO_OK;
+    const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
     tic(c, 1);
     if (c->has_ties)
-        k1_pairs<kTileI, true><<<grid, 256, 0, c->stream>>>(a);
+        k1_pairs<kTileI, 1, true><<<grid, 256, 0, c->stream>>>(a);
     else
-        k1_pairs<kTileI, false><<<grid, 256, 0, c->stream>>>(a);
+        k1_pairs<kTileI, kRJ, false><<<grid, 256, 0, c->stream>>>(a);
     toc(c);
     REO_HIP_CHECK(hipGetLastError());
-    // tile census for reporting
-    int64_t owned = 0, total = 0;
-    for (int y = 0; y < static_cast<int>(grid.y); ++y)
-        for (int x = 0; x < static_cast<int>(grid.x); ++x) {
-            if (x * 4 + 3 < (y * kTileI) / 64) continue;
-            ++total;
-            if (c->world == 1 || (x + y) % c->world == c->rank) ++owned;
-        }
-    c->tiles_owned = owned; c->tiles_total = total;
+    REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `units` is read by the async copy above
     return REO_OK;
 }
 
@@ -667,7 +796,7 @@ int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
     const int ibase = static_cast<int>(i0 / kTileI) * kTileI, jbase = static_cast<int>(j0 / kTileJ) * kTileJ;
     dim3 grid(static_cast<unsigned>((j1 - jbase + kTileJ - 1) / kTileJ),
               static_cast<unsigned>((i1 - ibase + kTileI - 1) / kTileI));
-    k1_counts<kTileI><<<grid, 256, 0, c->stream>>>(c->pos.p, c->lo.p, c->hi.p, c->Gp, c->goff_dev.p, c->ngroups,
+    k1_counts<kTileI><<<grid, 256, 0, c->stream>>>(reinterpret_cast<const uint4 *>(c->pos.p), c->lo.p, c->hi.p, c->Gp, c->goff_dev.p, c->ngroups,
                                                    ibase, jbase, static_cast<int>(i0), static_cast<int>(i1),
                                                    static_cast<int>(j0), static_cast<int>(j1), d_gt, d_eq);
     REO_HIP_CHECK(hipGetLastError());

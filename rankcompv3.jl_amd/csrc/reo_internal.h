@@ -15,6 +15,8 @@ namespace reo {
 constexpr int kTileJ = 256;   // genes per workgroup along j (4 waves x 64 lanes)
 constexpr int kTileI = 32;    // gene rows per pair tile (one mirror word)
 constexpr int kPlanes = 4;    // cL cH tL tH
+constexpr int kUnitH = 32;    // i-tiles per K1 work unit
+constexpr int kRJ = 1;        // genes j per lane in the tie-free pair kernel
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
 constexpr int kSortChunk = 2048; // genes per LDS bitonic sort in the ranking stage
 
@@ -89,15 +91,17 @@ struct reo_ctx {
     // rank/band transform output (samples re-ordered so groups are contiguous)
     int Gp = 0, Wp = 0;  // padded gene count, 32-bit words per bit row
     std::vector<int32_t> goff;  // ngroups+1 offsets into the sorted sample order
-    reo::DevBuf<uint16_t> pos;  // [S][Gp] position of gene in its sample's sorted order
-    reo::DevBuf<uint32_t> lo;   // [S][Gp] first position of the tie band
-    reo::DevBuf<uint32_t> hi;   // [S][Gp] one past the last position of the tie band
+    std::vector<int32_t> goff8; // the same with every group padded to a multiple of 8 sample slots
+    reo::DevBuf<uint16_t> pos;  // [S8/8][Gp][8] position of gene in its sample's sorted order, 8 slots per 16 B
+    reo::DevBuf<float> lo;      // [S8][Gp] first position of the tie band (exact integer in fp32)
+    reo::DevBuf<float> hi;      // [S8][Gp] one past the last position of the tie band
     reo::DevBuf<int32_t> goff_dev;
     // transform scratch (grow-only, freed with the context)
     reo::DevBuf<uint64_t> t_kin, t_kout;
     reo::DevBuf<uint16_t> t_vin, t_vout;
     reo::DevBuf<unsigned char> t_temp;
-    reo::DevBuf<int32_t> t_order, t_flags;
+    reo::DevBuf<int32_t> t_order, t_flags, t_slots;
+    reo::DevBuf<uint32_t> unit_map;  // K1 work units: panel << 16 | i-range
     bool transformed = false;
     int has_ties = 0;
 

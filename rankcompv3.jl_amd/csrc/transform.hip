@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) void t_keys(const T *__restrict__ X, int64_t l
 template <class T>
 __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys,
                                                const uint16_t *__restrict__ idx, int G, int Gp, int cb0,
-                                               uint16_t *__restrict__ pos, uint32_t *__restrict__ lo,
-                                               uint32_t *__restrict__ hi, int32_t *__restrict__ anytie)
+                                               const int32_t *__restrict__ slots,
+                                               uint16_t *__restrict__ pos, float *__restrict__ lo,
+                                               float *__restrict__ hi, int32_t *__restrict__ anytie)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
     int c = blockIdx.y;
@@ -103,10 +104,11 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
         if (*anytie == 0) atomicOr(anytie, 1);
     }
     int g = idx[static_cast<size_t>(c) * G + p];
-    size_t o = static_cast<size_t>(cb0 + c) * Gp + g;
-    pos[o] = static_cast<uint16_t>(p);
-    lo[o] = static_cast<uint32_t>(l);
-    hi[o] = static_cast<uint32_t>(h + 1);
+    const int slot = slots[cb0 + c];  // sample slot in the group-padded order
+    pos[(static_cast<size_t>(slot >> 3) * Gp + g) * 8 + (slot & 7)] = static_cast<uint16_t>(p);
+    const size_t o = static_cast<size_t>(slot) * Gp + g;
+    lo[o] = static_cast<float>(l);
+    hi[o] = static_cast<float>(h + 1);
 }
 
 struct SegOff {
@@ -128,24 +130,35 @@ int32_t transform_impl(reo_ctx *c)
     c->goff.assign(c->ngroups + 1, 0);
     for (int s = 0; s < S; ++s) c->goff[c->group_id[s] + 1]++;
     for (int g = 0; g < c->ngroups; ++g) c->goff[g + 1] += c->goff[g];
+    // every group is padded to a multiple of 8 sample slots: the pair kernel reads 8 samples
+    // of a gene with one 16-byte load.  Padding slots hold pos = 0xFFFF, which is below no band
+    // edge (edges are <= G <= 65535), so they add nothing to any count.
+    c->goff8.assign(c->ngroups + 1, 0);
+    for (int g = 0; g < c->ngroups; ++g) c->goff8[g + 1] = c->goff8[g] + (c->goff[g + 1] - c->goff[g] + 7) / 8 * 8;
+    const int S8 = c->goff8[c->ngroups];
+    std::vector<int32_t> slots(S), goff8_units(c->ngroups + 1);
+    for (int t = 0; t < S; ++t) {
+        const int g = c->group_id[order[t]];
+        slots[t] = c->goff8[g] + (t - c->goff[g]);
+    }
+    for (int g = 0; g <= c->ngroups; ++g) goff8_units[g] = c->goff8[g] / 8;
 
     // scratch lives in the context (grow-only): hipMalloc/hipFree per call cost milliseconds
     DevBuf<int32_t> &d_order = c->t_order, &d_flags = c->t_flags;
     int32_t rc;
-    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(2))) return rc;
+    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(2)) || (rc = c->t_slots.ensure(S))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+    REO_HIP_CHECK(hipMemcpyAsync(c->t_slots.p, slots.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
     REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 2 * sizeof(int32_t), st));
     if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
-    REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, c->goff.data(), sizeof(int32_t) * (c->ngroups + 1),
+    REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff8_units.data(), sizeof(int32_t) * (c->ngroups + 1),
                                  hipMemcpyHostToDevice, st));
 
-    const size_t n = static_cast<size_t>(S) * Gp;
+    const size_t n = static_cast<size_t>(S8) * Gp;
     if ((rc = c->pos.ensure(n)) || (rc = c->lo.ensure(n)) || (rc = c->hi.ensure(n))) return rc;
-    if (Gp > G) {  // padding genes compare as position 0 with an empty band; their table bits are masked out
-        REO_HIP_CHECK(hipMemset2DAsync(c->pos.p + G, Gp * sizeof(uint16_t), 0, (Gp - G) * sizeof(uint16_t), S, st));
-        REO_HIP_CHECK(hipMemset2DAsync(c->lo.p + G, Gp * sizeof(uint32_t), 0, (Gp - G) * sizeof(uint32_t), S, st));
-        REO_HIP_CHECK(hipMemset2DAsync(c->hi.p + G, Gp * sizeof(uint32_t), 0, (Gp - G) * sizeof(uint32_t), S, st));
-    }
+    REO_HIP_CHECK(hipMemsetAsync(c->pos.p, 0xFF, n * sizeof(uint16_t), st));
+    REO_HIP_CHECK(hipMemsetAsync(c->lo.p, 0, n * sizeof(float), st));
+    REO_HIP_CHECK(hipMemsetAsync(c->hi.p, 0, n * sizeof(float), st));
 
     // column batches: rocprim takes a 32-bit element count
     const int CB = std::max(1, std::min(S, static_cast<int>((1u << 27) / static_cast<unsigned>(G))));
@@ -174,7 +187,7 @@ int32_t transform_impl(reo_ctx *c)
                                                           static_cast<unsigned>(static_cast<size_t>(nc) * G),
                                                           static_cast<unsigned>(nc), seg_begin, seg_begin + 1,
                                                           0, 64, st));
-        t_bands<T><<<grid, 256, 0, st>>>(k_out.p, v_out.p, G, Gp, cb0, c->pos.p, c->lo.p, c->hi.p,
+        t_bands<T><<<grid, 256, 0, st>>>(k_out.p, v_out.p, G, Gp, cb0, c->t_slots.p, c->pos.p, c->lo.p, c->hi.p,
                                          d_flags.p + 1);
     }
     REO_HIP_CHECK(hipGetLastError());
