@@ -35,13 +35,6 @@ VALU_CMP_PEAK = 3.93e13    # comparisons/s: 256 CU x 4 SIMD x 64 lanes x 2.4 GHz
                            # 36.5e12/s for that pair at the clock the chip holds)
 
 
-class _RawDev:
-    """Zero-copy view of a raw device pointer for torch (cuda array interface)."""
-
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-
-
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,12 +76,7 @@ def main() -> None:
     if world > 1:
         ctx.set_shard(rank, world)
 
-        def allreduce(ptr: int, count: int) -> None:
-            t = torch.as_tensor(_RawDev(ptr, count), device=dev)
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
-
-        ctx.set_allreduce(allreduce)
+        ctx.set_allreduce(pkg.dist.allreduce_hook(dev))
 
     verbose = bool(os.environ.get("REO_BENCH_VERBOSE"))
 

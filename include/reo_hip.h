@@ -148,9 +148,12 @@ int32_t reo_set_profiling(reo_ctx *ctx, int32_t on);
 int32_t reo_reset_timings(reo_ctx *ctx);
 int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);
 
-/* Facts about the current problem for roofline accounting: 0 G, 1 S, 2 padded
- * G (table row pitch in bits), 3 class-table bytes, 4 data-has-ties flag,
- * 5 tiles owned by this shard, 6 tiles total. */
+/* Facts about the current problem for roofline accounting and for mirroring
+ * the shard ownership rule: 0 G, 1 S, 2 padded G (table row pitch in bits),
+ * 3 class-table bytes, 4 data-has-ties flag, 5 pair tiles owned by this
+ * shard, 6 pair tiles total, 7 gene rows per pair tile, 8 gene columns per
+ * workgroup, 9 column chunks per panel, 10 tiles per work-unit column,
+ * 11 padded sample slots. */
 int32_t reo_get_info(reo_ctx *ctx, int64_t *info, int32_t n);
 
 #ifdef __cplusplus

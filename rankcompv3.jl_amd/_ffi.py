@@ -63,6 +63,13 @@ def lib() -> ctypes.CDLL:
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise LibraryMissing(f"{LIB_PATH} not found: build it with __graft_entry__.build(); there is no CPU fallback")
+    try:
+        # torch ships its own copy of the HIP runtime; two copies in one process do not share the GPU
+        # (the second one reports "no HIP GPUs").  Importing torch first makes libreo_hip.so bind to
+        # the copy torch already loaded, so both see the same devices and streams.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, u64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
     sig = {
@@ -261,7 +268,8 @@ class Context:
                 "k1_launches": int(ms[5]), "allreduce_ms": ms[6]}
 
     def info(self) -> dict:
-        v = np.zeros(7, dtype=np.int64)
-        check(self._L.reo_get_info(self._h, _ptr(v), 7))
+        v = np.zeros(12, dtype=np.int64)
+        check(self._L.reo_get_info(self._h, _ptr(v), 12))
         return {"G": int(v[0]), "S": int(v[1]), "Gp": int(v[2]), "table_bytes": int(v[3]), "has_ties": int(v[4]),
-                "tiles_owned": int(v[5]), "tiles_total": int(v[6])}
+                "tiles_owned": int(v[5]), "tiles_total": int(v[6]), "tile_i": int(v[7]), "chunk_j": int(v[8]),
+                "chunks_per_panel": int(v[9]), "unit_h": int(v[10]), "sample_slots": int(v[11])}

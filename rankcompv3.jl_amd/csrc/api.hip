@@ -512,9 +512,10 @@ int32_t reo_get_timings(reo_ctx *c, double *ms, int32_t n)
 int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
 {
     if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
-    const int64_t v[7] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
-                          c->tiles_owned, c->tiles_total};
-    for (int i = 0; i < n && i < 7; ++i) info[i] = v[i];
+    const int64_t v[12] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
+                           c->tiles_owned, c->tiles_total, kTileI, c->k1_cj, c->k1_q, kUnitH,
+                           c->goff8.empty() ? 0 : c->goff8.back()};
+    for (int i = 0; i < n && i < 12; ++i) info[i] = v[i];
     return REO_OK;
 }
 

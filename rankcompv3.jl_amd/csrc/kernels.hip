@@ -771,6 +771,7 @@ int32_t launch_k1(reo_ctx *c, int k)
         }
     }
     c->tiles_owned = owned; c->tiles_total = total;
+    c->k1_cj = CJ; c->k1_q = Q;
     a.n_units = static_cast<int>(units.size()); a.Q = Q;
     int32_t rc;
     if ((rc = c->unit_map.ensure(std::max<size_t>(units.size(), 1)))) return rc;

@@ -109,6 +109,7 @@ struct reo_ctx {
     reo::DevBuf<uint32_t> table;
     int built_k = -1;
     int64_t tiles_owned = 0, tiles_total = 0;
+    int k1_cj = 0, k1_q = 0;  // K1 geometry of the last build: genes j per workgroup, j-chunks per panel
 
     // iteration state
     reo::DevBuf<uint32_t> refbits[2];   // [Wp]

@@ -1,0 +1,59 @@
+"""torch.distributed plumbing for G-sharded runs: one process per GPU, RCCL
+(backend "nccl") on MI355X, gloo in CPU tests.  The library itself is
+collective-agnostic: it hands the hook a raw pointer to int32 counters and the
+hook sums them in place across shards."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+
+class _RawDev:
+    """Zero-copy view of a raw device pointer for torch (cuda array interface)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def allreduce_hook(device=None, group=None):
+    """fn(ptr, count): sum int32[count] at `ptr` across the process group, in place.
+    `device` is a torch cuda device for device pointers, None for host pointers (gloo tests)."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(ptr: int, count: int) -> None:
+        if device is not None:
+            t = torch.as_tensor(_RawDev(ptr, count), device=device)
+            dist.all_reduce(t, group=group)
+            torch.cuda.synchronize(device)
+        else:
+            buf = (ctypes.c_int32 * count).from_address(ptr)
+            t = torch.from_numpy(np.ctypeslib.as_array(buf))
+            dist.all_reduce(t, group=group)
+
+    return fn
+
+
+def shard_of_process():
+    """(rank, world) of this process in the default group, (0, 1) without torch.distributed."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def run_identify_degs_sharded(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, *,
+                              device_index: int, seed: int = 0, profile: bool = False):
+    """identify_degs with the pair tiles split over the ranks of the default process group
+    (every rank passes the same arguments and gets the same result)."""
+    import torch
+
+    from .hotpath import run_identify_degs
+    rank, world = shard_of_process()
+    hook = allreduce_hook(torch.device("cuda", device_index)) if world > 1 else None
+    return run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv,
+                             seed=seed, device=device_index, shard=(rank, world), allreduce=hook, profile=profile)

@@ -1,0 +1,101 @@
+"""Python mirror of the pair-tile ownership rule of libreo_hip.so (launch_k1 in
+csrc/kernels.hip) and of the linear algebra of its tallies, so that the
+multi-GPU protocol can be exercised without a GPU.
+
+G is sharded by work unit: the upper triangle of the gene x gene pair matrix is
+cut into tiles of TILE_I rows x CHUNK_J columns; a unit = UNIT_H consecutive
+row tiles x Q column chunks of one panel; units are numbered panel-major and
+unit u belongs to shard u % world.  Every shard tallies its own tiles; the raw
+per-gene counters are linear in the table, so an integer all-reduce (sum) over
+the shards followed by `derive_tallies` reproduces the unsharded tallies bit
+for bit (src/RankCompV3.jl:403).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TILE_I = 32     # kTileI
+TILE_J = 256    # kTileJ
+RJ = 1          # kRJ (genes per lane in the tie-free kernel)
+UNIT_H = 32     # kUnitH
+
+
+def geometry(G: int, sample_slots: int, has_ties: bool):
+    """(Gp, CJ, Q) exactly as launch_k1 derives them."""
+    cj_pad = TILE_J * RJ
+    Gp = (G + cj_pad - 1) // cj_pad * cj_pad
+    CJ = TILE_J * (1 if has_ties else RJ)
+    chunk_bytes = CJ * sample_slots * 2
+    Q = 4 if chunk_bytes * 4 <= (2 << 20) else (2 if chunk_bytes * 2 <= (2 << 20) else 1)
+    return Gp, CJ, Q
+
+
+def sample_slots(group_sizes) -> int:
+    """Every group is padded to a multiple of 8 sample slots (transform.hip)."""
+    return int(sum((int(n) + 7) // 8 * 8 for n in group_sizes))
+
+
+def tile_owner(G: int, slots: int, has_ties: bool, world: int) -> np.ndarray:
+    """owner[it, jc] = shard that computes pair tile (rows 32*it.., columns CJ*jc..), or -1 if the
+    tile lies strictly below the diagonal (it is the mirror of another tile)."""
+    Gp, CJ, Q = geometry(G, slots, has_ties)
+    NJ, NIT = (Gp + CJ - 1) // CJ, Gp // TILE_I
+    NP = (NJ + Q - 1) // Q
+    owner = np.full((NIT, NJ), -1, dtype=np.int32)
+    gu = 0
+    for p in range(NP):
+        ni = min(NIT, (CJ // TILE_I) * Q * (p + 1))
+        r = 0
+        while r * UNIT_H < ni:
+            for t in range(r * UNIT_H, min(ni, (r + 1) * UNIT_H)):
+                for jc in range(p * Q, min(NJ, (p + 1) * Q)):
+                    if (jc * CJ + CJ - 1) // 64 < (t * TILE_I) // 64:
+                        continue
+                    owner[t, jc] = gu % world
+            gu += 1
+            r += 1
+    return owner
+
+
+def owned_pair_mask(G: int, slots: int, has_ties: bool, rank: int, world: int) -> np.ndarray:
+    """mask[i, j] (i != j) = True iff the unordered pair {i, j} is computed by shard `rank`
+    (the shard then holds both the (i,j) bits and the mirrored (j,i) bits)."""
+    Gp, CJ, Q = geometry(G, slots, has_ties)
+    owner = tile_owner(G, slots, has_ties, world)
+    i = np.arange(G)
+    lo, hi = np.minimum(i[:, None], i[None, :]), np.maximum(i[:, None], i[None, :])
+    m = owner[lo // TILE_I, hi // CJ] == rank
+    np.fill_diagonal(m, False)
+    return m
+
+
+def raw_counters(code: np.ndarray, ref: np.ndarray, mask: np.ndarray | None = None) -> np.ndarray:
+    """The 8 counters k2_tally writes per gene: marginals cL cH tL tH and cells LL LH HL HH over the
+    reference genes, restricted to the pairs in `mask` (a shard's share)."""
+    code = np.asarray(code)
+    G = code.shape[0]
+    sel = np.asarray(ref, dtype=bool)[None, :] & (code < 9)
+    if mask is not None:
+        sel = sel & mask
+    ic, it = code // 3, code % 3
+    out = np.zeros((G, 8), dtype=np.int32)
+    cL, cH, tL, tH = (ic == 0) & sel, (ic == 2) & sel, (it == 0) & sel, (it == 2) & sel
+    for k, m in enumerate((cL, cH, tL, tH, cL & tL, cL & tH, cH & tL, cH & tH)):
+        out[:, k] = m.sum(axis=1)
+    return out
+
+
+def derive_tallies(raw: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    """k3_derive: the 9 tallies n11..n33 from the (summed) raw counters."""
+    raw = np.asarray(raw, dtype=np.int64)
+    ref = np.asarray(ref, dtype=bool)
+    total = int(ref.sum()) - ref.astype(np.int64)
+    cLt, cHt, tLt, tHt, LL, LH, HL, HH = raw.T
+    c = np.zeros((raw.shape[0], 9), dtype=np.int64)
+    c[:, 0], c[:, 2], c[:, 6], c[:, 8] = LL, LH, HL, HH
+    c[:, 1] = cLt - LL - LH
+    c[:, 7] = cHt - HL - HH
+    c[:, 3] = tLt - LL - HL
+    c[:, 5] = tHt - LH - HH
+    c[:, 4] = total - (cLt + cHt + c[:, 3] + c[:, 5])
+    return c.astype(np.int32)

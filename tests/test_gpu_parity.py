@@ -241,3 +241,71 @@ def test_full_size_properties_20000x1000(pkg):
         # BH monotonicity: padj is a non-decreasing function of pval
         o = np.argsort(res[:, 0], kind="stable")
         assert (np.diff(res[o, 1]) >= -1e-15).all() and (res[:, 1] >= res[:, 0] - 1e-15).all()
+
+
+def test_two_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle):
+    """G-sharding: two contexts (shards 0/2 and 1/2) on one GPU, their all-reduce hooks joined by a
+    thread barrier.  Owned pairs carry the oracle's codes, the others are empty, and the summed
+    tallies / the whole iteration equal the unsharded result bit for bit."""
+    import threading
+    import torch
+    G, S, seed = 1500, 24, 0x5EED0005
+    X = pkg.synth.t1_counts(G, S, seed)
+    group = pkg.synth.groups(S)
+    gid, lev = pkg.encode_groups(group)
+    ref0 = pkg.synth.ref_mask(G, 200, seed)
+    exp, eit, etr = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, 8, 1, seed)
+    thr = [oracle.threshold(12), oracle.threshold(12)]
+    code = oracle.build_codes(X.astype(np.float64), gid, 2, 0, thr, seed)
+    world = 2
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+    dev = torch.device("cuda", 0)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            def hook(ptr, count):
+                slots[rank] = torch.as_tensor(pkg.dist._RawDev(ptr, count), device=dev)
+                barrier.wait()
+                if rank == 0:
+                    total = slots[0] + slots[1]
+                    slots[0].copy_(total)
+                    slots[1].copy_(total)
+                    torch.cuda.synchronize()
+                barrier.wait()
+
+            with pkg.Context(device=0, seed=seed) as ctx:
+                ctx.set_matrix(X)
+                ctx.set_groups(gid, 2)
+                ctx.compute_thresholds(0.01)
+                ctx.set_shard(rank, world)
+                ctx.set_allreduce(hook)
+                ctx.build_pairs(0)
+                info = ctx.info()
+                got = ctx.get_codes(0, G, 0, G)
+                mask = pkg.sharding.owned_pair_mask(G, info["sample_slots"], True, rank, world)
+                off = ~np.eye(G, dtype=bool)
+                assert np.array_equal(got[mask], code[mask])
+                assert (got[off & ~mask] == 4).all()
+                cont = ctx.tally(ref0)
+                res = ctx.identify_degs(ref0, 1.0, 0.05, 8, 1)
+                results[rank] = (info, cont, res)
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    owned = [results[r][0]["tiles_owned"] for r in range(world)]
+    assert sum(owned) == results[0][0]["tiles_total"] and min(owned) > 0
+    for r in range(world):
+        info, cont, (res, iters, trace) = results[r]
+        assert np.array_equal(cont, oracle.tally(code, ref0))
+        assert iters == eit and trace == etr
+        _check_result(res, exp)
