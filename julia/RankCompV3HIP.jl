@@ -1,0 +1,59 @@
+# Drop-in replacement for `identify_degs` of RankCompV3.jl (src/RankCompV3.jl:339-438) that runs the
+# pair loop, the tallies and the iteration on an MI355X through libreo_hip.so (include/reo_hip.h).
+# Same positional signature, same return value (G x 17 Matrix{Any} for two groups).  To use it inside
+# the package: `include("RankCompV3HIP.jl")` after the original definition, or replace the call at
+# src/RankCompV3.jl:652 with `RankCompV3HIP.identify_degs(...)`.
+# NOT EXECUTED in this repository's pipeline (no Julia toolchain in the image); kept logic-free.
+module RankCompV3HIP
+
+const LIB = get(ENV, "LIBREO_HIP", "libreo_hip")
+
+function check(rc::Int32)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:reo_last_error, LIB), Cstring, ()))
+    rc == -1 ? throw(DimensionMismatch(msg)) : error("libreo_hip status $rc: $msg")
+end
+
+function identify_degs(data::AbstractMatrix, group::AbstractVector, gene_names::AbstractVector,
+                       pval_reo::AbstractFloat, pval_deg::AbstractFloat, padj_deg::AbstractFloat,
+                       ref_gene::BitVector, n_iter::Int64, n_conv::Int64;
+                       seed::UInt64 = rand(UInt64), device::Integer = -1)
+    r, c = size(data)
+    glev = unique(group)                                            # :353
+    c == length(group) || throw(DimensionMismatch("'data' and 'group' do not have compatiable sizes"))
+    length(glev) > 1   || throw(DimensionMismatch("Only 1 level in 'group1, at least 2 levels!"))
+    gid = Int32[findfirst(==(g), glev) - 1 for g in group]          # 0-based, first-appearance order
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:reo_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, UInt64), ctx, device, seed))
+    try
+        if eltype(data) <: Integer
+            X = Matrix{Int64}(data)
+            check(ccall((:reo_set_matrix_i64, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Int64, Int64), ctx[], X, r, c, r))
+        else
+            X = Matrix{Float64}(data)
+            check(ccall((:reo_set_matrix_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64), ctx[], X, r, c, r))
+        end
+        check(ccall((:reo_set_groups, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int64, Int32), ctx[], gid, c, length(glev)))
+        check(ccall((:reo_compute_thresholds, LIB), Int32, (Ptr{Cvoid}, Float64), ctx[], pval_reo))           # :362
+        check(ccall((:reo_build_pairs, LIB), Int32, (Ptr{Cvoid}, Int32), ctx[], 0))                            # :363-392
+        result = zeros(Float64, r, 15)                                                                        # :398
+        ref0 = UInt8.(ref_gene)
+        iters = Ref{Int32}(0)
+        trace = zeros(Int32, 2, max(n_iter, 1))
+        check(ccall((:reo_identify_degs, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{UInt8}, Float64, Float64, Int32, Int32, Ptr{Float64}, Ref{Int32}, Ptr{Int32}),
+                    ctx[], ref0, pval_deg, padj_deg, n_iter, n_conv, result, iters, trace))                    # :396-425
+        for p in 1:iters[]
+            @info "INFO: iteration $(p-1),  # DEGs $(trace[1,p]), # non-DEGs $(trace[2,p])"                    # :418
+        end
+        gene_up_down = fill("no change", r)                                                                   # :426-429
+        sig = (result[:, 1] .<= pval_deg) .& (result[:, 2] .<= padj_deg)
+        gene_up_down[sig .& (result[:, 15] .> 0)] .= "up"
+        gene_up_down[sig .& (result[:, 15] .< 0)] .= "down"
+        return hcat(gene_names, result, gene_up_down)                                                         # :430,437
+    finally
+        ccall((:reo_destroy, LIB), Cvoid, (Ptr{Cvoid},), ctx[])
+    end
+end
+
+end # module
