@@ -46,6 +46,8 @@ def main() -> None:
     ap.add_argument("--n-iter", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-genes", type=int, default=6000)
+    ap.add_argument("--debug-gloo-one-gpu", action="store_true",
+                    help="debug only: every rank uses cuda:0 and the all-reduce goes through gloo via the host")
     args = ap.parse_args()
 
     import torch
@@ -56,10 +58,15 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.debug_gloo_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.debug_gloo_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pkg = ge.load_pkg()
     G, S, seed = args.genes, args.samples, 0x5EED0003
@@ -76,7 +83,7 @@ def main() -> None:
     if world > 1:
         ctx.set_shard(rank, world)
 
-        ctx.set_allreduce(pkg.dist.allreduce_hook(dev))
+        ctx.set_allreduce(pkg.dist.allreduce_hook(dev, via_host=args.debug_gloo_one_gpu))
 
     verbose = bool(os.environ.get("REO_BENCH_VERBOSE"))
 
@@ -109,7 +116,7 @@ def main() -> None:
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.debug_gloo_one_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, iters, trace, ctx.timings(), res

@@ -501,44 +501,83 @@ __device__ __forceinline__ int upper_bound_d(const double *__restrict__ a, int n
     return lo;
 }
 
-__global__ __launch_bounds__(1024) void k3_sort_chunks(const IterState *__restrict__ st,
-                                                       const double *__restrict__ d1, int G,
-                                                       double *__restrict__ cv, uint16_t *__restrict__ ci)
+// compare-exchange with the partner's element: keep the smaller value if keep_min, else the larger.
+// Equal values need no tie-break here: any consistent order among them still makes the ranks
+// permutations, and every quantity derived from them (sorted values, BH, trimmed std) is identical.
+__device__ __forceinline__ void cmpx(double &v, uint32_t &i, double pv, uint32_t pi, bool keep_min)
 {
-    if (st->done) return;
-    __shared__ double v[kSortChunk];
-    __shared__ uint16_t id[kSortChunk];
-    const int base = blockIdx.x * kSortChunk;
-    for (int t = threadIdx.x; t < kSortChunk; t += 1024) {
-        const int g = base + t;
-        v[t] = g < G ? d1[g] : INFINITY;  // padding sorts to the end of the last chunk
-        id[t] = static_cast<uint16_t>(t);
-    }
-    for (int k = 2; k <= kSortChunk; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            const int t = threadIdx.x;
-            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // low element of pair t
-            const int l = i + j;
-            const bool up = (i & k) == 0;
-            const double va = v[i], vb = v[l];
-            const uint16_t ia = id[i], ib = id[l];
-            const bool gt = va > vb || (va == vb && ia > ib);
-            if (gt == up) { v[i] = vb; v[l] = va; id[i] = ib; id[l] = ia; }
-        }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < kSortChunk; t += 1024) {
-        cv[base + t] = v[t];
-        ci[base + t] = id[t];
-    }
+    const bool take = keep_min ? (pv < v) : (pv > v);
+    if (take) { v = pv; i = pi; }
 }
 
+// Bitonic sort of one 2048-gene chunk by 512 threads, four consecutive elements per thread in
+// registers.  Exchange distances 1 and 2 stay inside the thread, distances 4..128 go through wave
+// shuffles, and only the six stages with distance >= 256 (partner in another wave) use LDS + a barrier.
+__global__ __launch_bounds__(512) void k3_sort_chunks(const IterState *__restrict__ st,
+                                                      const double *__restrict__ d1, int G,
+                                                      double *__restrict__ cv, uint16_t *__restrict__ ci)
+{
+    if (st->done) return;
+    __shared__ double sv[kSortChunk];
+    __shared__ uint16_t si[kSortChunk];
+    const int t = threadIdx.x, base = blockIdx.x * kSortChunk;
+    const int x0 = 4 * t;  // element index of this thread's first slot
+    double v[4];
+    uint32_t id[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = base + x0 + e < G ? d1[base + x0 + e] : INFINITY;  // padding sorts to the end of the last chunk
+        id[e] = x0 + e;
+    }
+#define REO_CX(a, b)                                                                      \
+    {                                                                                     \
+        const bool up_ = ((x0 + (a)) & k) == 0;                                           \
+        if ((v[a] > v[b]) == up_) {                                                       \
+            const double tv_ = v[a]; v[a] = v[b]; v[b] = tv_;                             \
+            const uint32_t ti_ = id[a]; id[a] = id[b]; id[b] = ti_;                       \
+        }                                                                                 \
+    }
+    for (int k = 2; k <= kSortChunk; k <<= 1) {
+        const bool up = (x0 & k) == 0;  // for k >= 4 all four slots share the direction
+        for (int j = k >> 1; j >= 256; j >>= 1) {
+            const int m = j >> 2;  // partner thread distance (>= 64: another wave)
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sv[x0 + e] = v[e]; si[x0 + e] = static_cast<uint16_t>(id[e]); }
+            __syncthreads();
+            const int px = 4 * (t ^ m);
+            const bool keep_min = ((t & m) == 0) == up;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cmpx(v[e], id[e], sv[px + e], si[px + e], keep_min);
+        }
+        for (int j = (k >> 1) < 128 ? (k >> 1) : 128; j >= 4; j >>= 1) {
+            const int m = j >> 2;  // 1..32: inside the wave
+            const bool keep_min = ((t & m) == 0) == up;
+            double pv[4];
+            uint32_t pi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pv[e] = __shfl_xor(v[e], m, 64); pi[e] = __shfl_xor(id[e], m, 64); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cmpx(v[e], id[e], pv[e], pi[e], keep_min);
+        }
+        if (k >= 4) { REO_CX(0, 2) REO_CX(1, 3) }
+        REO_CX(0, 1) REO_CX(2, 3)
+    }
+#undef REO_CX
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cv[base + x0 + e] = v[e]; ci[base + x0 + e] = static_cast<uint16_t>(id[e]); }
+}
+
+// Two-level search: every 32nd element of every chunk (64 splitters per chunk) is staged in LDS;
+// six LDS steps pick the 32-element segment, five global steps finish inside it.
 __global__ __launch_bounds__(256) void k3_merge_rank(const IterState *__restrict__ st, const double *__restrict__ cv,
                                                      const uint16_t *__restrict__ ci, int G, int nchunk,
                                                      uint32_t *__restrict__ rs, double *__restrict__ sorted_d)
 {
     if (st->done) return;
+    __shared__ double spl[32 * 64];  // [chunk][64], nchunk <= 32
+    for (int t = threadIdx.x; t < nchunk * 64; t += 256) spl[t] = cv[(t >> 6) * kSortChunk + ((t & 63) << 5)];
+    __syncthreads();
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int c = e / kSortChunk, p = e % kSortChunk;  // c is uniform in the workgroup
     const int gene = c * kSortChunk + ci[e];
@@ -550,18 +589,32 @@ __global__ __launch_bounds__(256) void k3_merge_rank(const IterState *__restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int cc = c0 + u;
-            lo[u] = 0;
-            hi[u] = (cc < nchunk && cc != c) ? min(kSortChunk, G - cc * kSortChunk) : 0;
+            const bool on = cc < nchunk && cc != c;
+            const int n = on ? min(kSortChunk, G - cc * kSortChunk) : 0;  // valid elements of that chunk
+            // segment search over the splitters: number of splitters that sort before v
+            int a = 0, b = on ? (n + 31) >> 5 : 0;
+            const double *sp = spl + (cc < nchunk ? cc : 0) * 64;
+#pragma unroll 1
+            for (int step = 0; step < 7 && a < b; ++step) {
+                const int m = (a + b) >> 1;
+                const double w = sp[m];
+                const bool less = cc < c ? (w <= v) : (w < v);  // equal values of earlier genes sort first
+                if (less) a = m + 1; else b = m;
+            }
+            // a = count of splitters before v: the answer lies in (32(a-1), 32a] clipped to the chunk
+            lo[u] = a > 0 ? ((a - 1) << 5) + 1 : 0;
+            hi[u] = a > 0 ? min(n, a << 5) : 0;
+            if (!on) { lo[u] = 0; hi[u] = 0; }
         }
 #pragma unroll 1
-        for (int step = 0; step < 12; ++step) {  // 2^11 = kSortChunk: 12 halvings empty every interval
+        for (int step = 0; step < 6; ++step) {  // at most 32 candidates left
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (lo[u] < hi[u]) {
                     const int cc = c0 + u;
                     const int m = (lo[u] + hi[u]) >> 1;
                     const double w = cv[cc * kSortChunk + m];
-                    const bool less = cc < c ? (w <= v) : (w < v);  // equal values of earlier genes sort first
+                    const bool less = cc < c ? (w <= v) : (w < v);
                     if (less) lo[u] = m + 1; else hi[u] = m;
                 }
             }
@@ -573,6 +626,19 @@ __global__ __launch_bounds__(256) void k3_merge_rank(const IterState *__restrict
     sorted_d[rank] = v;
 }
 
+// count of elements < v (strict = true) or <= v (strict = false) in the sorted array a[0..n): a coarse
+// search over every 64th element staged in LDS, then at most six steps in global memory
+__device__ __forceinline__ int bound_2level(const double *__restrict__ a, int n, const double *spl, int nspl,
+                                            double v, bool strict)
+{
+    int lo = 0, hi = nspl;  // splitter m = a[64 m]
+    while (lo < hi) { const int m = (lo + hi) >> 1; const double w = spl[m]; if (strict ? (w < v) : (w <= v)) lo = m + 1; else hi = m; }
+    if (lo == 0) return 0;
+    int l = ((lo - 1) << 6) + 1, h = min(n, lo << 6);
+    while (l < h) { const int m = (l + h) >> 1; const double w = a[m]; if (strict ? (w < v) : (w <= v)) l = m + 1; else h = m; }
+    return l;
+}
+
 __global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__ st, const double *__restrict__ d1,
                                                    const uint32_t *__restrict__ rs,
                                                    const double *__restrict__ sorted_d, int G, int a0, int b0,
@@ -580,15 +646,19 @@ __global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__
 {
     if (st->done) return;
     __shared__ double red[256];
+    __shared__ double spl[1024];  // every 64th element of the sorted vector (G <= 65535)
+    const int nspl = (G + 63) >> 6;
+    for (int t = threadIdx.x; t < nspl; t += 256) spl[t] = sorted_d[t << 6];
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < G) {
         const double v = d1[i];
         const int r = rs[i];
-        const int lbv = lower_bound_d(sorted_d, G, v);
-        const int ubn = upper_bound_d(sorted_d, G, -v);
+        const int lbv = bound_2level(sorted_d, G, spl, nspl, v, true);
+        const int ubn = bound_2level(sorted_d, G, spl, nspl, -v, false);
         int rank;
         if (v > 0.0) {  // larger |w|: w > v or w < -v; ties: the negatives -v first, then equals of v in sorted order
-            const int ubv = upper_bound_d(sorted_d, G, v);
+            const int ubv = bound_2level(sorted_d, G, spl, nspl, v, false);
             rank = (G - ubv) + ubn + (r - lbv);
         } else {        // larger |w|: w < v or w > -v
             rank = lbv + (G - ubn) + (r - lbv);
@@ -849,7 +919,7 @@ int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int 
     double *res = c->result.p;
     const double *d1 = res + 11 * c->G;
     const int nchunk = (G + kSortChunk - 1) / kSortChunk;
-    k3_sort_chunks<<<nchunk, 1024, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p);
+    k3_sort_chunks<<<nchunk, 512, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p);
     k3_merge_rank<<<nchunk * kSortChunk / 256, 256, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
                                                                    c->rank_s.p, c->sorted_d.p);
     k3_abs_rank<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->sorted_d.p, G, static_cast<int>(a - 1),

@@ -16,14 +16,22 @@ class _RawDev:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
-def allreduce_hook(device=None, group=None):
+def allreduce_hook(device=None, group=None, via_host: bool = False):
     """fn(ptr, count): sum int32[count] at `ptr` across the process group, in place.
-    `device` is a torch cuda device for device pointers, None for host pointers (gloo tests)."""
+    `device` is a torch cuda device for device pointers, None for host pointers (gloo tests).
+    via_host=True stages a device buffer through the host so that a gloo group can reduce it
+    (debugging the sharded flow with several ranks on one GPU, where RCCL refuses to run)."""
     import torch
     import torch.distributed as dist
 
     def fn(ptr: int, count: int) -> None:
-        if device is not None:
+        if device is not None and via_host:
+            t = torch.as_tensor(_RawDev(ptr, count), device=device)
+            h = t.cpu()
+            dist.all_reduce(h, group=group)
+            t.copy_(h)
+            torch.cuda.synchronize(device)
+        elif device is not None:
             t = torch.as_tensor(_RawDev(ptr, count), device=device)
             dist.all_reduce(t, group=group)
             torch.cuda.synchronize(device)
