@@ -84,7 +84,7 @@ int32_t reo_set_matrix_dev_i64(reo_ctx *ctx, const void *dX, int64_t G, int64_t 
 /* Group of each sample: the `group` argument (src/RankCompV3.jl:341) recoded
  * to 0-based ids in order of first appearance (unique(), :353).  Length must
  * equal S (else REO_EINVAL = the DimensionMismatch of :355); ngroups must be
- * >= 2 (:356).  This round only ngroups == 2 is built by reo_build_pairs. */
+ * >= 2 (:356) and <= 64. */
 int32_t reo_set_groups(reo_ctx *ctx, const int32_t *group_id, int64_t len, int32_t ngroups);
 
 /* Stable-REO thresholds: get_major_reo_lower_count (src/RankCompV3.jl:81-92)
@@ -97,7 +97,8 @@ int32_t reo_get_thresholds(reo_ctx *ctx, int32_t *m);
 /* The threshold function itself (host arithmetic), for tests. */
 int32_t reo_threshold(int32_t sample_size, double pval_reo);
 
-/* REO table build for comparison k (group k vs rest): replaces the pair loop
+/* REO table build for comparison k (group k vs every other sample; with two
+ * groups the reference only runs k = 0, :387-389): replaces the pair loop
  * src/RankCompV3.jl:363-392.  Runs the per-sample rank/band transform and the
  * pair-compare kernel and leaves the 4-bit class table in HBM. */
 int32_t reo_build_pairs(reo_ctx *ctx, int32_t k);

@@ -1,6 +1,6 @@
 # Drop-in replacement for `identify_degs` of RankCompV3.jl (src/RankCompV3.jl:339-438) that runs the
 # pair loop, the tallies and the iteration on an MI355X through libreo_hip.so (include/reo_hip.h).
-# Same positional signature, same return value (G x 17 Matrix{Any} for two groups).  To use it inside
+# Same positional signature, same return value (G x (1 + 16 C) Matrix{Any}; C = 1 for two groups).  To use it inside
 # the package: `include("RankCompV3HIP.jl")` after the original definition, or replace the call at
 # src/RankCompV3.jl:652 with `RankCompV3HIP.identify_degs(...)`.
 # NOT EXECUTED in this repository's pipeline (no Julia toolchain in the image); kept logic-free.
@@ -35,22 +35,27 @@ function identify_degs(data::AbstractMatrix, group::AbstractVector, gene_names::
         end
         check(ccall((:reo_set_groups, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int64, Int32), ctx[], gid, c, length(glev)))
         check(ccall((:reo_compute_thresholds, LIB), Int32, (Ptr{Cvoid}, Float64), ctx[], pval_reo))           # :362
-        check(ccall((:reo_build_pairs, LIB), Int32, (Ptr{Cvoid}, Int32), ctx[], 0))                            # :363-392
-        result = zeros(Float64, r, 15)                                                                        # :398
+        res = Matrix{Any}(reshape(gene_names, r, 1))
         ref0 = UInt8.(ref_gene)
-        iters = Ref{Int32}(0)
-        trace = zeros(Int32, 2, max(n_iter, 1))
-        check(ccall((:reo_identify_degs, LIB), Int32,
-                    (Ptr{Cvoid}, Ptr{UInt8}, Float64, Float64, Int32, Int32, Ptr{Float64}, Ref{Int32}, Ptr{Int32}),
-                    ctx[], ref0, pval_deg, padj_deg, n_iter, n_conv, result, iters, trace))                    # :396-425
-        for p in 1:iters[]
-            @info "INFO: iteration $(p-1),  # DEGs $(trace[1,p]), # non-DEGs $(trace[2,p])"                    # :418
+        for k in 1:length(glev)                                                                               # :396
+            check(ccall((:reo_build_pairs, LIB), Int32, (Ptr{Cvoid}, Int32), ctx[], k - 1))                   # :363-392
+            result = zeros(Float64, r, 15)                                                                    # :398
+            iters = Ref{Int32}(0)
+            trace = zeros(Int32, 2, max(n_iter, 1))
+            check(ccall((:reo_identify_degs, LIB), Int32,
+                        (Ptr{Cvoid}, Ptr{UInt8}, Float64, Float64, Int32, Int32, Ptr{Float64}, Ref{Int32}, Ptr{Int32}),
+                        ctx[], ref0, pval_deg, padj_deg, n_iter, n_conv, result, iters, trace))                # :400-425
+            for p in 1:iters[]
+                @info "INFO: iteration $(p-1),  # DEGs $(trace[1,p]), # non-DEGs $(trace[2,p])"                # :418
+            end
+            gene_up_down = fill("no change", r)                                                               # :426-429
+            sig = (result[:, 1] .<= pval_deg) .& (result[:, 2] .<= padj_deg)
+            gene_up_down[sig .& (result[:, 15] .> 0)] .= "up"
+            gene_up_down[sig .& (result[:, 15] .< 0)] .= "down"
+            res = hcat(res, result, gene_up_down)                                                             # :430
+            length(glev) == 2 && break                                                                        # :431-434
         end
-        gene_up_down = fill("no change", r)                                                                   # :426-429
-        sig = (result[:, 1] .<= pval_deg) .& (result[:, 2] .<= padj_deg)
-        gene_up_down[sig .& (result[:, 15] .> 0)] .= "up"
-        gene_up_down[sig .& (result[:, 15] .< 0)] .= "down"
-        return hcat(gene_names, result, gene_up_down)                                                         # :430,437
+        return res                                                                                            # :437
     finally
         ccall((:reo_destroy, LIB), Cvoid, (Ptr{Cvoid},), ctx[])
     end

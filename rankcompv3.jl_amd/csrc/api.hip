@@ -334,10 +334,6 @@ int32_t reo_build_pairs(reo_ctx *c, int32_t k)
     if (rc) return rc;
     if ((rc = ensure_transform(c))) return rc;
     if (!c->thr_set) { set_error("thresholds not set (reo_compute_thresholds)"); return REO_EINVAL; }
-    if (c->ngroups != 2) {
-        set_error("one-vs-rest with %d groups is not built yet; two groups only", c->ngroups);
-        return REO_EINVAL;
-    }
     if (k < 0 || k >= c->ngroups) { set_error("comparison %d outside [0,%d)", k, c->ngroups); return REO_EINVAL; }
     if ((rc = c->table.ensure(static_cast<size_t>(c->G) * kPlanes * c->Wp))) return rc;
     if ((rc = launch_k1(c, k))) return rc;

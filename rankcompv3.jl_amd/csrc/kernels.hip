@@ -159,13 +159,17 @@ struct K1Args {
     int m1, m2;          // threshold[1,k], threshold[2,k] (:362)
     uint64_t seed;
     int n_units, Q;      // units owned by this shard; j-chunks per panel
+    const int32_t *goff; // MULTI: group offsets in units of 8 sample slots (ngroups + 1)
+    int ngroups;
 };
 
 // state of one side: 0 = "i<j stable" (reference 1), 1 = unstable (2), 2 = "i>j stable" (3)  (:376-377)
 __device__ __forceinline__ int side_state(int n, int size, int m) { return n >= m ? 2 : ((size - n) >= m ? 0 : 1); }
 
-template <int RI, int RJ, bool TIES>
-__global__ __launch_bounds__(256, (TIES || RJ > 1) ? 4 : 5) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap 128 / 64
+// MULTI = one-vs-rest with more than two groups (:375-390): the treat side is every other group,
+// counted group by group because the tie coins are keyed by group.
+template <int RI, int RJ, bool TIES, bool MULTI>
+__global__ __launch_bounds__(256, MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4 : 5)) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
 {
     static_assert(RI == 32, "one mirror word per tile");
     const int lane = threadIdx.x & 63;
@@ -209,22 +213,57 @@ __global__ __launch_bounds__(256, (TIES || RJ > 1) ? 4 : 5) void k1_pairs(K1Args
             cH[r] |= (st == 2 ? 1u : 0u) << ii;
         }
     }
-    count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge);
+    if (!MULTI) {
+        count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge);
 #pragma unroll
-    for (int r = 0; r < RJ; ++r) {
-        tL[r] = 0; tH[r] = 0;
+        for (int r = 0; r < RJ; ++r) {
+            tL[r] = 0; tH[r] = 0;
 #pragma unroll
-        for (int ii = 0; ii < RI; ++ii) {
-            const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
-            int nre = static_cast<int>(fgt);
-            if (TIES) {
-                const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
-                const uint32_t neq = static_cast<uint32_t>(fge - fgt);
-                if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, a.gt, neq);
+            for (int ii = 0; ii < RI; ++ii) {
+                const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
+                int nre = static_cast<int>(fgt);
+                if (TIES) {
+                    const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
+                    const uint32_t neq = static_cast<uint32_t>(fge - fgt);
+                    if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, a.gt, neq);
+                }
+                const int st = side_state(nre, a.nt, a.m2);
+                tL[r] |= (st == 0 ? 1u : 0u) << ii;
+                tH[r] |= (st == 2 ? 1u : 0u) << ii;
             }
-            const int st = side_state(nre, a.nt, a.m2);
-            tL[r] |= (st == 0 ? 1u : 0u) << ii;
-            tH[r] |= (st == 2 ? 1u : 0u) << ii;
+        }
+    } else {
+        int tot[RJ][RI];  // not = sum(nre) - nre[k]  (:374)
+#pragma unroll
+        for (int r = 0; r < RJ; ++r)
+#pragma unroll
+            for (int ii = 0; ii < RI; ++ii) tot[r][ii] = 0;
+        for (int g = 0; g < a.ngroups; ++g) {
+            if (g == a.gc) continue;
+            count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge);
+#pragma unroll
+            for (int r = 0; r < RJ; ++r)
+#pragma unroll
+                for (int ii = 0; ii < RI; ++ii) {
+                    const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
+                    int nre = static_cast<int>(fgt);
+                    if (TIES) {
+                        const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
+                        const uint32_t neq = static_cast<uint32_t>(fge - fgt);
+                        if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, g, neq);
+                    }
+                    tot[r][ii] += nre;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < RJ; ++r) {
+            tL[r] = 0; tH[r] = 0;
+#pragma unroll
+            for (int ii = 0; ii < RI; ++ii) {
+                const int st = side_state(tot[r][ii], a.nt, a.m2);
+                tL[r] |= (st == 0 ? 1u : 0u) << ii;
+                tH[r] |= (st == 2 ? 1u : 0u) << ii;
+            }
         }
     }
 
@@ -808,11 +847,13 @@ int32_t launch_k1(reo_ctx *c, int k)
     K1Args a;
     a.pos8 = reinterpret_cast<const uint4 *>(c->pos.p); a.lo = c->lo.p; a.hi = c->hi.p; a.table = c->table.p;
     a.G = static_cast<int>(c->G); a.Gp = c->Gp; a.Wp = c->Wp;
-    const int other = 1 - k;  // two groups
+    const bool multi = c->ngroups > 2;
+    const int other = multi ? k : 1 - k;  // two groups: the treat side is the other group
     a.cb = c->goff8[k] / 8; a.ce = c->goff8[k + 1] / 8;
     a.tb = c->goff8[other] / 8; a.te = c->goff8[other + 1] / 8;
     a.gc = k; a.gt = other;
-    a.nc = c->goff[k + 1] - c->goff[k]; a.nt = c->goff[other + 1] - c->goff[other];
+    a.nc = c->goff[k + 1] - c->goff[k]; a.nt = static_cast<int>(c->S) - a.nc;  // gsi1, gsi2 (:358-359)
+    a.goff = c->goff_dev.p; a.ngroups = c->ngroups;
     a.m1 = c->thr[2 * k]; a.m2 = c->thr[2 * k + 1];
     a.seed = c->seed;
 
@@ -852,10 +893,13 @@ int32_t launch_k1(reo_ctx *c, int k)
     if (units.empty()) return REO_OK;
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
     tic(c, 1);
-    if (c->has_ties)
-        k1_pairs<kTileI, 1, true><<<grid, 256, 0, c->stream>>>(a);
-    else
-        k1_pairs<kTileI, kRJ, false><<<grid, 256, 0, c->stream>>>(a);
+    if (multi) {
+        if (c->has_ties) k1_pairs<kTileI, 1, true, true><<<grid, 256, 0, c->stream>>>(a);
+        else k1_pairs<kTileI, kRJ, false, true><<<grid, 256, 0, c->stream>>>(a);
+    } else {
+        if (c->has_ties) k1_pairs<kTileI, 1, true, false><<<grid, 256, 0, c->stream>>>(a);
+        else k1_pairs<kTileI, kRJ, false, false><<<grid, 256, 0, c->stream>>>(a);
+    }
     toc(c);
     REO_HIP_CHECK(hipGetLastError());
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `units` is read by the async copy above

@@ -44,22 +44,24 @@ def label_genes(result: np.ndarray, pval_deg: float, padj_deg: float) -> np.ndar
 
 @dataclass
 class DegRun:
-    """Everything one comparison produced (the reference only keeps `res`)."""
-    res: np.ndarray                 # G x 17 object matrix, the reference's return value (:437)
-    result: np.ndarray              # G x 15 Float64
-    labels: np.ndarray
+    """Everything the comparisons produced (the reference only keeps `res`)."""
+    res: np.ndarray                 # G x (1 + 16 C) object matrix, the reference's return value (:437)
+    result: np.ndarray              # G x 15 Float64 of the first comparison
+    labels: np.ndarray              # labels of the first comparison
     levels: list
     thresholds: np.ndarray          # 2 x ngroups (:362)
     iters_run: int
-    trace: list = field(default_factory=list)   # (#DEG, #non-DEG) per pass (:418)
+    trace: list = field(default_factory=list)   # (#DEG, #non-DEG) per pass (:418), first comparison
     timings: dict = field(default_factory=dict)
     info: dict = field(default_factory=dict)
+    comparisons: list = field(default_factory=list)  # per comparison: dict(k, result, labels, iters_run, trace)
 
 
 def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, *,
                       seed: int = 0, device: int = -1, shard=(0, 1), allreduce=None, profile: bool = False) -> DegRun:
-    """identify_degs with the extras (trace, timings) kept.  Two groups (the
-    reference's `gnum == 2` path, :387-389,431-434); one-vs-rest is the next row."""
+    """identify_degs with the extras (trace, timings) kept.  Two groups: one comparison, group 1 vs
+    group 2 (the reference's `gnum == 2` path, :387-389,431-434).  More groups: one comparison per
+    group, that group vs every other sample (:375-390,396-436), 16 more columns each."""
     data = np.asarray(data)
     if data.ndim != 2:
         raise _ffi.DimensionMismatch(_ffi.REO_EINVAL, "'data' must be a genes x samples matrix")
@@ -71,6 +73,8 @@ def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref
         raise _ffi.DimensionMismatch(_ffi.REO_EINVAL, "Only 1 level in 'group1, at least 2 levels!")
     if len(gene_names) != r or len(ref_gene) != r:
         raise _ffi.DimensionMismatch(_ffi.REO_EINVAL, "gene_names / ref_gene length != number of rows of 'data'")
+    ncomp = 1 if len(levels) == 2 else len(levels)
+    comps = []
     with _ffi.Context(device=device, seed=seed) as ctx:
         ctx.set_profiling(profile)
         ctx.set_matrix(data)
@@ -79,21 +83,25 @@ def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref
         if shard[1] > 1:
             ctx.set_shard(*shard)
             ctx.set_allreduce(allreduce)
-        ctx.build_pairs(0)
-        result, iters, trace = ctx.identify_degs(np.asarray(ref_gene, dtype=bool), pval_deg, padj_deg, n_iter, n_conv)
+        for k in range(ncomp):  # `for k=1:gnum ... if gnum==2 break` (:396,431-434)
+            ctx.build_pairs(k)
+            result, iters, trace = ctx.identify_degs(np.asarray(ref_gene, dtype=bool), pval_deg, padj_deg, n_iter, n_conv)
+            comps.append({"k": k, "result": result, "labels": label_genes(result, pval_deg, padj_deg),
+                          "iters_run": iters, "trace": trace})
         timings = ctx.timings() if profile else {}
         info = ctx.info()
-    labels = label_genes(result, pval_deg, padj_deg)
-    res = np.empty((r, 17), dtype=object)  # hcat(gene_names, result, gene_up_down), :430
+    res = np.empty((r, 1 + 16 * ncomp), dtype=object)  # hcat(res, result, gene_up_down) per comparison (:430)
     res[:, 0] = np.asarray(gene_names, dtype=object)
-    res[:, 1:16] = result
-    res[:, 16] = labels
-    return DegRun(res=res, result=result, labels=labels, levels=levels, thresholds=thr, iters_run=iters, trace=trace,
-                  timings=timings, info=info)
+    for q, cm in enumerate(comps):
+        res[:, 1 + 16 * q: 16 + 16 * q] = cm["result"]
+        res[:, 16 + 16 * q] = cm["labels"]
+    first = comps[0]
+    return DegRun(res=res, result=first["result"], labels=first["labels"], levels=levels, thresholds=thr,
+                  iters_run=first["iters_run"], trace=first["trace"], timings=timings, info=info, comparisons=comps)
 
 
 def identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, **kw) -> np.ndarray:
-    """Drop-in for identify_degs (src/RankCompV3.jl:339-350): same arguments in
-    the same order, same G x 17 return.  `seed=` keys the tie coins that the
-    reference draws from its unseeded global RNG (:73)."""
+    """Drop-in for identify_degs (src/RankCompV3.jl:339-350): same arguments in the same order, same
+    G x (1 + 16 C) return (C = 1 for two groups, else the number of groups).  `seed=` keys the tie
+    coins that the reference draws from its unseeded global RNG (:73)."""
     return run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, **kw).res

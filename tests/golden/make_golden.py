@@ -32,16 +32,16 @@ def dump(name, obj):
     print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
 
 
-def case(X, gid, ngroups, ref0, pval_reo, pval_deg, padj_deg, n_iter, n_conv, seed):
+def case(X, gid, ngroups, ref0, pval_reo, pval_deg, padj_deg, n_iter, n_conv, seed, k=0):
     G = X.shape[0]
     sizes = np.bincount(gid, minlength=ngroups)
-    thr = [oracle.threshold(int(sizes[0]), pval_reo), oracle.threshold(int(sizes.sum() - sizes[0]), pval_reo)]
-    assert thr == [rn.threshold(int(sizes[0]), pval_reo), rn.threshold(int(sizes.sum() - sizes[0]), pval_reo)]
+    thr = [oracle.threshold(int(sizes[k]), pval_reo), oracle.threshold(int(sizes.sum() - sizes[k]), pval_reo)]
+    assert thr == [rn.threshold(int(sizes[k]), pval_reo), rn.threshold(int(sizes.sum() - sizes[k]), pval_reo)]
     gt, eq = oracle.pair_counts(X, gid, ngroups, 0, G, 0, G)
     gt2, eq2 = rn.pair_counts(X, gid, ngroups)
     assert np.array_equal(gt, gt2) and np.array_equal(eq, eq2)
-    code = oracle.build_codes(X, gid, ngroups, 0, thr, seed)
-    assert np.array_equal(code, rn.build_codes(X, gid, ngroups, 0, thr, seed))
+    code = oracle.build_codes(X, gid, ngroups, k, thr, seed)
+    assert np.array_equal(code, rn.build_codes(X, gid, ngroups, k, thr, seed))
     cont = oracle.tally(code, ref0)
     assert np.array_equal(cont, rn.tally(code, ref0))
     res, iters, trace = oracle.iterate(code, ref0, pval_deg, padj_deg, n_iter, n_conv)
@@ -50,7 +50,7 @@ def case(X, gid, ngroups, ref0, pval_reo, pval_deg, padj_deg, n_iter, n_conv, se
     return {
         "X": X.tolist(), "gid": gid.tolist(), "ngroups": ngroups, "ref0": np.asarray(ref0, dtype=int).tolist(),
         "pval_reo": pval_reo, "pval_deg": pval_deg, "padj_deg": padj_deg, "n_iter": n_iter, "n_conv": n_conv,
-        "seed": seed, "thr": thr, "n_gt": gt.tolist(), "n_eq": eq.tolist(), "code": code.tolist(),
+        "seed": seed, "k": k, "thr": thr, "n_gt": gt.tolist(), "n_eq": eq.tolist(), "code": code.tolist(),
         "cont": cont.tolist(), "result": res.tolist(), "iters_run": iters, "trace": [list(t) for t in trace],
         "labels": rn.labels(res, pval_deg, padj_deg).tolist(),
     }
@@ -125,6 +125,20 @@ def main():
     assert sing, "example must exercise the singular-N branch"
     ch["singular_rows"] = sing
     dump("hand12.json", ch)
+
+    # (4b) three groups, one-vs-rest (:375-390,396-436): 48 genes of the bundled data, samples relabelled a/b/c
+    gid3 = np.array([0, 1, 2, 0, 1, 2, 0, 1, 2, 1], dtype=np.int32)
+    X3 = X[list(range(0, 30)) + list(range(12000, 12018))].astype(np.float64)
+    ref3 = np.ones(48, dtype=bool)
+    ref3[5::7] = False
+    multi = {"X": X3.tolist(), "gid": gid3.tolist(), "ngroups": 3, "ref0": ref3.astype(int).tolist(),
+             "comparisons": [case(X3, gid3, 3, ref3, 0.3, 1.0, 0.05, 6, 1, SEED, k=k) for k in range(3)]}
+    for cm in multi["comparisons"]:
+        for key in ("X", "gid", "ngroups", "ref0", "n_gt", "n_eq"):
+            cm.pop(key)
+    gt3, eq3 = oracle.pair_counts(X3, gid3, 3, 0, 48, 0, 48)
+    multi["n_gt"], multi["n_eq"] = gt3.tolist(), eq3.tolist()
+    dump("three_groups48.json", multi)
 
     # (5) BH + trimmed-std vectors, incl. half-even rounding and the G=10 error path
     rng = np.random.default_rng(12345)

@@ -309,3 +309,38 @@ def test_two_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle):
         assert np.array_equal(cont, oracle.tally(code, ref0))
         assert iters == eit and trace == etr
         _check_result(res, exp)
+
+
+def test_three_group_golden_and_synthetic_one_vs_rest(pkg, oracle, golden):
+    """More than two groups: one comparison per group against every other sample, 16 columns each."""
+    g = golden("three_groups48.json")
+    X = np.array(g["X"], dtype=np.float64)
+    with pkg.Context(device=0, seed=g["comparisons"][0]["seed"]) as ctx:
+        ctx.set_matrix(X)
+        ctx.set_groups(g["gid"], 3)
+        ctx.compute_thresholds(g["comparisons"][0]["pval_reo"])
+        gt, eq = ctx.pair_counts(0, 48, 0, 48)
+        assert np.array_equal(gt, g["n_gt"]) and np.array_equal(eq, g["n_eq"])
+        for cm in g["comparisons"]:
+            assert ctx.get_thresholds()[:, cm["k"]].tolist() == cm["thr"]
+            ctx.build_pairs(cm["k"])
+            assert np.array_equal(ctx.get_codes(0, 48, 0, 48), cm["code"])
+            assert np.array_equal(ctx.tally(np.array(g["ref0"])), cm["cont"])
+            res, iters, trace = ctx.identify_degs(np.array(g["ref0"]), cm["pval_deg"], cm["padj_deg"], cm["n_iter"], cm["n_conv"])
+            assert iters == cm["iters_run"] and [list(t) for t in trace] == cm["trace"]
+            _check_result(res, np.array(cm["result"]))
+    # synthetic: three groups of unequal size, tie-rich / tie-free / float
+    for family, gen in (("t1", pkg.synth.t1_counts), ("t0", pkg.synth.t0_ranks), ("float", pkg.synth.float_expr)):
+        G, S, seed = 520, 47, 0x5EED0006
+        X = gen(G, S, seed)
+        group = np.array(["a"] * 14 + ["b"] * 17 + ["c"] * 16, dtype=object)
+        group = group[np.random.default_rng(3).permutation(S)]  # interleaved samples
+        gid, lev = pkg.encode_groups(group)
+        ref0 = pkg.synth.ref_mask(G, 120, seed)
+        run = pkg.run_identify_degs(X, group, list(range(G)), 0.01, 1.0, 0.05, ref0, 8, 1, seed=seed, device=0)
+        assert run.res.shape == (G, 1 + 16 * 3) and len(run.comparisons) == 3
+        for cm in run.comparisons:
+            exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, 3, 0.01, 1.0, 0.05, ref0, 8, 1, seed, k=cm["k"])
+            assert cm["iters_run"] == iters and cm["trace"] == trace, (family, cm["k"])
+            _check_result(cm["result"], exp)
+            assert np.array_equal(run.res[:, 1 + 16 * cm["k"]: 16 + 16 * cm["k"]].astype(float), cm["result"])

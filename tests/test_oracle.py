@@ -114,3 +114,18 @@ def test_tie_coins_are_fair_and_keyed(oracle, rn):
     assert len(set(streams)) == 3 and all(400 < s[2] < 600 for s in streams)
     for n in (0, 1, 63, 64, 65, 200):
         assert oracle.tie_wins(5, 1, 2, 0, n) == rn.tie_wins(5, 1, 2, 0, n) <= n
+
+
+def test_three_group_golden(oracle, golden):
+    """One-vs-rest (src/RankCompV3.jl:375-390,396-436): comparison k = group k vs every other sample."""
+    g = golden("three_groups48.json")
+    X = np.array(g["X"], dtype=np.float64)
+    gid = np.array(g["gid"], dtype=np.int32)
+    gt, eq = oracle.pair_counts(X, gid, 3, 0, 48, 0, 48)
+    assert np.array_equal(gt, g["n_gt"]) and np.array_equal(eq, g["n_eq"])
+    for cm in g["comparisons"]:
+        code = oracle.build_codes(X, gid, 3, cm["k"], cm["thr"], cm["seed"])
+        assert np.array_equal(code, cm["code"])
+        res, iters, trace = oracle.identify_degs(X, gid, 3, cm["pval_reo"], cm["pval_deg"], cm["padj_deg"],
+                                                 np.array(g["ref0"]), cm["n_iter"], cm["n_conv"], cm["seed"], k=cm["k"])
+        assert iters == cm["iters_run"] and np.allclose(res, cm["result"], rtol=1e-12, atol=1e-14)
