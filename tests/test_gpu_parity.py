@@ -4,6 +4,8 @@ Integer outputs (pair counts, class codes, tallies, iteration trace) must be
 bit-exact; floating-point statistics within the tolerances written below
 (north star: p-values within 1e-6).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -344,3 +346,26 @@ def test_three_group_golden_and_synthetic_one_vs_rest(pkg, oracle, golden):
             assert cm["iters_run"] == iters and cm["trace"] == trace, (family, cm["k"])
             _check_result(cm["result"], exp)
             assert np.array_equal(run.res[:, 1 + 16 * cm["k"]: 16 + 16 * cm["k"]].astype(float), cm["result"])
+
+
+def test_reoa_bundled_test_data_end_to_end(pkg, oracle, tmp_path):
+    """BASELINE config 1: reoa(use_testdata="yes") on the reference's bundled files (README.md:26-56)."""
+    seed = 0x5EED0001
+    df = pkg.reoa(use_testdata="yes", work_dir=str(tmp_path), seed=seed, device=0)
+    assert df.shape == (19999, 2) and list(df.columns) == ["gene_name", "group1_vs_group2"]  # README.md:39-41
+    assert set(df["group1_vs_group2"]) <= {"up", "down", "no change"} and df["gene_name"][0] == "DE1"
+    for f in ("fn_expr_group1_group2_result.tsv", "fn_expr_df_expr.tsv", "fn_expr_df_meta.tsv", "fn_expr_gene_up_down.tsv"):
+        assert (tmp_path / f).stat().st_size > 0
+    run = df.attrs["run"]
+    import importlib
+    R = importlib.import_module(pkg.__name__ + ".reoa")
+    prep = R.prepare(
+        os.path.join(os.path.dirname(__file__), "golden", "fn_expr.txt"),
+        os.path.join(os.path.dirname(__file__), "golden", "fn_meta.txt"), seed=seed)
+    gid, lev = pkg.encode_groups(prep["sample_groups"])
+    assert run.thresholds[:, 0].tolist() == [5, 5]  # the WARN branch of :87-90 for 5-vs-5 samples
+    exp, iters, trace = oracle.identify_degs(prep["data"].astype(np.float64), gid, 2, 0.01, 1.0, 0.05, prep["ref"], 128, 5, seed)
+    assert run.iters_run == iters and run.trace == trace
+    _check_result(run.result, exp)
+    from oracle import reo_numpy as rn
+    assert df["group1_vs_group2"].tolist() == rn.labels(exp, 1.0, 0.05).tolist()

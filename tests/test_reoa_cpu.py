@@ -1,0 +1,106 @@
+"""reoa()'s preprocessing and writers (src/RankCompV3.jl:557-651, 663-683) -- host logic, no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def R(pkg):
+    import importlib
+    return importlib.import_module(pkg.__name__ + ".reoa")
+
+
+def test_julia_float_formatting(R):
+    f = R.julia_float
+    assert [f(v) for v in (0.0, 1.0, 12.0, 0.5, 100000.0, 999999.0, 1e6, 1234567.0, 1e-4, 1e-5, 0.00001234,
+                           1.5e-7, 2.5e21, -3.25, 0.1, 1.4504988072997458, float("nan"), float("inf"))] == \
+        ["0.0", "1.0", "12.0", "0.5", "100000.0", "999999.0", "1.0e6", "1.234567e6", "0.0001", "1.0e-5", "1.234e-5",
+         "1.5e-7", "2.5e21", "-3.25", "0.1", "1.4504988072997458", "NaN", "Inf"]
+    rng = np.random.default_rng(0)
+    for v in np.concatenate([rng.normal(0, 1, 200), 10.0 ** rng.uniform(-12, 12, 200)]):
+        assert float(f(float(v))) == float(v)  # round-trips
+
+
+def test_prepare_bundled_data_matches_the_readme(R):
+    """README.md:39-41: 19999 genes survive (EP5057 is all-zero and dropped by the row filter of :626)."""
+    p = R.prepare(os.path.join(GOLD, "fn_expr.txt"), os.path.join(GOLD, "fn_meta.txt"), seed=3)
+    assert p["data"].shape == (19999, 10) and "EP5057" not in p["gene_names"] and p["gene_names"][0] == "DE1"
+    assert p["g_name"] == ["group1", "group2"] and p["sample_groups"] == ["group1"] * 5 + ["group2"] * 5
+    assert p["sample_names"][0] == "Sample1" and p["ref"].sum() == 3000  # no HK table -> random 3000 (:635)
+    assert np.issubdtype(p["data"].dtype, np.integer)
+
+
+def _write(tmp_path, name, text):
+    path = tmp_path / name
+    path.write_text(text)
+    return str(path)
+
+
+def test_argument_errors_mirror_the_reference(R, tmp_path):
+    e = _write(tmp_path, "e.tsv", "gene\ts1\ts2\ts3\ts4\nA\t1\t2\t3\t4\nB\t0\t0\t5\t6\nC\t0\t0\t0\t0\n")
+    m = _write(tmp_path, "m.tsv", "sample\tgrp\ns1\tx\ns2\tx\ns3\ty\ns4\ty\n")
+    p = R.prepare(e, m)
+    assert p["gene_names"] == ["A", "B"] and p["data"].tolist() == [[1, 2, 3, 4], [0, 0, 5, 6]]  # C filtered (:626)
+    with pytest.raises(R.ArgumentError):  # :565
+        R.prepare(e, str(tmp_path / "missing.tsv"))
+    with pytest.raises(R.ArgumentError):  # :566
+        R.prepare(e, _write(tmp_path, "empty.tsv", ""))
+    with pytest.raises(R.ArgumentError):  # :574
+        R.prepare(e, _write(tmp_path, "m1.tsv", "sample\ns1\n"))
+    with pytest.raises(R.ArgumentError):  # :580-582
+        R.prepare(e, _write(tmp_path, "m2.tsv", "sample\tgrp\ns1\tx\nzz\ty\n"))
+    with pytest.raises(R.ArgumentError):  # :589-591
+        R.prepare(e, _write(tmp_path, "m3.tsv", "sample\tgrp\ns1\tx\ns2\tx\ns3\tx\ns4\tx\n"))
+    with pytest.raises(R.ArgumentError):
+        R.prepare(str(tmp_path / "x.rds"), m)
+    # min_profiles filters samples, min_features filters genes (:618,626)
+    p2 = R.prepare(e, m, min_profiles=1)
+    assert p2["sample_names"] == ["s3", "s4"] and p2["sample_groups"] == ["y", "y"]
+
+
+def test_hk_table_selects_reference_genes(R, tmp_path):
+    genes = [f"ENSG{i:05d}" for i in range(300)]
+    rows = "\n".join(f"{g}\t" + "\t".join(str((i * 7 + s) % 11 + 1) for s in range(4)) for i, g in enumerate(genes))
+    e = _write(tmp_path, "e.tsv", "Name\ts1\ts2\ts3\ts4\n" + rows + "\n")
+    m = _write(tmp_path, "m.tsv", "Name\tGroup\ns1\tx\ns2\tx\ns3\ty\ns4\ty\n")
+    hk = _write(tmp_path, "hk.tsv", "Name\tENSEMBL\n" + "\n".join(f"n{i}\t{g}" for i, g in enumerate(genes[:150])) + "\n")
+    p = R.prepare(e, m, hk_file=hk)
+    assert p["ref"].sum() == 150 and p["ref"][:150].all()
+    few = _write(tmp_path, "hk2.tsv", "Name\tENSEMBL\n" + "\n".join(f"n{i}\t{g}" for i, g in enumerate(genes[:20])) + "\n")
+    assert R.prepare(e, m, hk_file=few, ref_gene_max=50)["ref"].sum() == 50  # < ref_gene_min -> random (:645-648)
+    with pytest.raises(R.ArgumentError):
+        R.prepare(e, m, hk_file=str(tmp_path / "nope.tsv"))
+
+
+def test_pseudobulk_group_semantics(R):
+    """src/RankCompV3.jl:56-67: chunks of ceil(c/n_pseudo) shuffled cells, row sums, names <g>_x<k>."""
+    rng = np.random.default_rng(1)
+    vals = rng.integers(0, 33, size=(10, 6))
+    out, names = R.pseudobulk_group(vals, 3, "group1", seed=5, stream=0)
+    assert out.shape == (10, 3) and names == ["group1_x1", "group1_x2", "group1_x3"]
+    assert np.array_equal(out.sum(axis=1), vals.sum(axis=1))
+    out2, names2 = R.pseudobulk_group(rng.integers(0, 9, size=(4, 50000 // 2)), 64, "g", seed=5, stream=1)
+    assert out2.shape == (4, 64) and names2[-1] == "g_x64"  # ceil(25000/64) = 391 cells per chunk -> 64 chunks
+    out3, _ = R.pseudobulk_group(vals, 4, "g", seed=5, stream=0)  # ceil(6/4) = 2 -> only 3 chunks
+    assert out3.shape == (10, 3)
+
+
+def test_writers(R, pkg, tmp_path):
+    prep = {"data": np.array([[1, 2], [3, 4]]), "sample_names": ["s1", "s2"], "sample_groups": ["x", "y"],
+            "gene_names": ["A", "B"], "g_name": ["x", "y"], "ref": np.array([True, True])}
+    res = np.zeros((2, 15))
+    res[0] = [0.001, 0.01, 3, 0, 1, 0, 5, 0, 0, 2, 1, 1.5, 1.25, 0.5, 3.0]
+    res[1] = [0.5, 1.0, 0, 0, 0, 0, 9, 0, 0, 0, 0, 0, 0, 0, 0]
+    run = pkg.DegRun(res=None, result=res, labels=np.array(["up", "no change"], dtype=object), levels=["x", "y"],
+                     thresholds=None, iters_run=1, comparisons=[{"k": 0, "result": res, "labels": np.array(["up", "no change"], dtype=object)}])
+    df = R.write_outputs("fn_expr", prep, run, str(tmp_path))
+    assert list(df.columns) == ["gene_name", "x_vs_y"] and df["x_vs_y"].tolist() == ["up", "no change"]
+    lines = (tmp_path / "fn_expr_x_y_result.tsv").read_text().splitlines()
+    assert lines[0].split("\t") == ["genename"] + pkg.HEADER
+    assert lines[1] == "A\t0.001\t0.01\t3.0\t0.0\t1.0\t0.0\t5.0\t0.0\t0.0\t2.0\t1.0\t1.5\t1.25\t0.5\t3.0\tup"
+    assert (tmp_path / "fn_expr_df_expr.tsv").read_text().splitlines()[:2] == ["genename\ts1\ts2", "A\t1\t2"]
+    assert (tmp_path / "fn_expr_df_meta.tsv").read_text() == "Name\tGroup\ns1\tx\ns2\ty\n"
+    assert (tmp_path / "fn_expr_gene_up_down.tsv").read_text().splitlines()[0] == "gene_name\tx_vs_y"
