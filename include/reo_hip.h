@@ -138,12 +138,33 @@ int32_t reo_identify_degs(reo_ctx *ctx, const uint8_t *ref0, double pval_deg, do
  * (pval, delta1, delta2, se, z1) -- src/RankCompV3.jl:225-259. */
 int32_t reo_mccullagh(reo_ctx *ctx, const int32_t *cont, int64_t n, double *out);
 
+/* Pseudo-bulk front end: pseudobulk_group (src/RankCompV3.jl:56-67, call site :608-612) for all
+ * groups at once.  `order` lists the cells (0-based columns) of every output profile back to back --
+ * the reference's shuffled partition, sample(1:c, c) + Iterators.partition (:62) -- and
+ * chunk_ptr[o] .. chunk_ptr[o+1] delimits profile o (n_out + 1 entries, chunk_ptr[n_out] = n_order).
+ * Each profile is the row-wise sum of its cells taken in that order (:63): exact for Int64,
+ * bit-reproducible for Float64.  out is G x n_out column-major, caller-allocated.
+ * dense: X is the G x C cell matrix, column-major (what the reference holds after CSV.read);
+ * csc:   this build's container for sparse single-cell counts (colptr C+1, rowidx/val nnz). */
+int32_t reo_pseudobulk_dense_f64(reo_ctx *ctx, const double *X, int64_t G, int64_t C, int64_t ld,
+                                 const int32_t *order, int64_t n_order, const int32_t *chunk_ptr,
+                                 int32_t n_out, double *out);
+int32_t reo_pseudobulk_dense_i64(reo_ctx *ctx, const int64_t *X, int64_t G, int64_t C, int64_t ld,
+                                 const int32_t *order, int64_t n_order, const int32_t *chunk_ptr,
+                                 int32_t n_out, int64_t *out);
+int32_t reo_pseudobulk_csc_f64(reo_ctx *ctx, int64_t G, int64_t C, const int64_t *colptr, const int32_t *rowidx,
+                               const double *val, const int32_t *order, int64_t n_order,
+                               const int32_t *chunk_ptr, int32_t n_out, double *out);
+int32_t reo_pseudobulk_csc_i64(reo_ctx *ctx, int64_t G, int64_t C, const int64_t *colptr, const int32_t *rowidx,
+                               const int64_t *val, const int32_t *order, int64_t n_order,
+                               const int32_t *chunk_ptr, int32_t n_out, int64_t *out);
+
 /* Stage timers (HIP events on the library's stream), milliseconds, summed
  * since the last reo_reset_timings.  Index: 0 rank/band transform, 1 pair
  * kernel K1, 2 tally kernel K2 (sum), 3 iteration passes in total (K2 + the
  * statistics kernels K3, sum), 4 number of K2 launches (passes enqueued after
  * convergence return at once and are counted too), 5 number of K1 launches,
- * 6 all-reduce hook wall time. */
+ * 6 all-reduce hook wall time, 7 pseudo-bulk kernel. */
 enum { REO_NTIMINGS = 8 };
 int32_t reo_set_profiling(reo_ctx *ctx, int32_t on);
 int32_t reo_reset_timings(reo_ctx *ctx);

@@ -212,3 +212,17 @@ def labels(result, pval_deg, padj_deg):
     out[sig & (result[:, 14] > 0)] = "up"
     out[sig & (result[:, 14] < 0)] = "down"
     return out
+
+
+def pseudobulk(values: np.ndarray, order, chunk_ptr) -> np.ndarray:
+    """pseudobulk_group, src/RankCompV3.jl:56-67: profile o = row sums of the cells
+    order[chunk_ptr[o]:chunk_ptr[o+1]], added left to right like `sum(eachrow(...))` (:63)."""
+    values = np.asarray(values)
+    n_out = len(chunk_ptr) - 1
+    out = np.zeros((values.shape[0], n_out), dtype=values.dtype)
+    for o in range(n_out):
+        acc = np.zeros(values.shape[0], dtype=values.dtype)
+        for c in order[chunk_ptr[o]: chunk_ptr[o + 1]]:
+            acc = acc + values[:, c]
+        out[:, o] = acc
+    return out

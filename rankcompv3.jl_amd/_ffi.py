@@ -25,6 +25,7 @@ SYMBOLS = [
     "reo_set_groups", "reo_compute_thresholds", "reo_set_thresholds", "reo_get_thresholds", "reo_threshold",
     "reo_build_pairs", "reo_pair_counts", "reo_get_codes", "reo_tally", "reo_identify_degs", "reo_mccullagh",
     "reo_set_profiling", "reo_reset_timings", "reo_get_timings", "reo_get_info",
+    "reo_pseudobulk_dense_f64", "reo_pseudobulk_dense_i64", "reo_pseudobulk_csc_f64", "reo_pseudobulk_csc_i64",
 ]
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
@@ -98,6 +99,10 @@ def lib() -> ctypes.CDLL:
         "reo_reset_timings": (i32, [vp]),
         "reo_get_timings": (i32, [vp, vp, i32]),
         "reo_get_info": (i32, [vp, vp, i32]),
+        "reo_pseudobulk_dense_f64": (i32, [vp, vp, i64, i64, i64, vp, i64, vp, i32, vp]),
+        "reo_pseudobulk_dense_i64": (i32, [vp, vp, i64, i64, i64, vp, i64, vp, i32, vp]),
+        "reo_pseudobulk_csc_f64": (i32, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, vp]),
+        "reo_pseudobulk_csc_i64": (i32, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -254,6 +259,35 @@ class Context:
         check(self._L.reo_mccullagh(self._h, _ptr(cont), cont.shape[0], _ptr(out)))
         return out
 
+    # -- pseudo-bulk front end ------------------------------------------------------
+    def pseudobulk(self, cells, order, chunk_ptr) -> np.ndarray:
+        """Row-wise sums of groups of cells (src/RankCompV3.jl:56-67).  `cells` is a genes x cells
+        ndarray (Int64 / Float64) or a scipy.sparse matrix (converted to CSC); `order` lists the cells
+        of all output profiles back to back and chunk_ptr delimits them.  Returns genes x profiles."""
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        chunk_ptr = np.ascontiguousarray(chunk_ptr, dtype=np.int32)
+        n_out = chunk_ptr.size - 1
+        if hasattr(cells, "tocsc"):
+            m = cells.tocsc()
+            m.sort_indices()
+            G, C = m.shape
+            isint = np.issubdtype(m.dtype, np.integer)
+            val = np.ascontiguousarray(m.data, dtype=np.int64 if isint else np.float64)
+            colptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+            rowidx = np.ascontiguousarray(m.indices, dtype=np.int32)
+            out = np.zeros((G, n_out), dtype=val.dtype, order="F")
+            fn = self._L.reo_pseudobulk_csc_i64 if isint else self._L.reo_pseudobulk_csc_f64
+            check(fn(self._h, G, C, _ptr(colptr), _ptr(rowidx), _ptr(val), _ptr(order), order.size, _ptr(chunk_ptr), n_out, _ptr(out)))
+            return out
+        X = np.asarray(cells)
+        isint = np.issubdtype(X.dtype, np.integer)
+        Xf = np.asfortranarray(X, dtype=np.int64 if isint else np.float64)
+        G, C = Xf.shape
+        out = np.zeros((G, n_out), dtype=Xf.dtype, order="F")
+        fn = self._L.reo_pseudobulk_dense_i64 if isint else self._L.reo_pseudobulk_dense_f64
+        check(fn(self._h, _ptr(Xf), G, C, G, _ptr(order), order.size, _ptr(chunk_ptr), n_out, _ptr(out)))
+        return out
+
     # -- instrumentation -------------------------------------------------------
     def set_profiling(self, on: bool) -> None:
         check(self._L.reo_set_profiling(self._h, 1 if on else 0))
@@ -265,7 +299,7 @@ class Context:
         ms = np.zeros(NTIMINGS, dtype=np.float64)
         check(self._L.reo_get_timings(self._h, _ptr(ms), NTIMINGS))
         return {"transform_ms": ms[0], "k1_ms": ms[1], "k2_ms": ms[2], "iter_ms": ms[3], "k3_ms": max(ms[3] - ms[2], 0.0), "k2_launches": int(ms[4]),
-                "k1_launches": int(ms[5]), "allreduce_ms": ms[6]}
+                "k1_launches": int(ms[5]), "allreduce_ms": ms[6], "pseudobulk_ms": ms[7]}
 
     def info(self) -> dict:
         v = np.zeros(12, dtype=np.int64)

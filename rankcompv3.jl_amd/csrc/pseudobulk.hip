@@ -1,0 +1,193 @@
+// Pseudo-bulk front end: pseudobulk_group of /root/reference/src/RankCompV3.jl:56-67 (call site
+// :608-612) as a segmented column sum on the GPU.  The caller supplies the shuffled cell order
+// and the chunk boundaries (the reference's sample(1:c, c) + Iterators.partition, :62), so that
+// every output profile sums its cells in exactly that order: integer data is exact, Float64
+// data reproduces the reference's left-to-right row sums (:63) bit for bit.
+//
+//   dense  X f64/i64 [G x C] column-major (what the reference holds after CSV.read)
+//   CSC    colptr i64 [C+1], rowidx i32 [nnz], val f64/i64 [nnz]  (this build's own container for
+//          sparse single-cell counts; the reference has no sparse input format)
+// Both are HBM-bound streams: every needed input byte is read once.
+#include <algorithm>
+
+#include "reo_internal.h"
+
+namespace reo {
+
+namespace {
+
+// dense: one thread per gene row, one workgroup column per output profile; the threads of a wave
+// read consecutive rows of the same cell column (coalesced), cells in the given order.
+template <class T>
+__global__ __launch_bounds__(256) void pb_dense(const T *__restrict__ X, int64_t ld, int G,
+                                                const int32_t *__restrict__ order,
+                                                const int32_t *__restrict__ chunk_ptr, T *__restrict__ out)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int o = blockIdx.y;
+    if (g >= G) return;
+    T acc = 0;
+    for (int t = chunk_ptr[o]; t < chunk_ptr[o + 1]; ++t) acc += X[static_cast<int64_t>(order[t]) * ld + g];
+    out[static_cast<int64_t>(o) * G + g] = acc;
+}
+
+// CSC: one workgroup per (output profile, tile of kPbRows gene rows); a dense accumulator for the
+// tile lives in LDS; the cells of the profile are visited in order, a barrier between cells keeps
+// the per-row summation order; inside one cell every row occurs at most once, so plain LDS
+// read-modify-writes by distinct threads need no atomics.
+constexpr int kPbRows = 16384;
+
+template <class T>
+__global__ __launch_bounds__(256) void pb_csc(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
+                                              const T *__restrict__ val, int G, const int32_t *__restrict__ order,
+                                              const int32_t *__restrict__ chunk_ptr, T *__restrict__ out)
+{
+    __shared__ T acc[kPbRows];
+    const int o = blockIdx.x;
+    const int r0 = blockIdx.y * kPbRows, r1 = min(G, r0 + kPbRows);
+    for (int t = threadIdx.x; t < kPbRows; t += 256) acc[t] = 0;
+    __syncthreads();
+    for (int t = chunk_ptr[o]; t < chunk_ptr[o + 1]; ++t) {
+        const int c = order[t];
+        const int64_t e0 = colptr[c], e1 = colptr[c + 1];
+        for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+            const int r = rowidx[e];
+            if (r >= r0 && r < r1) acc[r - r0] += val[e];
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < r1 - r0; t += 256) out[static_cast<int64_t>(o) * G + r0 + t] = acc[t];
+}
+
+template <class T>
+int32_t run_dense(reo_ctx *c, const T *X, int64_t G, int64_t C, int64_t ld, const int32_t *order, int64_t n_order,
+                  const int32_t *chunk_ptr, int32_t n_out, T *out)
+{
+    DevBuf<T> dX, dOut;
+    DevBuf<int32_t> dOrd, dPtr;
+    int32_t rc;
+    if ((rc = dX.ensure(static_cast<size_t>(G) * C)) || (rc = dOut.ensure(static_cast<size_t>(G) * n_out)) ||
+        (rc = dOrd.ensure(std::max<int64_t>(n_order, 1))) || (rc = dPtr.ensure(n_out + 1)))
+        return rc;
+    hipError_t e = hipMemcpy2DAsync(dX.p, G * sizeof(T), X, ld * sizeof(T), G * sizeof(T), C, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n_order) e = hipMemcpyAsync(dOrd.p, order, n_order * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dPtr.p, chunk_ptr, (n_out + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        tic(c, 7);
+        pb_dense<T><<<dim3(static_cast<unsigned>((G + 255) / 256), n_out), 256, 0, c->stream>>>(dX.p, G, static_cast<int>(G), dOrd.p, dPtr.p, dOut.p);
+        toc(c);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dOut.p, static_cast<size_t>(G) * n_out * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dX.release(); dOut.release(); dOrd.release(); dPtr.release();
+    if (e != hipSuccess) { set_error("pseudobulk (dense) failed: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? REO_ENOMEM : REO_EHIP; }
+    collect_timings(c);
+    return REO_OK;
+}
+
+template <class T>
+int32_t run_csc(reo_ctx *c, int64_t G, int64_t C, const int64_t *colptr, const int32_t *rowidx, const T *val,
+                const int32_t *order, int64_t n_order, const int32_t *chunk_ptr, int32_t n_out, T *out)
+{
+    const int64_t nnz = colptr[C];
+    DevBuf<int64_t> dCp;
+    DevBuf<int32_t> dRi, dOrd, dPtr;
+    DevBuf<T> dVal, dOut;
+    int32_t rc;
+    if ((rc = dCp.ensure(C + 1)) || (rc = dRi.ensure(std::max<int64_t>(nnz, 1))) || (rc = dVal.ensure(std::max<int64_t>(nnz, 1))) ||
+        (rc = dOut.ensure(static_cast<size_t>(G) * n_out)) || (rc = dOrd.ensure(std::max<int64_t>(n_order, 1))) ||
+        (rc = dPtr.ensure(n_out + 1)))
+        return rc;
+    hipError_t e = hipMemcpyAsync(dCp.p, colptr, (C + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(dRi.p, rowidx, nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(dVal.p, val, nnz * sizeof(T), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n_order) e = hipMemcpyAsync(dOrd.p, order, n_order * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dPtr.p, chunk_ptr, (n_out + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        tic(c, 7);
+        pb_csc<T><<<dim3(n_out, static_cast<unsigned>((G + kPbRows - 1) / kPbRows)), 256, 0, c->stream>>>(
+            dCp.p, dRi.p, dVal.p, static_cast<int>(G), dOrd.p, dPtr.p, dOut.p);
+        toc(c);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dOut.p, static_cast<size_t>(G) * n_out * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dCp.release(); dRi.release(); dVal.release(); dOut.release(); dOrd.release(); dPtr.release();
+    if (e != hipSuccess) { set_error("pseudobulk (CSC) failed: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? REO_ENOMEM : REO_EHIP; }
+    collect_timings(c);
+    return REO_OK;
+}
+
+int32_t check_args(reo_ctx *c, int64_t G, int64_t C, const int32_t *order, int64_t n_order, const int32_t *chunk_ptr,
+                   int32_t n_out, const void *in, const void *out)
+{
+    if (!c || !in || !out || !chunk_ptr || (n_order > 0 && !order)) { set_error("null argument"); return REO_EINVAL; }
+    if (G < 1 || C < 1 || n_out < 1 || n_order < 0) { set_error("bad pseudobulk shape"); return REO_EINVAL; }
+    if (chunk_ptr[0] != 0 || chunk_ptr[n_out] != n_order) { set_error("chunk_ptr must run from 0 to n_order"); return REO_EINVAL; }
+    for (int o = 0; o < n_out; ++o)
+        if (chunk_ptr[o + 1] < chunk_ptr[o]) { set_error("chunk_ptr must be non-decreasing"); return REO_EINVAL; }
+    for (int64_t t = 0; t < n_order; ++t)
+        if (order[t] < 0 || order[t] >= C) { set_error("cell index %d outside [0,%lld)", order[t], (long long)C); return REO_EINVAL; }
+    REO_HIP_CHECK(hipSetDevice(c->device));
+    return REO_OK;
+}
+
+}  // namespace
+
+}  // namespace reo
+
+using namespace reo;
+
+extern "C" {
+
+int32_t reo_pseudobulk_dense_f64(reo_ctx *c, const double *X, int64_t G, int64_t C, int64_t ld, const int32_t *order,
+                                 int64_t n_order, const int32_t *chunk_ptr, int32_t n_out, double *out)
+{
+    int32_t rc = check_args(c, G, C, order, n_order, chunk_ptr, n_out, X, out);
+    if (rc) return rc;
+    if (ld < G) { set_error("leading dimension < G"); return REO_EINVAL; }
+    return run_dense<double>(c, X, G, C, ld, order, n_order, chunk_ptr, n_out, out);
+}
+
+int32_t reo_pseudobulk_dense_i64(reo_ctx *c, const int64_t *X, int64_t G, int64_t C, int64_t ld, const int32_t *order,
+                                 int64_t n_order, const int32_t *chunk_ptr, int32_t n_out, int64_t *out)
+{
+    int32_t rc = check_args(c, G, C, order, n_order, chunk_ptr, n_out, X, out);
+    if (rc) return rc;
+    if (ld < G) { set_error("leading dimension < G"); return REO_EINVAL; }
+    return run_dense<long long>(c, reinterpret_cast<const long long *>(X), G, C, ld, order, n_order, chunk_ptr, n_out,
+                                reinterpret_cast<long long *>(out));
+}
+
+static int32_t check_csc(int64_t G, int64_t C, const int64_t *colptr, const int32_t *rowidx)
+{
+    if (!colptr || colptr[0] != 0) { set_error("colptr must start at 0"); return REO_EINVAL; }
+    for (int64_t k = 0; k < C; ++k)
+        if (colptr[k + 1] < colptr[k]) { set_error("colptr must be non-decreasing"); return REO_EINVAL; }
+    if (colptr[C] > 0 && !rowidx) { set_error("rowidx is null"); return REO_EINVAL; }
+    for (int64_t e = 0; e < colptr[C]; ++e)
+        if (rowidx[e] < 0 || rowidx[e] >= G) { set_error("row index %d outside [0,%lld)", rowidx[e], (long long)G); return REO_EINVAL; }
+    return REO_OK;
+}
+
+int32_t reo_pseudobulk_csc_f64(reo_ctx *c, int64_t G, int64_t C, const int64_t *colptr, const int32_t *rowidx,
+                               const double *val, const int32_t *order, int64_t n_order, const int32_t *chunk_ptr,
+                               int32_t n_out, double *out)
+{
+    int32_t rc = check_args(c, G, C, order, n_order, chunk_ptr, n_out, colptr, out);
+    if (rc || (rc = check_csc(G, C, colptr, rowidx))) return rc;
+    return run_csc<double>(c, G, C, colptr, rowidx, val, order, n_order, chunk_ptr, n_out, out);
+}
+
+int32_t reo_pseudobulk_csc_i64(reo_ctx *c, int64_t G, int64_t C, const int64_t *colptr, const int32_t *rowidx,
+                               const int64_t *val, const int32_t *order, int64_t n_order, const int32_t *chunk_ptr,
+                               int32_t n_out, int64_t *out)
+{
+    int32_t rc = check_args(c, G, C, order, n_order, chunk_ptr, n_out, colptr, out);
+    if (rc || (rc = check_csc(G, C, colptr, rowidx))) return rc;
+    return run_csc<long long>(c, G, C, colptr, rowidx, reinterpret_cast<const long long *>(val), order, n_order,
+                              chunk_ptr, n_out, reinterpret_cast<long long *>(out));
+}
+
+}  // extern "C"

@@ -76,22 +76,39 @@ def shuffled(n: int, seed: int, stream: int) -> np.ndarray:
     return np.argsort(h, kind="stable")
 
 
-def pseudobulk_group(values: np.ndarray, n_pseudo: int, g_name: str, seed: int, stream: int):
-    """pseudobulk_group, src/RankCompV3.jl:56-67: shuffle the group's cells, cut into chunks of
-    ceil(c / n_pseudo) cells, sum each chunk.  Returns (matrix r x chunks, column names `<g>_x<k>`)."""
-    r, c = values.shape
+def pseudobulk_partition(c: int, n_pseudo: int, seed: int, stream: int):
+    """The reference's shuffled partition of one group's c cells (src/RankCompV3.jl:60-62): chunks of
+    ceil(c / n_pseudo) cells of sample(1:c, c, replace=false).  Returns (order, chunk_ptr)."""
     cp = math.ceil(c / n_pseudo)
     if cp <= 1:
         log.info("WARN: too few profiles to generate %d pseudo-bulk profiles for the 'group' group", n_pseudo)
     order = shuffled(c, seed, stream)
-    chunks = [order[i: i + cp] for i in range(0, c, cp)]  # Iterators.partition
-    out = np.stack([values[:, ch].sum(axis=1) for ch in chunks], axis=1)
-    return out, [f"{g_name}_x{k + 1}" for k in range(len(chunks))]
+    ptr = list(range(0, c, cp)) + [c]  # Iterators.partition
+    return order.astype(np.int32), np.asarray(ptr, dtype=np.int32)
+
+
+def host_sums(values, order, chunk_ptr) -> np.ndarray:
+    """Left-to-right row sums of groups of cells on the host (used by the CPU-side unit tests only;
+    `reoa` itself runs the HIP kernel, Context.pseudobulk)."""
+    values = np.asarray(values)
+    out = np.zeros((values.shape[0], len(chunk_ptr) - 1), dtype=values.dtype)
+    for o in range(len(chunk_ptr) - 1):
+        for c in order[chunk_ptr[o]: chunk_ptr[o + 1]]:
+            out[:, o] = out[:, o] + values[:, c]
+    return out
+
+
+def pseudobulk_group(values: np.ndarray, n_pseudo: int, g_name: str, seed: int, stream: int, sums=host_sums):
+    """pseudobulk_group, src/RankCompV3.jl:56-67: shuffle the group's cells, cut into chunks of
+    ceil(c / n_pseudo) cells, sum each chunk.  Returns (matrix r x chunks, column names `<g>_x<k>`)."""
+    order, ptr = pseudobulk_partition(values.shape[1], n_pseudo, seed, stream)
+    out = sums(values, order, ptr)
+    return out, [f"{g_name}_x{k + 1}" for k in range(len(ptr) - 1)]
 
 
 def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: int = 0, n_pseudo: int = 0,
             use_hk_genes: str = "yes", hk_file: str | None = None, gene_name_type: str = "ENSEMBL",
-            ref_gene_max: int = 3000, ref_gene_min: int = 100, seed: int = 0):
+            ref_gene_max: int = 3000, ref_gene_min: int = 100, seed: int = 0, sums=host_sums):
     """Everything `reoa` does before `identify_degs` (:565-651).  Returns a dict with the expression
     matrix (genes x samples), the sample table (Name, Group), gene names, group levels and the reference mask."""
     import pandas as pd
@@ -128,7 +145,7 @@ def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: 
         mats, names, groups = [], [], []
         for gi, g in enumerate(g_name):
             cols = list(meta["Name"][meta["Group"] == g])
-            m, nm = pseudobulk_group(expr[cols].to_numpy(), n_pseudo, g, seed, gi)
+            m, nm = pseudobulk_group(expr[cols].to_numpy(), n_pseudo, g, seed, gi, sums)
             mats.append(m); names += nm; groups += [g] * len(nm)
         data = np.concatenate(mats, axis=1)
         sample_names, sample_groups = names, groups
@@ -225,9 +242,14 @@ def reoa(fn_expr: str = "fn_expr.txt", fn_meta: str = "fn_meta.txt", *, expr_thr
     elif not os.path.isabs(fn_expr):
         fn_expr, fn_meta = os.path.join(work_dir, fn_expr), os.path.join(work_dir, fn_meta)  # cd(work_dir), :557
     stem = os.path.splitext(os.path.basename(fn_expr))[0]  # :567
+
+    def gpu_sums(values, order, chunk_ptr):  # pseudobulk_group's sums on the GPU (:63)
+        with _ffi.Context(device=device, seed=seed) as pctx:
+            return pctx.pseudobulk(values, order, chunk_ptr)
+
     prep = prepare(fn_expr, fn_meta, min_profiles=min_profiles, min_features=min_features, n_pseudo=n_pseudo,
                    use_hk_genes=use_hk_genes, hk_file=hk_file, gene_name_type=gene_name_type,
-                   ref_gene_max=ref_gene_max, ref_gene_min=ref_gene_min, seed=seed)
+                   ref_gene_max=ref_gene_max, ref_gene_min=ref_gene_min, seed=seed, sums=gpu_sums)
     run = run_identify_degs(prep["data"], prep["sample_groups"], prep["gene_names"], pval_reo, pval_deg, padj_deg,
                             prep["ref"], n_iter, n_conv, seed=seed, device=device)  # :652-662
     for p, (d, n) in enumerate(run.trace):

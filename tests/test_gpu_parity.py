@@ -369,3 +369,68 @@ def test_reoa_bundled_test_data_end_to_end(pkg, oracle, tmp_path):
     _check_result(run.result, exp)
     from oracle import reo_numpy as rn
     assert df["group1_vs_group2"].tolist() == rn.labels(exp, 1.0, 0.05).tolist()
+
+
+def test_pseudobulk_kernels_dense_and_csc(pkg, rn):
+    """pseudobulk_group (src/RankCompV3.jl:56-67) on the GPU: exact for counts, bit-exact for Float64
+    (cells are added in the shuffled order, left to right, like sum(eachrow(...)) at :63)."""
+    import importlib
+    import scipy.sparse as sp
+    R = importlib.import_module(pkg.__name__ + ".reoa")
+    rng = np.random.default_rng(11)
+    G, C = 2500, 900
+    dense_i = (rng.random((G, C)) < 0.08) * rng.integers(1, 400, size=(G, C))
+    dense_f = dense_i * rng.random((G, C)) * 1.37
+    orders, ptrs, base = [], [0], 0
+    for gi, (lo, hi) in enumerate(((0, 500), (500, 900))):  # two groups of cells, 64 and 7 profiles
+        o, p = R.pseudobulk_partition(hi - lo, 64 if gi == 0 else 7, seed=9, stream=gi)
+        orders.append(o + lo)
+        ptrs += (p[1:] + base).tolist()
+        base += hi - lo
+    order, ptr = np.concatenate(orders), np.asarray(ptrs, dtype=np.int32)
+    assert len(ptr) - 1 == 63 + 7  # ceil(500/64) = 8 cells per chunk -> 63 chunks; ceil(400/7) = 58 -> 7 chunks
+    with pkg.Context(device=0) as ctx:
+        for X in (dense_i.astype(np.int64), dense_f):
+            exp = rn.pseudobulk(X, order, ptr)
+            assert np.array_equal(ctx.pseudobulk(X, order, ptr), exp)                  # dense
+            assert np.array_equal(ctx.pseudobulk(sp.csc_matrix(X), order, ptr), exp)   # CSC
+        assert np.array_equal(exp.sum(axis=1), dense_f[:, order].sum(axis=1)) or np.allclose(exp.sum(axis=1), dense_f.sum(axis=1))
+        # more gene rows than one LDS tile, empty cells, a dropped cell, an empty profile
+        G2 = 40000
+        X2 = sp.random(G2, 300, density=0.01, random_state=3, format="csc", dtype=np.float64)
+        X2.data = np.round(X2.data * 50)
+        o2 = np.arange(299, dtype=np.int32)[::-1].copy()
+        p2 = np.array([0, 100, 100, 250, 299], dtype=np.int32)
+        exp2 = rn.pseudobulk(X2.toarray(), o2, p2)
+        assert np.array_equal(ctx.pseudobulk(X2, o2, p2), exp2) and not exp2[:, 1].any()
+        assert np.array_equal(ctx.pseudobulk(X2.toarray(), o2, p2), exp2)
+        with pytest.raises(pkg.DimensionMismatch):
+            ctx.pseudobulk(X2, np.array([5, 300], dtype=np.int32), np.array([0, 2], dtype=np.int32))
+
+
+def test_reoa_pseudobulk_mode(pkg, oracle, tmp_path):
+    """reoa(n_pseudo=...) (src/RankCompV3.jl:608-612): cells -> pseudo-bulk profiles -> identify_degs."""
+    import importlib
+    R = importlib.import_module(pkg.__name__ + ".reoa")
+    G, C, seed = 400, 240, 0x5EED0007
+    X = pkg.synth.t1_counts(G, C, seed)
+    names = [f"g{i}" for i in range(G)]
+    cells = [f"c{j}" for j in range(C)]
+    with open(tmp_path / "cells.tsv", "w") as f:
+        f.write("Name\t" + "\t".join(cells) + "\n")
+        for i in range(G):
+            f.write(names[i] + "\t" + "\t".join(str(v) for v in X[i]) + "\n")
+    with open(tmp_path / "meta.tsv", "w") as f:
+        f.write("Name\tGroup\n" + "".join(f"{c}\t{'ctrl' if j < C // 2 else 'case'}\n" for j, c in enumerate(cells)))
+    df = pkg.reoa(str(tmp_path / "cells.tsv"), str(tmp_path / "meta.tsv"), n_pseudo=12, use_hk_genes="no",
+                  ref_gene_max=100, n_iter=8, n_conv=1, work_dir=str(tmp_path), seed=seed, device=0)
+    prep = R.prepare(str(tmp_path / "cells.tsv"), str(tmp_path / "meta.tsv"), n_pseudo=12, use_hk_genes="no",
+                     ref_gene_max=100, seed=seed)  # host sums: the same matrix
+    assert prep["data"].shape[1] == 24 and prep["sample_names"][0] == "ctrl_x1" and prep["sample_groups"][-1] == "case"
+    meta_out = (tmp_path / "cells_df_meta.tsv").read_text().splitlines()
+    assert meta_out[1] == "ctrl_x1\tctrl" and len(meta_out) == 25
+    gid, lev = pkg.encode_groups(prep["sample_groups"])
+    exp, iters, trace = oracle.identify_degs(prep["data"].astype(np.float64), gid, 2, 0.01, 1.0, 0.05, prep["ref"], 8, 1, seed)
+    run = df.attrs["run"]
+    assert run.iters_run == iters and run.trace == trace
+    _check_result(run.result, exp)

@@ -86,6 +86,10 @@ def test_pseudobulk_group_semantics(R):
     assert out2.shape == (4, 64) and names2[-1] == "g_x64"  # ceil(25000/64) = 391 cells per chunk -> 64 chunks
     out3, _ = R.pseudobulk_group(vals, 4, "g", seed=5, stream=0)  # ceil(6/4) = 2 -> only 3 chunks
     assert out3.shape == (10, 3)
+    order, ptr = R.pseudobulk_partition(6, 3, seed=5, stream=0)
+    assert sorted(order.tolist()) == list(range(6)) and ptr.tolist() == [0, 2, 4, 6]
+    from oracle import reo_numpy as rn
+    assert np.array_equal(R.host_sums(vals, order, ptr), rn.pseudobulk(vals, order, ptr))
 
 
 def test_writers(R, pkg, tmp_path):
