@@ -61,13 +61,16 @@ void reo_destroy(reo_ctx *ctx);
  * multi-device path); see DESIGN.md "Multi-GPU". */
 int32_t reo_set_shard(reo_ctx *ctx, int32_t rank, int32_t world);
 
-/* Hook called once per iteration between the tally kernel and the statistics
- * kernels when world > 1: must sum `count` int32 values at device pointer
- * `dev_buf` across all shards in place (e.g. RCCL ncclAllReduce, or
- * torch.distributed.all_reduce on a tensor aliasing it) and return 0.  The
- * library synchronises its stream before the call and expects the result to
- * be complete (visible to any stream) on return. */
-typedef int32_t (*reo_allreduce_fn)(void *dev_buf, int64_t count, void *user);
+/* Hook called once per pass, between the tally kernel and the statistics kernels, when world > 1:
+ * it must arrange for `count` int32 values at device pointer `dev_buf` to be summed in place across
+ * all shards, ORDERED ON `stream` (a hipStream_t): everything the library enqueued on `stream` before
+ * the call has to precede the sum, and the sum has to precede whatever is enqueued on `stream`
+ * afterwards.  The library does not synchronise the host around the call, so a hook that enqueues
+ * the collective on `stream` (RCCL ncclAllReduce(..., stream), or torch.distributed.all_reduce under
+ * torch.cuda.stream(ExternalStream(stream))) keeps whole batches of passes in flight; a hook that
+ * works on the host must synchronise `stream` itself before and after.  Return 0 on success.  Every
+ * shard must call its hook the same number of times (they do: all shards see identical data). */
+typedef int32_t (*reo_allreduce_fn)(void *dev_buf, int64_t count, void *stream, void *user);
 int32_t reo_set_allreduce(reo_ctx *ctx, reo_allreduce_fn fn, void *user);
 
 /* Expression matrix, G genes x S samples, column-major with leading dimension

@@ -28,7 +28,7 @@ SYMBOLS = [
     "reo_pseudobulk_dense_f64", "reo_pseudobulk_dense_i64", "reo_pseudobulk_csc_f64", "reo_pseudobulk_csc_i64",
 ]
 
-ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class LibraryMissing(RuntimeError):
@@ -205,10 +205,11 @@ class Context:
         check(self._L.reo_set_shard(self._h, int(rank), int(world)))
 
     def set_allreduce(self, fn) -> None:
-        """fn(dev_ptr: int, count: int) -> None sums int32[count] in place across shards."""
-        def _cb(ptr, count, _user):
+        """fn(dev_ptr: int, count: int, stream: int) -> None: sum int32[count] in place across shards,
+        ordered on the HIP stream `stream` (see include/reo_hip.h)."""
+        def _cb(ptr, count, stream, _user):
             try:
-                fn(int(ptr), int(count))
+                fn(int(ptr), int(count), int(stream or 0))
                 return 0
             except Exception:  # never let an exception cross the C boundary
                 import traceback

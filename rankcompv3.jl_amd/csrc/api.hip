@@ -176,9 +176,8 @@ static int32_t allreduce_raw(reo_ctx *c)
 {
     if (c->world <= 1) return REO_OK;
     if (!c->ar) { set_error("world = %d but no all-reduce hook is set (reo_set_allreduce)", c->world); return REO_ECOMM; }
-    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
-    const int32_t rc = c->ar(c->raw.p, c->G * kRaw, c->ar_user);
+    const int32_t rc = c->ar(c->raw.p, c->G * kRaw, c->stream, c->ar_user);  // stream-ordered, no host sync here
     c->t_ms[6] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc) { set_error("all-reduce hook failed with %d", rc); return REO_ECOMM; }
     return REO_OK;
@@ -232,7 +231,7 @@ void reo_destroy(reo_ctx *c)
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
     c->table.release();
     c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
-    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release();
+    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release(); c->own_mask.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
@@ -432,8 +431,10 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // The loop control of :400,418-424 lives in device memory (IterState): passes are
     // enqueued in batches and every kernel of a pass returns at once after convergence,
     // so the host only looks at the state once per batch.  With more than one shard the
-    // all-reduce hook runs on the host between K2 and K3, i.e. batches of one pass.
-    const int batch = c->world > 1 ? 1 : 8;
+    // all-reduce hook is called between K2 and K3 of every pass; it is stream-ordered, so the
+    // batches stay (after convergence the remaining passes of a batch still call the hook on
+    // every shard alike, and their kernels return at once).
+    const int batch = 8;
     int enq = 0, passes = 0;
     while (enq < n_iter) {  // :400
         const int nb = std::min(batch, n_iter - enq);

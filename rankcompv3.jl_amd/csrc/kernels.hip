@@ -392,8 +392,11 @@ __device__ __forceinline__ void tally_word(uint32_t cl, uint32_t ch, uint32_t tl
     c[4] += __popc(cl & tl); c[5] += __popc(cl & th); c[6] += __popc(ch & tl); c[7] += __popc(ch & th);
 }
 
+// own: with G-sharding, one bit per 16-byte chunk of a row and per 32-row block: set iff this shard
+// wrote anything there (the rest of its table is zero and need not be read); nullptr = everything.
 __global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st, const uint4 *__restrict__ table,
                                                 const uint4 *__restrict__ refbits, int G, int Wq,
+                                                const uint32_t *__restrict__ own, int own_words,
                                                 int32_t *__restrict__ raw)
 {
     if (st->done) return;
@@ -401,8 +404,10 @@ __global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= G) return;
     const uint4 *r = table + static_cast<size_t>(row) * kPlanes * Wq;
+    const uint32_t *ow = own ? own + static_cast<size_t>(row >> 5) * own_words : nullptr;
     uint32_t c[kRaw] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = lane; q < Wq; q += 64) {
+        if (ow && !((ow[q >> 5] >> (q & 31)) & 1u)) continue;
         const uint4 m = refbits[q];
         const uint4 cl = r[q], ch = r[Wq + q], tl = r[2 * Wq + q], th = r[3 * Wq + q];
         tally_word(cl.x, ch.x, tl.x, th.x, m.x, c);
@@ -525,20 +530,6 @@ __device__ __forceinline__ double block_sum_256(double v, double *red)
 //     being a decreasing function of |delta1|, :412) from three binary searches
 //     in the sorted array, plus per-block moments of the 5 %-95 % slice.
 // Ties are broken consistently, so both ranks are permutations.
-
-__device__ __forceinline__ int lower_bound_d(const double *__restrict__ a, int n, double v)
-{  // number of elements < v
-    int lo = 0, hi = n;
-    while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
-    return lo;
-}
-
-__device__ __forceinline__ int upper_bound_d(const double *__restrict__ a, int n, double v)
-{  // number of elements <= v
-    int lo = 0, hi = n;
-    while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] <= v) lo = m + 1; else hi = m; }
-    return lo;
-}
 
 // compare-exchange with the partner's element: keep the smaller value if keep_min, else the larger.
 // Equal values need no tie-break here: any consistent order among them still makes the ranks
@@ -868,6 +859,10 @@ int32_t launch_k1(reo_ctx *c, int k)
     std::vector<uint32_t> units;
     int64_t owned = 0, total = 0;
     uint32_t gu = 0;
+    // chunk-ownership mask for K2 (16-byte chunks = 128 columns; one row of bits per 32-row block)
+    const int Wq = c->Wp / 4, own_words = (Wq + 31) / 32, nblk32 = c->Gp / 32;
+    std::vector<uint32_t> ownm(c->world > 1 ? static_cast<size_t>(nblk32) * own_words : 0, 0u);
+    auto mark = [&](int rowblk, int chunk) { ownm[static_cast<size_t>(rowblk) * own_words + (chunk >> 5)] |= 1u << (chunk & 31); };
     for (int p = 0; p < NP; ++p) {
         const int ni = std::min(NIT, (CJ / kTileI) * Q * (p + 1));  // i-tiles that reach this panel's columns
         for (int r = 0; r * kUnitH < ni; ++r, ++gu) {
@@ -878,11 +873,23 @@ int32_t launch_k1(reo_ctx *c, int k)
                     if ((jc * CJ + CJ - 1) / 64 < (t * kTileI) / 64) continue;
                     ++total;
                     if (mine) ++owned;
+                    if (mine && c->world > 1) {
+                        // forward bits: rows of tile t, columns of chunk jc; mirror bits: rows of chunk jc, columns of tile t
+                        for (int q = jc * CJ / 128; q < std::min(Wq, (jc + 1) * CJ / 128); ++q) mark(t, q);
+                        for (int rb = jc * CJ / 32; rb < std::min(nblk32, (jc + 1) * CJ / 32); ++rb) mark(rb, (t * kTileI) / 128);
+                    }
                 }
         }
     }
     c->tiles_owned = owned; c->tiles_total = total;
     c->k1_cj = CJ; c->k1_q = Q;
+    c->own_words = own_words;
+    if (c->world > 1) {
+        int32_t rc0;
+        if ((rc0 = c->own_mask.ensure(ownm.size()))) return rc0;
+        REO_HIP_CHECK(hipMemcpyAsync(c->own_mask.p, ownm.data(), ownm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     a.n_units = static_cast<int>(units.size()); a.Q = Q;
     int32_t rc;
     if ((rc = c->unit_map.ensure(std::max<size_t>(units.size(), 1)))) return rc;
@@ -940,7 +947,7 @@ int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits)
     tic(c, 2);
     k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(c->state.p, reinterpret_cast<const uint4 *>(c->table.p),
                                                  reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp / 4,
-                                                 c->raw.p);
+                                                 c->world > 1 ? c->own_mask.p : nullptr, c->own_words, c->raw.p);
     toc(c);
     c->t_ms[4] += 1.0;
     REO_HIP_CHECK(hipGetLastError());

@@ -102,6 +102,8 @@ struct reo_ctx {
     reo::DevBuf<unsigned char> t_temp;
     reo::DevBuf<int32_t> t_order, t_flags, t_slots;
     reo::DevBuf<uint32_t> unit_map;  // K1 work units: panel << 16 | i-range
+    reo::DevBuf<uint32_t> own_mask;  // [Gp/32][own_words] chunks of the class table this shard wrote (world > 1)
+    int own_words = 0;
     bool transformed = false;
     int has_ties = 0;
 

@@ -17,28 +17,32 @@ class _RawDev:
 
 
 def allreduce_hook(device=None, group=None, via_host: bool = False):
-    """fn(ptr, count): sum int32[count] at `ptr` across the process group, in place.
-    `device` is a torch cuda device for device pointers, None for host pointers (gloo tests).
-    via_host=True stages a device buffer through the host so that a gloo group can reduce it
-    (debugging the sharded flow with several ranks on one GPU, where RCCL refuses to run)."""
+    """fn(ptr, count, stream): sum int32[count] at `ptr` across the process group, in place, ordered
+    on the library's HIP stream.  `device` is a torch cuda device for device pointers: the collective
+    (RCCL through torch.distributed) is enqueued under torch.cuda.stream(ExternalStream(stream)), so
+    nothing blocks on the host.  device=None: `ptr` is a host pointer (gloo tests).  via_host=True
+    stages a device buffer through the host so that a gloo group can reduce it (debugging the sharded
+    flow with several ranks on one GPU, where RCCL refuses to run)."""
     import torch
     import torch.distributed as dist
 
-    def fn(ptr: int, count: int) -> None:
-        if device is not None and via_host:
-            t = torch.as_tensor(_RawDev(ptr, count), device=device)
-            h = t.cpu()
-            dist.all_reduce(h, group=group)
-            t.copy_(h)
-            torch.cuda.synchronize(device)
-        elif device is not None:
-            t = torch.as_tensor(_RawDev(ptr, count), device=device)
-            dist.all_reduce(t, group=group)
-            torch.cuda.synchronize(device)
-        else:
+    def fn(ptr: int, count: int, stream: int = 0) -> None:
+        if device is None:
             buf = (ctypes.c_int32 * count).from_address(ptr)
             t = torch.from_numpy(np.ctypeslib.as_array(buf))
             dist.all_reduce(t, group=group)
+            return
+        ext = torch.cuda.ExternalStream(stream, device=device) if stream else torch.cuda.current_stream(device)
+        with torch.cuda.stream(ext):
+            t = torch.as_tensor(_RawDev(ptr, count), device=device)
+            if via_host:
+                ext.synchronize()
+                h = t.cpu()
+                dist.all_reduce(h, group=group)
+                t.copy_(h)
+                ext.synchronize()
+            else:
+                dist.all_reduce(t, group=group)  # enqueued; `ext` waits for it, the host does not
 
     return fn
 

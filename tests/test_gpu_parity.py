@@ -267,7 +267,8 @@ def test_two_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle):
 
     def run(rank):
         try:
-            def hook(ptr, count):
+            def hook(ptr, count, stream):
+                torch.cuda.ExternalStream(stream, device=dev).synchronize()  # a host-side hook syncs the stream itself
                 slots[rank] = torch.as_tensor(pkg.dist._RawDev(ptr, count), device=dev)
                 barrier.wait()
                 if rank == 0:

@@ -71,7 +71,7 @@ def _worker(rank, world, port, G, S, seed, out):
         trace, i_iter = [], 0
         while i_iter < 6:
             raw = np.ascontiguousarray(sh.raw_counters(code, ref, mask))
-            hook(raw.ctypes.data, raw.size)                       # sum over shards, in place
+            hook(raw.ctypes.data, raw.size, 0)                    # sum over shards, in place
             cont = sh.derive_tallies(raw, ref)
             assert np.array_equal(cont, oracle.tally(code, ref))  # == unsharded tallies, bit for bit
             inds = np.zeros(G, dtype=np.uint8)
