@@ -93,6 +93,119 @@ __device__ __forceinline__ void acc4(float2v &c0, float2v &c1, float2v a0, float
             : "s"(a0), "s"(a1), "v"(bb));
 }
 
+// Same as acc4 with the band edges in VGPR pairs (they come from LDS broadcast reads).
+template <bool HI>
+__device__ __forceinline__ void acc4v(float2v &c0, float2v &c1, float2v a0, float2v a1, float2v bb)
+{
+    float2v t0, t1;
+    if (HI)
+        asm("v_pk_add_f32 %2, %4, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %3, %5, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3"
+            : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
+            : "v"(a0), "v"(a1), "v"(bb));
+    else
+        asm("v_pk_add_f32 %2, %4, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %3, %5, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %0, %0, %2\n\t"
+            "v_pk_add_f32 %1, %1, %3"
+            : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
+            : "v"(a0), "v"(a1), "v"(bb));
+}
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+constexpr int kStage = 32;  // sample slots per LDS stage of the band edges
+
+// LDS-fed form of the pair loop for the whole workgroup (every thread must call it: it has barriers).
+// The band edges of the tile's 32 genes are staged through LDS in chunks of kStage sample slots:
+// ordinary 16-byte vector loads, issued one chunk ahead (vmcnt is ordered, so unlike scalar loads
+// they can stay in flight across the compute phase), double-buffered, one barrier per chunk.  Each
+// wave reads a sample's 32 edges back with broadcast ds_read_b128 and runs the same packed
+// clamp/add pairs on VGPR operands.  With RJ = 2 genes per lane the LDS pipe is about half busy.
+// Measured reason for this form: with scalar loads (count_pass) 31 % of K1's time is exposed s_load
+// latency -- SMEM returns out of order, so a wave can keep only one generation of loads in flight.
+template <int RI, int RJ, bool TIES>
+__device__ __forceinline__ void count_pass_lds(const uint4 *__restrict__ pos8, const float *__restrict__ lo,
+                                               const float *__restrict__ hi, int Gp, int i0, int j, int s8b,
+                                               int s8e, float2v (&gt)[RJ][RI / 2], float2v (&ge)[RJ][RI / 2],
+                                               float4v *sm_lo, float4v *sm_hi)
+{
+    static_assert(RI == 32, "stage layout assumes 32 genes = 8 float4 per sample");
+#pragma unroll
+    for (int r = 0; r < RJ; ++r)
+#pragma unroll
+        for (int ii = 0; ii < RI / 2; ++ii) { gt[r][ii] = float2v{0.f, 0.f}; ge[r][ii] = float2v{0.f, 0.f}; }
+    const int sb = s8b * 8, se = s8e * 8;  // sample slots
+    if (sb >= se) return;
+    const int srow = threadIdx.x >> 3, scol = threadIdx.x & 7;  // staging role: sample row, float4 column
+    auto stage_load = [&](int s0, float4v &vl, float4v &vh) {
+        const int s = min(s0 + srow, se - 1);
+        vl = *reinterpret_cast<const float4v *>(lo + static_cast<size_t>(s) * Gp + i0 + 4 * scol);
+        if (TIES) vh = *reinterpret_cast<const float4v *>(hi + static_cast<size_t>(s) * Gp + i0 + 4 * scol);
+    };
+    float4v vl, vh;
+    stage_load(sb, vl, vh);
+    __syncthreads();  // the previous pass may still be reading the stage buffers
+    sm_lo[srow * 8 + scol] = vl;
+    if (TIES) sm_hi[srow * 8 + scol] = vh;
+    __syncthreads();
+    const uint4 *pb = pos8 + static_cast<size_t>(s8b) * Gp + j;  // lane's genes: j, j + 256, ...
+    int buf = 0;
+    for (int s0 = sb; s0 < se; s0 += kStage) {
+        const bool more = s0 + kStage < se;
+        if (more) stage_load(s0 + kStage, vl, vh);  // in flight during this chunk's compute
+        const float4v *al = sm_lo + buf * (kStage * 8);
+        const float4v *ah = sm_hi + buf * (kStage * 8);
+        const int ng = min(kStage, se - s0) >> 3;  // groups of 8 slots in this chunk
+        for (int g8 = 0; g8 < ng; ++g8) {
+            uint4 cur[RJ];
+#pragma unroll
+            for (int r = 0; r < RJ; ++r) cur[r] = pb[r * 256];
+            pb += Gp;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float2v bb[RJ];
+#pragma unroll
+                for (int r = 0; r < RJ; ++r) {
+                    const uint32_t w = kk == 0 ? cur[r].x : kk == 1 ? cur[r].y : kk == 2 ? cur[r].z : cur[r].w;
+                    bb[r] = float2v{static_cast<float>(w & 0xFFFFu), static_cast<float>(w >> 16)};
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int srel = g8 * 8 + kk * 2 + half;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4v a = al[srel * 8 + q];  // broadcast read: every lane the same address
+                        const float2v a0 = {a.x, a.y}, a1 = {a.z, a.w};
+#pragma unroll
+                        for (int r = 0; r < RJ; ++r) {
+                            if (half) acc4v<true>(gt[r][2 * q], gt[r][2 * q + 1], a0, a1, bb[r]);
+                            else acc4v<false>(gt[r][2 * q], gt[r][2 * q + 1], a0, a1, bb[r]);
+                        }
+                        if (TIES) {
+                            const float4v h = ah[srel * 8 + q];
+                            const float2v h0 = {h.x, h.y}, h1 = {h.z, h.w};
+#pragma unroll
+                            for (int r = 0; r < RJ; ++r) {
+                                if (half) acc4v<true>(ge[r][2 * q], ge[r][2 * q + 1], h0, h1, bb[r]);
+                                else acc4v<false>(ge[r][2 * q], ge[r][2 * q + 1], h0, h1, bb[r]);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one sample's band edges (32 VGPRs) live at a time
+                }
+            }
+        }
+        if (more) {
+            sm_lo[(buf ^ 1) * (kStage * 8) + srow * 8 + scol] = vl;
+            if (TIES) sm_hi[(buf ^ 1) * (kStage * 8) + srow * 8 + scol] = vh;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 template <int RI, int RJ, bool TIES>
 __device__ __forceinline__ void count_pass(const uint4 *__restrict__ pos8, const float *__restrict__ lo,
                                            const float *__restrict__ hi, int Gp, int i0, int j, int s8b,
@@ -168,8 +281,8 @@ __device__ __forceinline__ int side_state(int n, int size, int m) { return n >= 
 
 // MULTI = one-vs-rest with more than two groups (:375-390): the treat side is every other group,
 // counted group by group because the tie coins are keyed by group.
-template <int RI, int RJ, bool TIES, bool MULTI>
-__global__ __launch_bounds__(256, MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4 : 5)) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
+template <int RI, int RJ, bool TIES, bool MULTI, bool LDSFEED>
+__global__ __launch_bounds__(256, LDSFEED ? 3 : (MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4 : 5))) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
 {
     static_assert(RI == 32, "one mirror word per tile");
     const int lane = threadIdx.x & 63;
@@ -190,12 +303,19 @@ __global__ __launch_bounds__(256, MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4
     if (i0 >= a.Gp || jc * CJ >= a.Gp) return;
     const int j0 = jc * CJ + threadIdx.x;  // this lane's genes are j0 + 256 r
     const int bi = i0 >> 6;                // 64-gene blocks
-    if (((j0 + 256 * (RJ - 1)) >> 6) < bi) return;  // every gene of this wave is strictly below the diagonal
+    if (LDSFEED) {  // barriers inside: only a whole workgroup may leave
+        if (((jc * CJ + CJ - 1) >> 6) < bi) return;
+    } else {
+        if (((j0 + 256 * (RJ - 1)) >> 6) < bi) return;  // every gene of this wave is strictly below the diagonal
+    }
+    __shared__ float4v sm_lo[LDSFEED ? 2 * kStage * 8 : 1];
+    __shared__ float4v sm_hi[(LDSFEED && TIES) ? 2 * kStage * 8 : 1];
 
     float2v gt[RJ][RI / 2], ge[RJ][RI / 2];
     uint32_t cL[RJ], cH[RJ], tL[RJ], tH[RJ];
 
-    count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge);
+    if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge, sm_lo, sm_hi);
+    else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge);
 #pragma unroll
     for (int r = 0; r < RJ; ++r) {
         cL[r] = 0; cH[r] = 0;
@@ -214,7 +334,8 @@ __global__ __launch_bounds__(256, MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4
         }
     }
     if (!MULTI) {
-        count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge);
+        if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge, sm_lo, sm_hi);
+        else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge);
 #pragma unroll
         for (int r = 0; r < RJ; ++r) {
             tL[r] = 0; tH[r] = 0;
@@ -240,7 +361,8 @@ __global__ __launch_bounds__(256, MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4
             for (int ii = 0; ii < RI; ++ii) tot[r][ii] = 0;
         for (int g = 0; g < a.ngroups; ++g) {
             if (g == a.gc) continue;
-            count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge);
+            if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi);
+            else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge);
 #pragma unroll
             for (int r = 0; r < RJ; ++r)
 #pragma unroll
@@ -901,11 +1023,11 @@ int32_t launch_k1(reo_ctx *c, int k)
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
     tic(c, 1);
     if (multi) {
-        if (c->has_ties) k1_pairs<kTileI, 1, true, true><<<grid, 256, 0, c->stream>>>(a);
-        else k1_pairs<kTileI, kRJ, false, true><<<grid, 256, 0, c->stream>>>(a);
+        if (c->has_ties) k1_pairs<kTileI, 1, true, true, false><<<grid, 256, 0, c->stream>>>(a);
+        else k1_pairs<kTileI, kRJ, false, true, true><<<grid, 256, 0, c->stream>>>(a);
     } else {
-        if (c->has_ties) k1_pairs<kTileI, 1, true, false><<<grid, 256, 0, c->stream>>>(a);
-        else k1_pairs<kTileI, kRJ, false, false><<<grid, 256, 0, c->stream>>>(a);
+        if (c->has_ties) k1_pairs<kTileI, 1, true, false, false><<<grid, 256, 0, c->stream>>>(a);
+        else k1_pairs<kTileI, kRJ, false, false, true><<<grid, 256, 0, c->stream>>>(a);
     }
     toc(c);
     REO_HIP_CHECK(hipGetLastError());

@@ -16,7 +16,7 @@ constexpr int kTileJ = 256;   // genes per workgroup along j (4 waves x 64 lanes
 constexpr int kTileI = 32;    // gene rows per pair tile (one mirror word)
 constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kUnitH = 32;    // i-tiles per K1 work unit
-constexpr int kRJ = 1;        // genes j per lane in the tie-free pair kernel
+constexpr int kRJ = 2;        // genes j per lane in the tie-free pair kernel
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
 constexpr int kSortChunk = 2048; // genes per LDS bitonic sort in the ranking stage
 

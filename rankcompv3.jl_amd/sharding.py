@@ -16,7 +16,7 @@ import numpy as np
 
 TILE_I = 32     # kTileI
 TILE_J = 256    # kTileJ
-RJ = 1          # kRJ (genes per lane in the tie-free kernel)
+RJ = 2          # kRJ (genes per lane in the tie-free kernel)
 UNIT_H = 32     # kUnitH
 
 
