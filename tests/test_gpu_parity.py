@@ -435,3 +435,102 @@ def test_reoa_pseudobulk_mode(pkg, oracle, tmp_path):
     run = df.attrs["run"]
     assert run.iters_run == iters and run.trace == trace
     _check_result(run.result, exp)
+
+
+def _random_case(rng):
+    G = int(rng.integers(12, 700))
+    ng = int(rng.choice([2, 2, 2, 3, 4]))
+    sizes = rng.integers(2, 24, size=ng)
+    S = int(sizes.sum())
+    labels = np.concatenate([[f"grp{g}"] * int(n) for g, n in enumerate(sizes)])
+    if rng.random() < 0.5:
+        labels = labels[rng.permutation(S)]
+    kind = rng.choice(["small_int", "wide_int", "float_band", "ranks", "float_cont"])
+    if kind == "small_int":
+        X = rng.integers(0, int(rng.integers(2, 12)), size=(G, S))
+    elif kind == "wide_int":
+        X = rng.integers(-50000, 50000, size=(G, S))
+    elif kind == "float_band":  # many values closer than 0.1 apart, some exactly 0.1 apart
+        X = np.round(rng.normal(5, 1.0, size=(G, S)), 1) + rng.choice([0.0, 0.04, 0.099, 0.1], size=(G, S))
+    elif kind == "ranks":
+        X = np.argsort(np.argsort(rng.random((G, S)), axis=0), axis=0)
+    else:
+        X = rng.normal(0, 3, size=(G, S))
+    return dict(G=G, S=S, ng=ng, labels=labels, X=X, kind=str(kind), pval_reo=float(rng.choice([0.01, 0.05, 0.3])),
+                n_conv=int(rng.choice([1, 5])), n_iter=int(rng.integers(1, 7)), seed=int(rng.integers(0, 2 ** 40)),
+                nref=int(rng.integers(3, G)))
+
+
+def test_randomized_sweep_against_oracle(pkg, oracle):
+    """Random shapes, group layouts (2-4 groups, contiguous or interleaved), dtypes and tie structures."""
+    rng = np.random.default_rng(20261003)
+    kinds = set()
+    for case_no in range(40):
+        cs = _random_case(rng)
+        G, S = cs["G"], cs["S"]
+        if G < 10:
+            continue
+        gid, lev = pkg.encode_groups(cs["labels"])
+        ref0 = pkg.synth.ref_mask(G, cs["nref"], cs["seed"])
+        tag = (case_no, cs["kind"], G, S, cs["ng"])
+        run = pkg.run_identify_degs(cs["X"], cs["labels"], list(range(G)), cs["pval_reo"], 1.0, 0.05, ref0, cs["n_iter"],
+                                    cs["n_conv"], seed=cs["seed"], device=0)
+        Xf = np.asarray(cs["X"], dtype=np.float64)
+        for cm in run.comparisons:
+            exp, iters, trace = oracle.identify_degs(Xf, gid, len(lev), cs["pval_reo"], 1.0, 0.05, ref0, cs["n_iter"],
+                                                     cs["n_conv"], cs["seed"], k=cm["k"])
+            assert cm["iters_run"] == iters and cm["trace"] == trace, tag
+            assert np.array_equal(cm["result"][:, 2:11], exp[:, 2:11]), tag
+            ok = np.isfinite(exp).all(axis=1)
+            assert np.allclose(cm["result"][ok][:, :2], exp[ok][:, :2], rtol=0, atol=P_ATOL), tag
+            assert np.allclose(cm["result"][ok][:, 11:], exp[ok][:, 11:], rtol=STAT_RTOL, atol=1e-9), tag
+        if case_no % 4 == 0:  # raw counts on the whole pair matrix
+            with pkg.Context(device=0, seed=cs["seed"]) as ctx:
+                ctx.set_matrix(cs["X"])
+                ctx.set_groups(gid, len(lev))
+                gt, eq = ctx.pair_counts(0, G, 0, G)
+                egt, eeq = oracle.pair_counts(Xf, gid, len(lev), 0, G, 0, G)
+                assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), tag
+        kinds.add(cs["kind"])
+    assert len(kinds) == 5
+
+
+def test_maximum_gene_count_65535(pkg, oracle):
+    """G = 65535 (the u16 position limit), S = 16: sampled pair blocks and the mirror rule at full size."""
+    G, S, seed = 65535, 16, 77
+    rng = np.random.default_rng(seed)
+    X = rng.integers(0, 40, size=(G, S))  # tie-rich
+    group = pkg.synth.groups(S)
+    gid, lev = pkg.encode_groups(group)
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X)
+        ctx.set_groups(gid, 2)
+        thr = ctx.compute_thresholds(0.01)
+        assert thr[:, 0].tolist() == [8, 8]
+        Xf = X.astype(np.float64)
+        for (i0, i1, j0, j1) in [(0, 40, 65400, 65535), (65500, 65535, 0, 300), (32760, 32790, 32700, 32900)]:
+            gt, eq = ctx.pair_counts(i0, i1, j0, j1)
+            egt, eeq = oracle.pair_counts(Xf, gid, 2, i0, i1, j0, j1)
+            assert np.array_equal(gt, egt) and np.array_equal(eq, eeq)
+        ctx.build_pairs(0)
+        for (a, b) in [(0, 65279), (65279, 65279), (40000, 123)]:
+            c1 = ctx.get_codes(a, a + 256, b, b + 256).astype(np.int16)
+            c2 = ctx.get_codes(b, b + 256, a, a + 256).astype(np.int16)
+            off = (np.arange(a, a + 256)[:, None] != np.arange(b, b + 256)[None, :])
+            assert np.array_equal(c1[off], (8 - c2.T)[off]) and ((c1 == 255) == ~off).all()
+        # codes of a block against the oracle's classification of the same counts (tie coins included)
+        i0, i1, j0, j1 = 1000, 1032, 60000, 60256
+        gt, eq = oracle.pair_counts(Xf, gid, 2, i0, i1, j0, j1)
+        exp = np.empty((i1 - i0, j1 - j0), dtype=np.uint8)
+        for a in range(i1 - i0):
+            for b in range(j1 - j0):
+                nre = [int(gt[a, b, g]) + (oracle.tie_wins(seed, i0 + a, j0 + b, g, int(eq[a, b, g])) if eq[a, b, g] else 0) for g in (0, 1)]
+                ic = 2 if nre[0] >= 8 else (0 if 8 - nre[0] >= 8 else 1)
+                it = 2 if nre[1] >= 8 else (0 if 8 - nre[1] >= 8 else 1)
+                exp[a, b] = 3 * ic + it
+        assert np.array_equal(ctx.get_codes(i0, i1, j0, j1), exp)
+        ref0 = pkg.synth.ref_mask(G, 3000, seed)
+        cont = ctx.tally(ref0)
+        assert np.array_equal(cont.sum(axis=1), ref0.sum() - ref0.astype(np.int64)) and cont.min() >= 0
+        res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, 4, 5)
+        assert 1 <= iters <= 4 and np.isfinite(res).all()
