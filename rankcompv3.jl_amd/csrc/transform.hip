@@ -57,16 +57,26 @@ template <class T>
 __global__ __launch_bounds__(256) void t_keys(const T *__restrict__ X, int64_t ld,
                                               const int32_t *__restrict__ colmap, int G, int cb0,
                                               uint64_t *__restrict__ keys, uint16_t *__restrict__ idx,
-                                              int32_t *__restrict__ bad)
+                                              int32_t *__restrict__ bad, unsigned long long *__restrict__ varbits)
 {
     int g = blockIdx.x * 256 + threadIdx.x;
     int c = blockIdx.y;
-    if (g >= G) return;
-    T x = X[static_cast<int64_t>(g) + static_cast<int64_t>(colmap[cb0 + c]) * ld];
-    if (!Codec<T>::finite(x)) atomicOr(bad, 1);
-    size_t o = static_cast<size_t>(c) * G + g;
-    keys[o] = Codec<T>::enc(x);
-    idx[o] = static_cast<uint16_t>(g);
+    uint64_t diff = 0;
+    if (g < G) {
+        T x = X[static_cast<int64_t>(g) + static_cast<int64_t>(colmap[cb0 + c]) * ld];
+        if (!Codec<T>::finite(x)) atomicOr(bad, 1);
+        size_t o = static_cast<size_t>(c) * G + g;
+        const uint64_t k = Codec<T>::enc(x);
+        keys[o] = k;
+        idx[o] = static_cast<uint16_t>(g);
+        diff = k ^ Codec<T>::enc(X[0]);  // bits in which any key differs from one fixed key
+    }
+    // only the key bits that vary anywhere need sorting: OR-reduce them (wave, then one atomic per wave)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    // most waves find their bits already recorded: look before touching the one shared word
+    if ((threadIdx.x & 63) == 0 && (diff & ~__hip_atomic_load(varbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
+        atomicOr(varbits, diff);
 }
 
 template <class T>
@@ -146,10 +156,11 @@ int32_t transform_impl(reo_ctx *c)
     // scratch lives in the context (grow-only): hipMalloc/hipFree per call cost milliseconds
     DevBuf<int32_t> &d_order = c->t_order, &d_flags = c->t_flags;
     int32_t rc;
-    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(2)) || (rc = c->t_slots.ensure(S))) return rc;
+    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(4)) || (rc = c->t_slots.ensure(S))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
     REO_HIP_CHECK(hipMemcpyAsync(c->t_slots.p, slots.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
-    REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 2 * sizeof(int32_t), st));
+    REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int32_t), st));
+    unsigned long long *d_varbits = reinterpret_cast<unsigned long long *>(d_flags.p + 2);
     if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff8_units.data(), sizeof(int32_t) * (c->ngroups + 1),
                                  hipMemcpyHostToDevice, st));
@@ -181,12 +192,20 @@ int32_t transform_impl(reo_ctx *c)
     for (int cb0 = 0; cb0 < S; cb0 += CB) {
         const int nc = std::min(CB, S - cb0);
         dim3 grid((G + 255) / 256, nc);
-        t_keys<T><<<grid, 256, 0, st>>>(X, c->ld, d_order.p, G, cb0, k_in.p, v_in.p, d_flags.p);
+        REO_HIP_CHECK(hipMemsetAsync(d_varbits, 0, sizeof(unsigned long long), st));
+        t_keys<T><<<grid, 256, 0, st>>>(X, c->ld, d_order.p, G, cb0, k_in.p, v_in.p, d_flags.p, d_varbits);
+        // radix-sort only the bit range in which the keys of this batch differ at all (rank-like data: 15 bits)
+        unsigned long long vb = 0;
+        REO_HIP_CHECK(hipMemcpyAsync(&vb, d_varbits, sizeof vb, hipMemcpyDeviceToHost, st));
+        REO_HIP_CHECK(hipStreamSynchronize(st));
+        unsigned begin_bit = 0, end_bit = 64;
+        if (vb == 0) { begin_bit = 0; end_bit = 1; }
+        else { begin_bit = static_cast<unsigned>(__builtin_ctzll(vb)); end_bit = 64u - static_cast<unsigned>(__builtin_clzll(vb)); }
         size_t tb = temp_bytes;
         REO_HIP_CHECK(rocprim::segmented_radix_sort_pairs(temp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p,
                                                           static_cast<unsigned>(static_cast<size_t>(nc) * G),
                                                           static_cast<unsigned>(nc), seg_begin, seg_begin + 1,
-                                                          0, 64, st));
+                                                          begin_bit, end_bit, st));
         t_bands<T><<<grid, 256, 0, st>>>(k_out.p, v_out.p, G, Gp, cb0, c->t_slots.p, c->pos.p, c->lo.p, c->hi.p,
                                          d_flags.p + 1);
     }
