@@ -662,12 +662,15 @@ __device__ __forceinline__ void cmpx(double &v, uint32_t &i, double pv, uint32_t
     if (take) { v = pv; i = pi; }
 }
 
-// Bitonic sort of one 2048-gene chunk by 512 threads, four consecutive elements per thread in
-// registers.  Exchange distances 1 and 2 stay inside the thread, distances 4..128 go through wave
-// shuffles, and only the six stages with distance >= 256 (partner in another wave) use LDS + a barrier.
-__global__ __launch_bounds__(512) void k3_sort_chunks(const IterState *__restrict__ st,
-                                                      const double *__restrict__ d1, int G,
-                                                      double *__restrict__ cv, uint16_t *__restrict__ ci)
+// Bitonic sort of one kSortChunk-gene chunk, four consecutive elements per thread in registers
+// (kSortChunk / 4 threads).  Exchange distances 1 and 2 stay inside the thread, distances 4..128 go
+// through wave shuffles, and only the stages with distance >= 256 (partner in another wave) use
+// LDS + a barrier.
+constexpr int kSortThreads = kSortChunk / 4;
+
+__global__ __launch_bounds__(kSortThreads) void k3_sort_chunks(const IterState *__restrict__ st,
+                                                               const double *__restrict__ d1, int G,
+                                                               double *__restrict__ cv, uint16_t *__restrict__ ci)
 {
     if (st->done) return;
     __shared__ double sv[kSortChunk];
@@ -720,62 +723,60 @@ __global__ __launch_bounds__(512) void k3_sort_chunks(const IterState *__restric
     for (int e = 0; e < 4; ++e) { cv[base + x0 + e] = v[e]; ci[base + x0 + e] = static_cast<uint16_t>(id[e]); }
 }
 
-// Two-level search: every 32nd element of every chunk (64 splitters per chunk) is staged in LDS;
-// six LDS steps pick the 32-element segment, five global steps finish inside it.
-__global__ __launch_bounds__(256) void k3_merge_rank(const IterState *__restrict__ st, const double *__restrict__ cv,
+// Rank of an element = its position in its own chunk + the number of smaller elements in every
+// other chunk.  A group of kMergeLanes lanes serves one element: each lane searches different
+// chunks (two-level: every 32nd element of every chunk sits in LDS as a splitter; log2(kSortChunk/32)
+// LDS steps pick the 32-element segment, five global steps finish inside it), then the counts are
+// summed across the group with shuffles.  Chunks hold contiguous gene ranges, so "smaller gene
+// index" is "earlier chunk": equal values of earlier chunks sort first.
+constexpr int kMergeLanes = 16;
+constexpr int kMergeThreads = 256;   // 16 elements per workgroup share one copy of the splitters
+constexpr int kSplit = kSortChunk / 32;  // splitters per chunk
+
+__global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *__restrict__ st, const double *__restrict__ cv,
                                                      const uint16_t *__restrict__ ci, int G, int nchunk,
                                                      uint32_t *__restrict__ rs, double *__restrict__ sorted_d)
 {
     if (st->done) return;
-    __shared__ double spl[32 * 64];  // [chunk][64], nchunk <= 32
-    for (int t = threadIdx.x; t < nchunk * 64; t += 256) spl[t] = cv[(t >> 6) * kSortChunk + ((t & 63) << 5)];
+    __shared__ double spl[(65536 / kSortChunk) * kSplit];  // [chunk][kSplit]: 2048 splitters at most (G <= 65535)
+    for (int t = threadIdx.x; t < nchunk * kSplit; t += kMergeThreads) spl[t] = cv[(t / kSplit) * kSortChunk + ((t % kSplit) << 5)];
     __syncthreads();
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int c = e / kSortChunk, p = e % kSortChunk;  // c is uniform in the workgroup
-    const int gene = c * kSortChunk + ci[e];
-    if (gene >= G) return;
-    const double v = cv[e];
-    int rank = p;
-    for (int c0 = 0; c0 < nchunk; c0 += 8) {  // eight independent searches in flight
-        int lo[8], hi[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int cc = c0 + u;
-            const bool on = cc < nchunk && cc != c;
-            const int n = on ? min(kSortChunk, G - cc * kSortChunk) : 0;  // valid elements of that chunk
-            // segment search over the splitters: number of splitters that sort before v
-            int a = 0, b = on ? (n + 31) >> 5 : 0;
-            const double *sp = spl + (cc < nchunk ? cc : 0) * 64;
-#pragma unroll 1
-            for (int step = 0; step < 7 && a < b; ++step) {
+    const int e = blockIdx.x * (kMergeThreads / kMergeLanes) + threadIdx.x / kMergeLanes;  // element (position in the chunked array)
+    const int sub = threadIdx.x % kMergeLanes;
+    const int c = e / kSortChunk, p = e % kSortChunk;
+    const bool live = e < nchunk * kSortChunk;
+    const int gene = live ? c * kSortChunk + ci[e] : G;
+    const double v = live ? cv[e] : 0.0;
+    int count = 0;
+    if (gene < G) {
+        for (int cc = sub; cc < nchunk; cc += kMergeLanes) {
+            if (cc == c) continue;
+            const int n = min(kSortChunk, G - cc * kSortChunk);  // valid elements of that chunk
+            const double *sp = spl + cc * kSplit;
+            int a = 0, b = (n + 31) >> 5;
+            while (a < b) {  // number of splitters that sort before v
                 const int m = (a + b) >> 1;
                 const double w = sp[m];
-                const bool less = cc < c ? (w <= v) : (w < v);  // equal values of earlier genes sort first
-                if (less) a = m + 1; else b = m;
+                if (cc < c ? (w <= v) : (w < v)) a = m + 1; else b = m;
             }
-            // a = count of splitters before v: the answer lies in (32(a-1), 32a] clipped to the chunk
-            lo[u] = a > 0 ? ((a - 1) << 5) + 1 : 0;
-            hi[u] = a > 0 ? min(n, a << 5) : 0;
-            if (!on) { lo[u] = 0; hi[u] = 0; }
-        }
-#pragma unroll 1
-        for (int step = 0; step < 6; ++step) {  // at most 32 candidates left
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (lo[u] < hi[u]) {
-                    const int cc = c0 + u;
-                    const int m = (lo[u] + hi[u]) >> 1;
-                    const double w = cv[cc * kSortChunk + m];
-                    const bool less = cc < c ? (w <= v) : (w < v);
-                    if (less) lo[u] = m + 1; else hi[u] = m;
-                }
+            if (a == 0) continue;
+            int lo = ((a - 1) << 5) + 1, hi = min(n, a << 5);  // the answer lies in (32(a-1), 32a]
+            const double *ch = cv + cc * kSortChunk;
+            while (lo < hi) {
+                const int m = (lo + hi) >> 1;
+                const double w = ch[m];
+                if (cc < c ? (w <= v) : (w < v)) lo = m + 1; else hi = m;
             }
+            count += lo;
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) rank += lo[u];
     }
-    rs[gene] = rank;
-    sorted_d[rank] = v;
+#pragma unroll
+    for (int o = kMergeLanes >> 1; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
+    if (sub == 0 && gene < G) {
+        const int rank = p + count;
+        rs[gene] = rank;
+        sorted_d[rank] = v;
+    }
 }
 
 // count of elements < v (strict = true) or <= v (strict = false) in the sorted array a[0..n): a coarse
@@ -1092,8 +1093,8 @@ int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int 
     double *res = c->result.p;
     const double *d1 = res + 11 * c->G;
     const int nchunk = (G + kSortChunk - 1) / kSortChunk;
-    k3_sort_chunks<<<nchunk, 512, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p);
-    k3_merge_rank<<<nchunk * kSortChunk / 256, 256, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
+    k3_sort_chunks<<<nchunk, kSortThreads, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p);
+    k3_merge_rank<<<(nchunk * kSortChunk + kMergeThreads / kMergeLanes - 1) / (kMergeThreads / kMergeLanes), kMergeThreads, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
                                                                    c->rank_s.p, c->sorted_d.p);
     k3_abs_rank<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->sorted_d.p, G, static_cast<int>(a - 1),
                                            static_cast<int>(b - 1), c->rank_a.p, c->part.p);

@@ -18,7 +18,7 @@ constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kUnitH = 32;    // i-tiles per K1 work unit
 constexpr int kRJ = 2;        // genes j per lane in the tie-free pair kernel
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
-constexpr int kSortChunk = 2048; // genes per LDS bitonic sort in the ranking stage
+constexpr int kSortChunk = 1024; // genes per bitonic sort in the ranking stage
 
 // Device-resident loop state of the iteration driver (src/RankCompV3.jl:396-425),
 // so that passes can be enqueued back to back without a host round trip.
