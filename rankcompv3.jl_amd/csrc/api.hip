@@ -146,7 +146,7 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(64)) ||
         (rc = c->state.ensure(1)) ||
         (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) ||
-        (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * 256)))
+        (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
@@ -443,7 +443,6 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
             const int cur = t & 1;  // pass t reads mask buffer t&1 and writes the other (ref_gene_vec = inds, :424)
             if ((rc = launch_k2(c, c->refbits[cur].p))) return rc;
             if ((rc = allreduce_raw(c))) return rc;
-            if ((rc = launch_derive(c, c->refbytes[cur].p, 1))) return rc;
             if ((rc = launch_stats(c, cur, pval_deg, padj_deg, n_conv, a, b))) return rc;
         }
         toc(c);

@@ -596,17 +596,14 @@ __global__ void k_mccullagh(const int32_t *__restrict__ cont, int64_t n, double 
 // raw counters -> 9 tallies (:403) [-> McCullagh -> result columns 3..15 (:404-405)]
 // nref comes from the
 // device-side iteration state so that passes can be enqueued back to back.
-__global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ st, const int32_t *__restrict__ raw,
-                                                 const uint8_t *__restrict__ refbytes, int G,
-                                                 int32_t *__restrict__ cont, double *__restrict__ result,
-                                                 int with_stats)
+// one gene: raw counters -> 9 tallies (:403) [-> McCullagh -> result columns 3..15 (:404-405)]; returns delta1
+__device__ __forceinline__ double derive_gene(const int32_t *__restrict__ raw, const uint8_t *__restrict__ refbytes,
+                                              int nref, int G, int i, int32_t *__restrict__ cont,
+                                              double *__restrict__ result, bool with_stats)
 {
-    if (st->done) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= G) return;
     const int4 r0 = reinterpret_cast<const int4 *>(raw)[2 * i], r1 = reinterpret_cast<const int4 *>(raw)[2 * i + 1];
     const int cLt = r0.x, cHt = r0.y, tLt = r0.z, tHt = r0.w, LL = r1.x, LH = r1.y, HL = r1.z, HH = r1.w;
-    const int total = st->nref - (refbytes[i] ? 1 : 0);  // the diagonal is never set (:363,385)
+    const int total = nref - (refbytes[i] ? 1 : 0);  // the diagonal is never set (:363,385)
     int32_t c[9];
     c[0] = LL; c[2] = LH; c[6] = HL; c[8] = HH;
     c[1] = cLt - LL - LH;
@@ -614,9 +611,11 @@ __global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ s
     c[3] = tLt - LL - HL;
     c[5] = tHt - LH - HH;
     c[4] = total - (cLt + cHt + c[3] + c[5]);
+    if (cont) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) cont[static_cast<size_t>(i) * 9 + t] = c[t];
-    if (!with_stats) return;
+        for (int t = 0; t < 9; ++t) cont[static_cast<size_t>(i) * 9 + t] = c[t];
+    }
+    if (!with_stats) return 0.0;
     double o[5];
     mccullagh3(c, o);
     const size_t Gs = G;
@@ -626,6 +625,19 @@ __global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ s
     for (int t = 0; t < 9; ++t) result[(2 + t) * Gs + i] = static_cast<double>(c[t]);
     result[11 * Gs + i] = o[1]; result[12 * Gs + i] = o[2];
     result[13 * Gs + i] = o[3]; result[14 * Gs + i] = o[4];
+    return o[1];
+}
+
+// stand-alone form for reo_tally (tallies only)
+__global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ st, const int32_t *__restrict__ raw,
+                                                 const uint8_t *__restrict__ refbytes, int G,
+                                                 int32_t *__restrict__ cont, double *__restrict__ result,
+                                                 int with_stats)
+{
+    if (st->done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G) return;
+    derive_gene(raw, refbytes, st->nref, G, i, cont, result, with_stats != 0);
 }
 
 __device__ __forceinline__ double block_sum_256(double v, double *red)
@@ -735,9 +747,11 @@ constexpr int kSplit = kSortChunk / 32;  // splitters per chunk
 
 __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *__restrict__ st, const double *__restrict__ cv,
                                                      const uint16_t *__restrict__ ci, int G, int nchunk,
-                                                     uint32_t *__restrict__ rs, double *__restrict__ sorted_d)
+                                                     int a0, int b0, uint32_t *__restrict__ rs,
+                                                     double *__restrict__ sorted_d, double *__restrict__ part)
 {
     if (st->done) return;
+    __shared__ double slice[kMergeThreads / kMergeLanes];
     __shared__ double spl[(65536 / kSortChunk) * kSplit];  // [chunk][kSplit]: 2048 splitters at most (G <= 65535)
     for (int t = threadIdx.x; t < nchunk * kSplit; t += kMergeThreads) spl[t] = cv[(t / kSplit) * kSortChunk + ((t % kSplit) << 5)];
     __syncthreads();
@@ -772,10 +786,23 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *
     }
 #pragma unroll
     for (int o = kMergeLanes >> 1; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
+    bool in = false;
     if (sub == 0 && gene < G) {
         const int rank = p + count;
         rs[gene] = rank;
         sorted_d[rank] = v;
+        in = rank >= a0 && rank <= b0;  // inside the 5 %-95 % slice of :411
+    }
+    // moments (count, mean, M2) of this block's elements that fall into the slice; combined in k3_abs_rank
+    if (sub == 0) slice[threadIdx.x / kMergeLanes] = in ? v : NAN;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double n = 0.0, sum = 0.0;
+        for (int t = 0; t < kMergeThreads / kMergeLanes; ++t) { const double x = slice[t]; if (x == x) { n += 1.0; sum += x; } }
+        const double mean = n > 0.0 ? sum / n : 0.0;
+        double m2 = 0.0;
+        for (int t = 0; t < kMergeThreads / kMergeLanes; ++t) { const double x = slice[t]; if (x == x) m2 += (x - mean) * (x - mean); }
+        part[3 * blockIdx.x] = n; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = m2;
     }
 }
 
@@ -792,77 +819,58 @@ __device__ __forceinline__ int bound_2level(const double *__restrict__ a, int n,
     return l;
 }
 
+// |delta1| ranks (= rank of pval ascending), then se = std of the 5 %-95 % slice of the sorted delta1
+// (n-1 estimator, :409-411) from the per-block moments of k3_merge_rank (every workgroup combines them
+// the same way: n = sum n_b, mean = sum n_b mean_b / n, M2 = sum [M2_b + n_b (mean_b - mean)^2], fixed-
+// order tree sums), then pval = pvalue(Normal(0,se), delta1, tail=:both) (:412) -> column 1, and into
+// rank order for the BH step.
 __global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__ st, const double *__restrict__ d1,
                                                    const uint32_t *__restrict__ rs,
-                                                   const double *__restrict__ sorted_d, int G, int a0, int b0,
-                                                   uint32_t *__restrict__ ra, double *__restrict__ part)
+                                                   const double *__restrict__ sorted_d, int G,
+                                                   const double *__restrict__ part, int npart,
+                                                   uint32_t *__restrict__ ra, double *__restrict__ pval,
+                                                   double *__restrict__ sorted_p, double *__restrict__ scal)
 {
     if (st->done) return;
     __shared__ double red[256];
     __shared__ double spl[1024];  // every 64th element of the sorted vector (G <= 65535)
     const int nspl = (G + 63) >> 6;
     for (int t = threadIdx.x; t < nspl; t += 256) spl[t] = sorted_d[t << 6];
-    __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < G) {
-        const double v = d1[i];
-        const int r = rs[i];
-        const int lbv = bound_2level(sorted_d, G, spl, nspl, v, true);
-        const int ubn = bound_2level(sorted_d, G, spl, nspl, -v, false);
-        int rank;
-        if (v > 0.0) {  // larger |w|: w > v or w < -v; ties: the negatives -v first, then equals of v in sorted order
-            const int ubv = bound_2level(sorted_d, G, spl, nspl, v, false);
-            rank = (G - ubv) + ubn + (r - lbv);
-        } else {        // larger |w|: w < v or w > -v
-            rank = lbv + (G - ubn) + (r - lbv);
-        }
-        ra[i] = rank;
+    double nb = 0.0, sb = 0.0;
+    for (int t = threadIdx.x; t < npart; t += 256) { const double n_ = part[3 * t]; nb += n_; sb += n_ * part[3 * t + 1]; }
+    const double n = block_sum_256(nb, red);  // (also the barrier that publishes spl)
+    const double mean = block_sum_256(sb, red) / n;
+    double qb = 0.0;
+    for (int t = threadIdx.x; t < npart; t += 256) {
+        const double n_ = part[3 * t], d_ = part[3 * t + 1] - mean;
+        qb += part[3 * t + 2] + n_ * d_ * d_;
     }
-    // moments of this block's part of the slice [a0, b0] of the sorted vector (merged in k3_pvals)
-    const bool in = i >= a0 && i <= b0;  // i doubles as a position in sorted order here
-    const double x = in ? sorted_d[i] : 0.0;
-    const double cnt = block_sum_256(in ? 1.0 : 0.0, red);
-    const double sum = block_sum_256(x, red);
-    const double mean = cnt > 0.0 ? sum / cnt : 0.0;
-    const double e = in ? x - mean : 0.0;
-    const double m2 = block_sum_256(e * e, red);
-    if (threadIdx.x == 0) { part[3 * blockIdx.x] = cnt; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = m2; }
-}
-
-// se = std of the 5 %-95 % slice of the sorted delta1 (n-1 estimator, :409-411)
-// from the per-block moments (every workgroup combines them the same way);
-// then pval = pvalue(Normal(0,se), delta1, tail=:both) (:412) -> column 1, and
-// into rank order for the BH step.
-__global__ __launch_bounds__(256) void k3_pvals(const IterState *__restrict__ st, const double *__restrict__ d1,
-                                                const uint32_t *__restrict__ ra, const double *__restrict__ part,
-                                                int nblk, int G, double *__restrict__ pval,
-                                                double *__restrict__ sorted_p, double *__restrict__ scal)
-{
-    if (st->done) return;
-    __shared__ double red[256];
-    // combine the per-block moments around the global mean: n = sum n_b, mean = sum n_b mean_b / n,
-    // M2 = sum [ M2_b + n_b (mean_b - mean)^2 ]  (one partial per thread, fixed-order tree sums)
-    const bool has = static_cast<int>(threadIdx.x) < nblk;
-    const double nb = has ? part[3 * threadIdx.x] : 0.0;
-    const double mb = has ? part[3 * threadIdx.x + 1] : 0.0;
-    const double qb = has ? part[3 * threadIdx.x + 2] : 0.0;
-    const double n = block_sum_256(nb, red);
-    const double mean = block_sum_256(nb * mb, red) / n;
-    const double m2 = block_sum_256(qb + nb * (mb - mean) * (mb - mean), red);
-    const double se = sqrt(m2 / (n - 1.0));
+    const double se = sqrt(block_sum_256(qb, red) / (n - 1.0));
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = se;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= G) return;
+    const double v = d1[i];
+    const int r = rs[i];
+    const int lbv = bound_2level(sorted_d, G, spl, nspl, v, true);
+    const int ubn = bound_2level(sorted_d, G, spl, nspl, -v, false);
+    int rank;
+    if (v > 0.0) {  // larger |w|: w > v or w < -v; ties: the negatives -v first, then equals of v in sorted order
+        const int ubv = bound_2level(sorted_d, G, spl, nspl, v, false);
+        rank = (G - ubv) + ubn + (r - lbv);
+    } else {        // larger |w|: w < v or w > -v
+        rank = lbv + (G - ubn) + (r - lbv);
+    }
+    ra[i] = rank;
     double p;
     if (se == 0.0) {
         p = 0.0;  // Normal(0,0): cdf/ccdf degenerate to a step, the smaller tail is 0
     } else {
-        const double z = fabs(d1[i]) / se;
+        const double z = fabs(v) / se;
         p = erfc(z * 0.70710678118654752440);
         p = p > 1.0 ? 1.0 : p;
     }
     pval[i] = p;
-    sorted_p[ra[i]] = p;
+    sorted_p[rank] = p;
 }
 
 // Benjamini-Hochberg step-up (:413), part 1: p_(r) * (n/r) and the reverse
@@ -1093,12 +1101,14 @@ int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int 
     double *res = c->result.p;
     const double *d1 = res + 11 * c->G;
     const int nchunk = (G + kSortChunk - 1) / kSortChunk;
+    const int nmerge = (nchunk * kSortChunk + kMergeThreads / kMergeLanes - 1) / (kMergeThreads / kMergeLanes);
+    k3_derive<<<nb, 256, 0, c->stream>>>(c->state.p, c->raw.p, c->refbytes[cur].p, G, nullptr, res, 1);
     k3_sort_chunks<<<nchunk, kSortThreads, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p);
-    k3_merge_rank<<<(nchunk * kSortChunk + kMergeThreads / kMergeLanes - 1) / (kMergeThreads / kMergeLanes), kMergeThreads, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
-                                                                   c->rank_s.p, c->sorted_d.p);
-    k3_abs_rank<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->sorted_d.p, G, static_cast<int>(a - 1),
-                                           static_cast<int>(b - 1), c->rank_a.p, c->part.p);
-    k3_pvals<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_a.p, c->part.p, nb, G, res, c->sorted_p.p, c->scal.p);
+    k3_merge_rank<<<nmerge, kMergeThreads, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
+                                                           static_cast<int>(a - 1), static_cast<int>(b - 1),
+                                                           c->rank_s.p, c->sorted_d.p, c->part.p);
+    k3_abs_rank<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->sorted_d.p, G, c->part.p, nmerge,
+                                           c->rank_a.p, res, c->sorted_p.p, c->scal.p);
     k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(c->state.p, c->sorted_p.p, G, c->blockmin.p);
     k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(c->state.p, res, c->sorted_p.p, c->blockmin.p, c->rank_a.p, G,
                                                     c->Gp, pval_deg, padj_deg, n_conv, res + c->G,

@@ -48,6 +48,10 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }  // locals are freed on every return path; context members with the context
     int32_t ensure(size_t count)
     {
         if (count <= n && p) return REO_OK;
