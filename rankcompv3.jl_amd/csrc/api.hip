@@ -128,7 +128,8 @@ static int32_t ensure_transform(reo_ctx *c)
         return REO_EINVAL;
     }
     if (c->transformed) return REO_OK;
-    c->Gp = static_cast<int>((c->G + kTileJ * kRJ - 1) / (kTileJ * kRJ)) * (kTileJ * kRJ);  // every lane's genes exist
+    constexpr int kPad = kTileJ * (kRJ > kRJTies ? kRJ : kRJTies);
+    c->Gp = static_cast<int>((c->G + kPad - 1) / kPad) * kPad;  // every lane's genes exist
     c->Wp = c->Gp / 32;
     return run_transform(c);
 }

@@ -282,7 +282,7 @@ __device__ __forceinline__ int side_state(int n, int size, int m) { return n >= 
 // MULTI = one-vs-rest with more than two groups (:375-390): the treat side is every other group,
 // counted group by group because the tie coins are keyed by group.
 template <int RI, int RJ, bool TIES, bool MULTI, bool LDSFEED>
-__global__ __launch_bounds__(256, LDSFEED ? 3 : (MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4 : 5))) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
+__global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : 3) : (MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4 : 5))) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
 {
     static_assert(RI == 32, "one mirror word per tile");
     const int lane = threadIdx.x & 63;
@@ -981,7 +981,7 @@ int32_t launch_k1(reo_ctx *c, int k)
 
     // work units: panel p = Q consecutive j-chunks, cut into i-ranges of kUnitH tiles.  Q keeps the
     // panel's pos slice (Q x 256 genes x S8 slots x 2 B) within about 2 MiB of the 4 MiB L2 of an XCD.
-    const int RJ = c->has_ties ? 1 : kRJ;  // genes j per lane
+    const int RJ = c->has_ties ? kRJTies : kRJ;  // genes j per lane
     const int CJ = kTileJ * RJ;
     const int NJ = (c->Gp + CJ - 1) / CJ, NIT = c->Gp / kTileI;
     const size_t chunk_bytes = static_cast<size_t>(CJ) * c->goff8[c->ngroups] * 2;
@@ -1032,10 +1032,10 @@ int32_t launch_k1(reo_ctx *c, int k)
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
     tic(c, 1);
     if (multi) {
-        if (c->has_ties) k1_pairs<kTileI, 1, true, true, false><<<grid, 256, 0, c->stream>>>(a);
+        if (c->has_ties) k1_pairs<kTileI, kRJTies, true, true, kLdsTies><<<grid, 256, 0, c->stream>>>(a);
         else k1_pairs<kTileI, kRJ, false, true, true><<<grid, 256, 0, c->stream>>>(a);
     } else {
-        if (c->has_ties) k1_pairs<kTileI, 1, true, false, false><<<grid, 256, 0, c->stream>>>(a);
+        if (c->has_ties) k1_pairs<kTileI, kRJTies, true, false, kLdsTies><<<grid, 256, 0, c->stream>>>(a);
         else k1_pairs<kTileI, kRJ, false, false, true><<<grid, 256, 0, c->stream>>>(a);
     }
     toc(c);

@@ -17,6 +17,8 @@ constexpr int kTileI = 32;    // gene rows per pair tile (one mirror word)
 constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kUnitH = 32;    // i-tiles per K1 work unit
 constexpr int kRJ = 2;        // genes j per lane in the tie-free pair kernel
+constexpr int kRJTies = 1;    // genes j per lane in the tie-rich pair kernel
+constexpr bool kLdsTies = true;  // tie-rich kernel: band edges through LDS (true) or the scalar cache (false)
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
 constexpr int kSortChunk = 1024; // genes per bitonic sort in the ranking stage
 

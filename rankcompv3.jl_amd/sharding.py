@@ -17,14 +17,15 @@ import numpy as np
 TILE_I = 32     # kTileI
 TILE_J = 256    # kTileJ
 RJ = 2          # kRJ (genes per lane in the tie-free kernel)
+RJ_TIES = 1     # kRJTies (genes per lane in the tie-rich kernel)
 UNIT_H = 32     # kUnitH
 
 
 def geometry(G: int, sample_slots: int, has_ties: bool):
     """(Gp, CJ, Q) exactly as launch_k1 derives them."""
-    cj_pad = TILE_J * RJ
+    cj_pad = TILE_J * max(RJ, RJ_TIES)
     Gp = (G + cj_pad - 1) // cj_pad * cj_pad
-    CJ = TILE_J * (1 if has_ties else RJ)
+    CJ = TILE_J * (RJ_TIES if has_ties else RJ)
     chunk_bytes = CJ * sample_slots * 2
     Q = 4 if chunk_bytes * 4 <= (2 << 20) else (2 if chunk_bytes * 2 <= (2 << 20) else 1)
     return Gp, CJ, Q

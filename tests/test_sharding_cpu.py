@@ -14,7 +14,7 @@ def test_python_mirror_constants_match_the_library_source(pkg):
     hdr = open(os.path.join(ROOT, "rankcompv3.jl_amd", "csrc", "reo_internal.h")).read()
     val = {k: int(v) for k, v in re.findall(r"constexpr int (k\w+) = (\d+);", hdr)}
     sh = pkg.sharding
-    assert (val["kTileI"], val["kTileJ"], val["kRJ"], val["kUnitH"]) == (sh.TILE_I, sh.TILE_J, sh.RJ, sh.UNIT_H)
+    assert (val["kTileI"], val["kTileJ"], val["kRJ"], val["kRJTies"], val["kUnitH"]) == (sh.TILE_I, sh.TILE_J, sh.RJ, sh.RJ_TIES, sh.UNIT_H)
 
 
 @pytest.mark.parametrize("G,slots,world", [(1400, 32, 2), (5000, 208, 2), (5000, 208, 8), (20000, 1008, 8), (900, 16, 3)])
