@@ -534,3 +534,42 @@ def test_maximum_gene_count_65535(pkg, oracle):
         assert np.array_equal(cont.sum(axis=1), ref0.sum() - ref0.astype(np.int64)) and cont.min() >= 0
         res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, 4, 5)
         assert 1 <= iters <= 4 and np.isfinite(res).all()
+
+
+@pytest.mark.parametrize("case", ["two_samples", "one_vs_nine", "empty_ref", "full_ref", "g11", "constant", "one_group_all_ties"])
+def test_edge_cases_against_oracle(pkg, oracle, case):
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    G, seed, n_iter, n_conv = 64, 5, 5, 1
+    X = rng.integers(0, 30, size=(G, 10))
+    group = ["a"] * 5 + ["b"] * 5
+    ref0 = pkg.synth.ref_mask(G, 20, seed)
+    if case == "two_samples":          # one sample per group: m(1) = 1 (the WARN branch)
+        X, group = X[:, :2], ["a", "b"]
+    elif case == "one_vs_nine":
+        group = ["a"] + ["b"] * 9
+    elif case == "empty_ref":          # no reference genes: every tally is 0, every N singular
+        ref0 = np.zeros(G, dtype=bool)
+    elif case == "full_ref":
+        ref0 = np.ones(G, dtype=bool)
+    elif case == "g11":                # smallest G the reference's slice (:411) accepts: round(Int, 0.5) = 0 for G = 10
+        X, ref0 = X[:11], np.ones(11, dtype=bool)
+        with pytest.raises(pkg.DimensionMismatch):
+            pkg.identify_degs(X[:10], group, list(range(10)), 0.01, 1.0, 0.05, np.ones(10, bool), 3, 1, device=0)
+        with pytest.raises(RuntimeError):
+            oracle.identify_degs(X[:10].astype(np.float64), pkg.encode_groups(group)[0], 2, 0.01, 1.0, 0.05, np.ones(10, bool), 3, 1, seed)
+    elif case == "constant":           # every pair tied in every sample: classes come from the coins alone
+        X = np.full((G, 10), 7)
+    elif case == "one_group_all_ties":
+        X = X.copy(); X[:, :5] = 3
+    Gx = X.shape[0]
+    gid, lev = pkg.encode_groups(group)
+    run = pkg.run_identify_degs(X, group, list(range(Gx)), 0.01, 1.0, 0.05, ref0, n_iter, n_conv, seed=seed, device=0)
+    exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, n_iter, n_conv, seed)
+    assert run.iters_run == iters and run.trace == trace, case
+    _check_result(run.result, exp)
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X)
+        ctx.set_groups(gid, 2)
+        gt, eq = ctx.pair_counts(0, Gx, 0, Gx)
+        egt, eeq = oracle.pair_counts(X.astype(np.float64), gid, 2, 0, Gx, 0, Gx)
+        assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), case
