@@ -164,11 +164,12 @@ int32_t reo_pseudobulk_csc_i64(reo_ctx *ctx, int64_t G, int64_t C, const int64_t
 
 /* Stage timers (HIP events on the library's stream), milliseconds, summed
  * since the last reo_reset_timings.  Index: 0 rank/band transform, 1 pair
- * kernel K1, 2 tally kernel K2 (sum), 3 iteration passes in total (K2 + the
+ * kernel K1, 2 tally stage K2 (full scan or incremental update, sum), 3 iteration passes in total (K2 + the
  * statistics kernels K3, sum), 4 number of K2 launches (passes enqueued after
  * convergence return at once and are counted too), 5 number of K1 launches,
- * 6 all-reduce hook wall time, 7 pseudo-bulk kernel. */
-enum { REO_NTIMINGS = 8 };
+ * 6 all-reduce hook wall time, 7 pseudo-bulk kernel, 8 K2 stage of the passes that scanned the whole table (sum), 9 their
+ * number, 10 K2 stage of the passes that updated the tallies incrementally (sum). */
+enum { REO_NTIMINGS = 12 };
 int32_t reo_set_profiling(reo_ctx *ctx, int32_t on);
 int32_t reo_reset_timings(reo_ctx *ctx);
 int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libreo_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 REO_OK, REO_EINVAL, REO_EHIP, REO_ECOMM, REO_ENOMEM = 0, -1, -2, -3, -4
-NTIMINGS = 8
+NTIMINGS = 12
 
 # every symbol include/reo_hip.h declares
 SYMBOLS = [
@@ -300,7 +300,8 @@ class Context:
         ms = np.zeros(NTIMINGS, dtype=np.float64)
         check(self._L.reo_get_timings(self._h, _ptr(ms), NTIMINGS))
         return {"transform_ms": ms[0], "k1_ms": ms[1], "k2_ms": ms[2], "iter_ms": ms[3], "k3_ms": max(ms[3] - ms[2], 0.0), "k2_launches": int(ms[4]),
-                "k1_launches": int(ms[5]), "allreduce_ms": ms[6], "pseudobulk_ms": ms[7]}
+                "k1_launches": int(ms[5]), "allreduce_ms": ms[6], "pseudobulk_ms": ms[7], "k2_full_ms": ms[8],
+                "k2_full_launches": int(ms[9]), "k2_delta_ms": ms[10]}
 
     def info(self) -> dict:
         v = np.zeros(12, dtype=np.int64)

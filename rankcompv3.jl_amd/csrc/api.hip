@@ -46,11 +46,22 @@ void collect_timings(reo_ctx *c)
     for (auto &pr : c->pending) {
         float ms = 0.f;
         (void)hipEventSynchronize(pr.second.b);
-        if (hipEventElapsedTime(&ms, pr.second.a, pr.second.b) == hipSuccess) c->t_ms[pr.first] += ms;
+        if (hipEventElapsedTime(&ms, pr.second.a, pr.second.b) == hipSuccess) {
+            c->t_ms[pr.first] += ms;
+            if (pr.first == 2 && !c->k2_modes.empty()) {  // split the K2 stage time by what the pass did on the device
+                if (c->k2_seen < c->k2_modes.size()) {
+                    if (c->k2_modes[c->k2_seen]) { c->t_ms[8] += ms; c->t_ms[9] += 1.0; }
+                    else c->t_ms[10] += ms;
+                }
+                ++c->k2_seen;
+            }
+        }
         c->pool.push_back(pr.second);
     }
     c->pending.clear();
     c->open.clear();
+    c->k2_modes.clear();
+    c->k2_seen = 0;
 }
 
 // get_major_reo_lower_count, src/RankCompV3.jl:81-92, with
@@ -142,7 +153,8 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         if ((rc = c->refbits[t].ensure(c->Wp))) return rc;
         if ((rc = c->refbytes[t].ensure(c->Gp))) return rc;
     }
-    if ((rc = c->raw.ensure(G * kRaw)) || (rc = c->cont.ensure(G * 9)) || (rc = c->result.ensure(G * 15)) ||
+    if ((rc = c->raw.ensure(G * kRaw)) || (rc = c->raw_local.ensure(c->world > 1 ? G * kRaw : 1)) ||
+        (rc = c->delta_list.ensure(2 * static_cast<size_t>(c->Gp))) || (rc = c->cont.ensure(G * 9)) || (rc = c->result.ensure(G * 15)) ||
         (rc = c->sorted_d.ensure(G)) || (rc = c->sorted_p.ensure(G)) || (rc = c->rank_s.ensure(G)) ||
         (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(64)) ||
         (rc = c->state.ensure(1)) ||
@@ -168,6 +180,7 @@ static int32_t init_state(reo_ctx *c, int32_t nref)
     IterState st;
     memset(&st, 0, sizeof st);
     st.nref = nref;
+    st.delta_cnt[0] = st.delta_cnt[1] = 0x7FFFFFFF;  // the first pass counts from scratch
     *c->host_state = st;
     REO_HIP_CHECK(hipMemcpyAsync(c->state.p, c->host_state, sizeof st, hipMemcpyHostToDevice, c->stream));
     return REO_OK;
@@ -234,9 +247,9 @@ void reo_destroy(reo_ctx *c)
     c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
     c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release(); c->own_mask.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
-    c->raw.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
+    c->raw.release(); c->raw_local.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
+    c->state.release(); c->trace.release(); c->modes.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -398,7 +411,7 @@ int32_t reo_tally(reo_ctx *c, const uint8_t *ref_mask, int32_t *cont)
     int32_t nref = 0;
     if ((rc = upload_ref(c, ref_mask, 0, &nref))) return rc;
     if ((rc = init_state(c, nref))) return rc;
-    if ((rc = launch_k2(c, c->refbits[0].p))) return rc;
+    if ((rc = launch_k2(c, c->refbits[0].p, 0, false))) return rc;
     if ((rc = allreduce_raw(c))) return rc;
     if ((rc = launch_derive(c, c->refbytes[0].p, 0))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(cont, c->cont.p, sizeof(int32_t) * 9 * c->G, hipMemcpyDeviceToHost, c->stream));
@@ -428,6 +441,8 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     if ((rc = upload_ref(c, ref0, 0, &nref))) return rc;
     if ((rc = init_state(c, nref))) return rc;
     if ((rc = c->trace.ensure(2 * static_cast<size_t>(n_iter > 0 ? n_iter : 1)))) return rc;
+    if ((rc = c->modes.ensure(static_cast<size_t>(n_iter > 0 ? n_iter : 1)))) return rc;
+    collect_timings(c);  // flush timers of earlier calls: the K2 timers below are matched to passes by order
     REO_HIP_CHECK(hipMemsetAsync(c->result.p, 0, sizeof(double) * 15 * G, c->stream));  // zeros(r,15), :398
     // The loop control of :400,418-424 lives in device memory (IterState): passes are
     // enqueued in batches and every kernel of a pass returns at once after convergence,
@@ -442,7 +457,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         tic(c, 3);
         for (int t = enq; t < enq + nb; ++t) {
             const int cur = t & 1;  // pass t reads mask buffer t&1 and writes the other (ref_gene_vec = inds, :424)
-            if ((rc = launch_k2(c, c->refbits[cur].p))) return rc;
+            if ((rc = launch_k2(c, c->refbits[cur].p, cur, true))) return rc;
             if ((rc = allreduce_raw(c))) return rc;
             if ((rc = launch_stats(c, cur, pval_deg, padj_deg, n_conv, a, b))) return rc;
         }
@@ -455,6 +470,10 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     }
     if (trace && passes > 0)
         REO_HIP_CHECK(hipMemcpyAsync(trace, c->trace.p, sizeof(int32_t) * 2 * passes, hipMemcpyDeviceToHost, c->stream));
+    if (c->profiling && passes > 0) {
+        c->k2_modes.assign(passes, 0);
+        REO_HIP_CHECK(hipMemcpyAsync(c->k2_modes.data(), c->modes.p, sizeof(int32_t) * passes, hipMemcpyDeviceToHost, c->stream));
+    }
     if (iters_run) *iters_run = passes;
     REO_HIP_CHECK(hipMemcpyAsync(result, c->result.p, sizeof(double) * 15 * G, hipMemcpyDeviceToHost, c->stream));
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));

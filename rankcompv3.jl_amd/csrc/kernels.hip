@@ -519,9 +519,12 @@ __device__ __forceinline__ void tally_word(uint32_t cl, uint32_t ch, uint32_t tl
 __global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st, const uint4 *__restrict__ table,
                                                 const uint4 *__restrict__ refbits, int G, int Wq,
                                                 const uint32_t *__restrict__ own, int own_words,
-                                                int32_t *__restrict__ raw)
+                                                int32_t *__restrict__ raw, int slot, int32_t *__restrict__ modes)
 {
     if (st->done) return;
+    const bool full = !(slot >= 0 && st->delta_cnt[slot] <= kDeltaMax);
+    if (modes && blockIdx.x == 0 && threadIdx.x == 0) modes[st->passes] = full ? 1 : 0;  // for the stage timers
+    if (!full) return;  // k2_delta updates the counters instead
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= G) return;
@@ -549,6 +552,39 @@ __global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st
         o[0] = make_int4(c[0], c[1], c[2], c[3]);
         o[1] = make_int4(c[4], c[5], c[6], c[7]);
     }
+}
+
+// Incremental form of K2.  From one pass to the next the reference set usually changes by a handful
+// of genes (the k3_finalize of the previous pass lists them).  The counters are linear in the mask, and
+// by the mirror rule (:386) column j of the table is row j with L and H swapped, so gene j entering
+// (leaving) the reference set adds (removes), for every gene i, the class bits found at bit i of ROW j:
+// one contiguous row per changed gene instead of the whole table.  Exact (integer sums).
+__global__ __launch_bounds__(256) void k2_delta(const IterState *__restrict__ st, const uint32_t *__restrict__ table,
+                                                int G, int Wp, const uint32_t *__restrict__ list, int slot,
+                                                int32_t *__restrict__ raw)
+{
+    if (st->done) return;
+    const int n = st->delta_cnt[slot];
+    if (n > kDeltaMax) return;  // k2_tally recounts from scratch
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G) return;
+    const int w = i >> 5, sh = i & 31;
+    int d[kRaw] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = 0; e < n; ++e) {
+        const uint32_t ent = list[e];  // wave-uniform
+        const uint32_t *row = table + static_cast<size_t>(ent >> 1) * kPlanes * Wp + w;
+        const int sgn = (ent & 1u) ? 1 : -1;
+        // pair (i, j) seen from gene i: cL(i,j) = cH(j,i), cH(i,j) = cL(j,i), likewise for the treat side
+        const int cl = (row[Wp] >> sh) & 1, ch = (row[0] >> sh) & 1;
+        const int tl = (row[3 * Wp] >> sh) & 1, th = (row[2 * Wp] >> sh) & 1;
+        d[0] += sgn * cl; d[1] += sgn * ch; d[2] += sgn * tl; d[3] += sgn * th;
+        d[4] += sgn * (cl & tl); d[5] += sgn * (cl & th); d[6] += sgn * (ch & tl); d[7] += sgn * (ch & th);
+    }
+    int4 *o = reinterpret_cast<int4 *>(raw + static_cast<size_t>(i) * kRaw);
+    int4 a = o[0], b = o[1];
+    a.x += d[0]; a.y += d[1]; a.z += d[2]; a.w += d[3];
+    b.x += d[4]; b.y += d[5]; b.z += d[6]; b.w += d[7];
+    o[0] = a; o[1] = b;
 }
 
 // ---------------------------------------------------------------------------
@@ -632,10 +668,11 @@ __device__ __forceinline__ double derive_gene(const int32_t *__restrict__ raw, c
 __global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ st, const int32_t *__restrict__ raw,
                                                  const uint8_t *__restrict__ refbytes, int G,
                                                  int32_t *__restrict__ cont, double *__restrict__ result,
-                                                 int with_stats)
+                                                 int with_stats, IterState *__restrict__ stw, int slot_next)
 {
     if (st->done) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && stw) stw->delta_cnt[slot_next] = 0;  // k3_finalize of this pass fills that list
     if (i >= G) return;
     derive_gene(raw, refbytes, st->nref, G, i, cont, result, with_stats != 0);
 }
@@ -904,7 +941,9 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
                                                    const uint32_t *__restrict__ ra, int G, int Gp,
                                                    double pval_deg, double padj_deg, int n_conv,
                                                    double *__restrict__ padj, uint8_t *__restrict__ nbytes,
-                                                   uint32_t *__restrict__ nbits, int32_t *__restrict__ trace)
+                                                   uint32_t *__restrict__ nbits, int32_t *__restrict__ trace,
+                                                   const uint8_t *__restrict__ obytes, uint32_t *__restrict__ dlist,
+                                                   int slot_next)
 {
     if (st->done) return;
     __shared__ double tail[65];
@@ -930,6 +969,16 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
         ind = !(pval[i] <= pval_deg && q <= padj_deg);
     }
     if (i < Gp) nbytes[i] = ind ? 1 : 0;
+    // genes whose mask bit changes: the next pass can update its tallies from their rows alone (k2_delta)
+    const bool changed = i < G && ind != (obytes[i] != 0);
+    const unsigned long long cm = __ballot(changed);
+    if (cm) {
+        int basepos = 0;
+        if ((threadIdx.x & 63) == 0) basepos = atomicAdd(&st->delta_cnt[slot_next], __popcll(cm));
+        basepos = __shfl(basepos, 0, 64);
+        const int at = basepos + __popcll(cm & ((1ULL << (threadIdx.x & 63)) - 1ULL));
+        if (changed && at < kDeltaMax) dlist[at] = (static_cast<uint32_t>(i) << 1) | (ind ? 1u : 0u);
+    }
     const unsigned long long m = __ballot(ind);
     if ((threadIdx.x & 63) == 0 && i < Gp) {
         nbits[i >> 5] = static_cast<uint32_t>(m);
@@ -1072,16 +1121,23 @@ int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits)
     return REO_OK;
 }
 
-int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits)
+int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits, int slot, bool allow_delta)
 {
     const int G = static_cast<int>(c->G);
+    int32_t *raw = c->world > 1 ? c->raw_local.p : c->raw.p;  // shards keep their own counters, the sum goes to raw
     tic(c, 2);
+    if (allow_delta)
+        k2_delta<<<(G + 255) / 256, 256, 0, c->stream>>>(c->state.p, c->table.p, G, c->Wp,
+                                                         c->delta_list.p + static_cast<size_t>(slot) * c->Gp, slot, raw);
     k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(c->state.p, reinterpret_cast<const uint4 *>(c->table.p),
                                                  reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp / 4,
-                                                 c->world > 1 ? c->own_mask.p : nullptr, c->own_words, c->raw.p);
+                                                 c->world > 1 ? c->own_mask.p : nullptr, c->own_words, raw,
+                                                 allow_delta ? slot : -1, allow_delta ? c->modes.p : nullptr);
     toc(c);
     c->t_ms[4] += 1.0;
     REO_HIP_CHECK(hipGetLastError());
+    if (c->world > 1)
+        REO_HIP_CHECK(hipMemcpyAsync(c->raw.p, c->raw_local.p, sizeof(int32_t) * kRaw * c->G, hipMemcpyDeviceToDevice, c->stream));
     return REO_OK;
 }
 
@@ -1089,7 +1145,7 @@ int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int with_stats)
 {
     const int G = static_cast<int>(c->G);
     k3_derive<<<(G + 255) / 256, 256, 0, c->stream>>>(c->state.p, c->raw.p, d_refbytes, G, c->cont.p, c->result.p,
-                                                      with_stats);
+                                                      with_stats, nullptr, 0);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -1102,7 +1158,7 @@ int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int 
     const double *d1 = res + 11 * c->G;
     const int nchunk = (G + kSortChunk - 1) / kSortChunk;
     const int nmerge = (nchunk * kSortChunk + kMergeThreads / kMergeLanes - 1) / (kMergeThreads / kMergeLanes);
-    k3_derive<<<nb, 256, 0, c->stream>>>(c->state.p, c->raw.p, c->refbytes[cur].p, G, nullptr, res, 1);
+    k3_derive<<<nb, 256, 0, c->stream>>>(c->state.p, c->raw.p, c->refbytes[cur].p, G, nullptr, res, 1, c->state.p, 1 - cur);
     k3_sort_chunks<<<nchunk, kSortThreads, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p);
     k3_merge_rank<<<nmerge, kMergeThreads, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
                                                            static_cast<int>(a - 1), static_cast<int>(b - 1),
@@ -1112,7 +1168,9 @@ int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int 
     k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(c->state.p, c->sorted_p.p, G, c->blockmin.p);
     k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(c->state.p, res, c->sorted_p.p, c->blockmin.p, c->rank_a.p, G,
                                                     c->Gp, pval_deg, padj_deg, n_conv, res + c->G,
-                                                    c->refbytes[1 - cur].p, c->refbits[1 - cur].p, c->trace.p);
+                                                    c->refbytes[1 - cur].p, c->refbits[1 - cur].p, c->trace.p,
+                                                    c->refbytes[cur].p,
+                                                    c->delta_list.p + static_cast<size_t>(1 - cur) * c->Gp, 1 - cur);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

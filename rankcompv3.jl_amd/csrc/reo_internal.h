@@ -20,6 +20,7 @@ constexpr int kRJ = 2;        // genes j per lane in the tie-free pair kernel
 constexpr int kRJTies = 1;    // genes j per lane in the tie-rich pair kernel
 constexpr bool kLdsTies = true;  // tie-rich kernel: band edges through LDS (true) or the scalar cache (false)
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
+constexpr int kDeltaMax = 384;   // at most this many changed reference genes: update the tallies incrementally
 constexpr int kSortChunk = 1024; // genes per bitonic sort in the ranking stage
 
 // Device-resident loop state of the iteration driver (src/RankCompV3.jl:396-425),
@@ -31,7 +32,7 @@ struct IterState {
     int32_t i_iter;   // :397,423
     int32_t ticket;   // finished workgroups of k3_finalize
     int32_t nn_acc;   // running sum(inds)
-    int32_t pad[2];
+    int32_t delta_cnt[2];  // genes whose mask bit changes for the pass of that parity (see k2_delta)
 };
 
 void set_error(const char *fmt, ...);
@@ -122,7 +123,9 @@ struct reo_ctx {
     // iteration state
     reo::DevBuf<uint32_t> refbits[2];   // [Wp]
     reo::DevBuf<uint8_t> refbytes[2];   // [Gp]
-    reo::DevBuf<int32_t> raw;           // [G][8]
+    reo::DevBuf<int32_t> raw;           // [G][8] (summed over shards when world > 1)
+    reo::DevBuf<int32_t> raw_local;     // [G][8] this shard's own counters (world > 1 only)
+    reo::DevBuf<uint32_t> delta_list;   // [2][Gp] changed genes (gene << 1 | added) per pass parity
     reo::DevBuf<int32_t> cont;          // [G][9]
     reo::DevBuf<double> result;         // [15][G]
     reo::DevBuf<double> sorted_d;       // [G]
@@ -135,6 +138,7 @@ struct reo_ctx {
     reo::DevBuf<double> part;           // [<= 256][3] slice moments per block
     reo::DevBuf<reo::IterState> state;  // [1]
     reo::DevBuf<int32_t> trace;         // [n_iter][2]
+    reo::DevBuf<int32_t> modes;         // [n_iter] 1 = the pass scanned the whole table in K2, 0 = incremental update
     reo::IterState *host_state = nullptr;  // pinned
 
     // timing
@@ -143,6 +147,8 @@ struct reo_ctx {
     std::vector<std::pair<int, reo::StageTimer>> pending;  // (slot, events)
     std::vector<reo::StageTimer> pool;
     std::vector<size_t> open;  // indices into pending of timers not yet closed (tic/toc nest)
+    std::vector<int32_t> k2_modes;  // per pass of the last identify_degs call: 1 = full table scan in K2
+    size_t k2_seen = 0;
 };
 
 namespace reo {
@@ -155,7 +161,7 @@ int32_t launch_k1(reo_ctx *c, int k);
 int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq);
 int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
-int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits);
+int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits, int slot, bool allow_delta);
 int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int with_stats);
 int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int n_conv, int64_t a, int64_t b);
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
