@@ -20,7 +20,7 @@ constexpr int kRJ = 2;        // genes j per lane in the tie-free pair kernel
 constexpr int kRJTies = 1;    // genes j per lane in the tie-rich pair kernel
 constexpr bool kLdsTies = true;  // tie-rich kernel: band edges through LDS (true) or the scalar cache (false)
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
-constexpr int kDeltaMax = 384;   // at most this many changed reference genes: update the tallies incrementally
+constexpr int kDeltaMax = 128;   // at most this many changed reference genes: update the tallies incrementally
 constexpr int kSortChunk = 1024; // genes per bitonic sort in the ranking stage
 
 // Device-resident loop state of the iteration driver (src/RankCompV3.jl:396-425),
