@@ -3,14 +3,16 @@
 //   K1  k1_pairs    pair compare -> per-group counts -> stable-REO class ->
 //                   4 bit planes per ordered pair      (src/RankCompV3.jl:363-392)
 //   K2  k2_tally    class table x reference mask -> per-gene tallies   (:403)
-//   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask (:404-417,225-259)
+//       k2_delta    the same as an incremental update from the rows of the genes whose mask bit changed
+//   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask, loop control (:404-425,225-259)
 //
 // All file:line citations are relative to /root/reference.
 //
 // Data layout in HBM
 //   pos  u16 [S8/8][Gp][8]  position of gene g in its sample's sorted order, 8 sample slots per
 //                   16 bytes (lane operand; groups padded to multiples of 8 slots with 0xFFFF)
-//   lo   f32 [S8][Gp]  first position of g's tie band   (wave-uniform operand -> s_load)
+//   lo   f32 [S8][Gp]  first position of g's tie band   (wave-uniform operand: staged through LDS,
+//                   or s_load in the scalar-fed variant)
 //   hi   f32 [S8][Gp]  one past the last position of g's tie band (both exact integers < 2^16)
 //   table u32 [G][4][Wp]  bit planes cL cH tL tH of row i: bit j of plane cL is
 //                   set iff pair (i,j) is "i<j stable" in ctrl (ic==1), cH iff
@@ -52,16 +54,15 @@ __device__ uint32_t tie_wins(uint64_t seed, uint32_t i, uint32_t j, uint32_t g, 
 }
 
 // ---------------------------------------------------------------------------
-// K1 inner loop.  Lane = gene j, the RI genes i of the tile are wave-uniform:
-// their band edges arrive through the scalar cache (s_load) as floats.  All
-// values are integers below 2^16, exact in fp32, so
+// K1 inner loop.  Lane = gene j, the RI genes i of the tile are wave-uniform.
+// All values are integers below 2^16, exact in fp32, so
 //     [pos_j < lo_i] = clamp(lo_i - pos_j, 0, 1)
-// is ONE v_sub_f32 with the clamp output modifier, and the count is one
-// v_add_f32: two full-rate VALU ops per (pair, sample) without ties, four with.
-// Measured on MI355X (tools/microbench_cmp*.hip): this pair issues in 2.04 ns
-// per 64 comparisons per SIMD, against 3.50 ns for v_cmp + v_addc (every VALU op
-// that writes or reads a lane mask in SGPRs issues at half rate) and 3.8 ns for
-// v_cmp + s_bcnt1 + s_add (the ballot/popcount form).
+// is one subtraction with the clamp output modifier and the count is one add;
+// both are issued packed (v_pk_add_f32: two band edges per instruction).
+// Measured on MI355X (tools/microbench_cmp*.hip), ns per 64 comparisons per SIMD:
+// v_pk_add_f32 clamp + v_pk_add_f32 1.80, v_sub_f32 clamp + v_add_f32 2.09,
+// v_cmp + v_addc 3.50 (every VALU op that writes or reads a lane mask in SGPRs
+// issues at half rate), v_cmp + s_bcnt1 + s_add (the ballot/popcount form) 3.81.
 // n_gt(i,j) = #{s : pos_j < lo_i},  n_ge(i,j) = #{s : pos_j < hi_i}.
 // The lane operand comes 8 samples at a time (one coalesced 16-byte load per
 // lane, 1 KiB per wave) and the next group is fetched while this one is used.
