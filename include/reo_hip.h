@@ -179,7 +179,10 @@ int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);
  * 3 class-table bytes, 4 data-has-ties flag, 5 pair tiles owned by this
  * shard, 6 pair tiles total, 7 gene rows per pair tile, 8 gene columns per
  * workgroup, 9 column chunks per panel, 10 tiles per work-unit column,
- * 11 padded sample slots. */
+ * 11 padded sample slots, 12 the last class table came from the shared
+ * per-group counts (more than two groups: the one-vs-rest comparisons count
+ * every group once and keep the counts in HBM; REO_SHARE_GROUP_COUNTS=0 in the
+ * environment recounts per comparison), 13 bytes held by those counts. */
 int32_t reo_get_info(reo_ctx *ctx, int64_t *info, int32_t n);
 
 #ifdef __cplusplus

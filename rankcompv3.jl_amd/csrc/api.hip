@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "reo_internal.h"
@@ -102,6 +103,7 @@ static void invalidate(reo_ctx *c)
 {
     c->transformed = false;
     c->built_k = -1;
+    c->gc_valid = false;
 }
 
 static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64_t ld, int dtype, bool on_device)
@@ -229,6 +231,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (!c) { set_error("out of host memory"); return REO_ENOMEM; }
     c->device = device;
     c->seed = seed;
+    if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return REO_EHIP; }
     *out = c;
@@ -261,6 +264,7 @@ int32_t reo_set_shard(reo_ctx *c, int32_t rank, int32_t world)
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad shard %d of %d", rank, world); return REO_EINVAL; }
     c->rank = rank; c->world = world;
     c->built_k = -1;
+    c->gc_valid = false;
     return REO_OK;
 }
 
@@ -528,10 +532,11 @@ int32_t reo_get_timings(reo_ctx *c, double *ms, int32_t n)
 int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
 {
     if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
-    const int64_t v[12] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
+    const int64_t v[14] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
                            c->tiles_owned, c->tiles_total, kTileI, c->k1_cj, c->k1_q, kUnitH,
-                           c->goff8.empty() ? 0 : c->goff8.back()};
-    for (int i = 0; i < n && i < 12; ++i) info[i] = v[i];
+                           c->goff8.empty() ? 0 : c->goff8.back(), c->last_k1_shared,
+                           static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t))};
+    for (int i = 0; i < n && i < 14; ++i) info[i] = v[i];
     return REO_OK;
 }
 

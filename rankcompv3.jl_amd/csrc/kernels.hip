@@ -280,6 +280,67 @@ struct K1Args {
 // state of one side: 0 = "i<j stable" (reference 1), 1 = unstable (2), 2 = "i>j stable" (3)  (:376-377)
 __device__ __forceinline__ int side_state(int n, int size, int m) { return n >= m ? 2 : ((size - n) >= m ? 0 : 1); }
 
+// Tile epilogue: the lane holds, for each of its RJ genes j, four 32-bit words (bit ii = pair (i0+ii, j)):
+// control-side L/H and treat-side L/H.  Writes the forward words of rows i0..i0+31 (ballot over the
+// lanes) and the mirror words of rows j.
+template <int RI, int RJ>
+__device__ __forceinline__ void emit_tile(const K1Args &a, int i0, int j0, int bi, int lane, const uint32_t (&cL)[RJ],
+                                          const uint32_t (&cH)[RJ], const uint32_t (&tL)[RJ], const uint32_t (&tH)[RJ])
+{
+#pragma unroll
+    for (int r = 0; r < RJ; ++r) {
+        const int j = j0 + 256 * r;
+        const int bj = j >> 6;  // wave-uniform
+        if (j >= a.Gp || bj < bi) continue;
+        // only pairs i < j < G are real; everything else contributes zero bits
+        uint32_t vm = 0;
+        if (j < a.G) {
+            const int d = j - i0;  // rows i0+ii with ii < d are above the diagonal
+            vm = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1u));
+        }
+        const uint32_t wcL = cL[r] & vm, wcH = cH[r] & vm, wtL = tL[r] & vm, wtH = tH[r] & vm;
+        const bool diag = (bj == bi);
+        // forward bits: row i, 64-bit word of columns [64*bj, 64*bj+64) = ballot over the lanes
+        unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+#pragma unroll
+        for (int ii = 0; ii < RI; ++ii) {
+            const unsigned long long b0 = __ballot((wcL >> ii) & 1u);
+            const unsigned long long b1 = __ballot((wcH >> ii) & 1u);
+            const unsigned long long b2 = __ballot((wtL >> ii) & 1u);
+            const unsigned long long b3 = __ballot((wtH >> ii) & 1u);
+            if (lane == ii) { f0 = b0; f1 = b1; f2 = b2; f3 = b3; }
+        }
+        if (lane < RI && i0 + lane < a.G) {
+            uint32_t *row = a.table + static_cast<size_t>(i0 + lane) * kPlanes * a.Wp + 2 * bj;
+            if (!diag) {
+                *reinterpret_cast<unsigned long long *>(row) = f0;
+                *reinterpret_cast<unsigned long long *>(row + a.Wp) = f1;
+                *reinterpret_cast<unsigned long long *>(row + 2 * a.Wp) = f2;
+                *reinterpret_cast<unsigned long long *>(row + 3 * a.Wp) = f3;
+            } else {
+                const unsigned long long f[4] = {f0, f1, f2, f3};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (static_cast<uint32_t>(f[p])) atomicOr(row + p * a.Wp, static_cast<uint32_t>(f[p]));
+                    if (static_cast<uint32_t>(f[p] >> 32)) atomicOr(row + p * a.Wp + 1, static_cast<uint32_t>(f[p] >> 32));
+                }
+            }
+        }
+        // mirror bits (:386): pair (j,i) is in state 2 - state(i,j) on both sides -> L and H swap
+        if (j < a.G) {
+            uint32_t *row = a.table + static_cast<size_t>(j) * kPlanes * a.Wp + (i0 >> 5);
+            if (!diag) {
+                row[0] = wcH; row[a.Wp] = wcL; row[2 * a.Wp] = wtH; row[3 * a.Wp] = wtL;
+            } else {
+                if (wcH) atomicOr(row, wcH);
+                if (wcL) atomicOr(row + a.Wp, wcL);
+                if (wtH) atomicOr(row + 2 * a.Wp, wtH);
+                if (wtL) atomicOr(row + 3 * a.Wp, wtL);
+            }
+        }
+    }
+}
+
 // MULTI = one-vs-rest with more than two groups (:375-390): the treat side is every other group,
 // counted group by group because the tie coins are keyed by group.
 template <int RI, int RJ, bool TIES, bool MULTI, bool LDSFEED>
@@ -390,58 +451,125 @@ __global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : 3) : (MULTI 
         }
     }
 
+    emit_tile<RI, RJ>(a, i0, j0, bi, lane, cL, cH, tL, tH);
+}
+
+// ---------------------------------------------------------------------------
+// One-vs-rest with C > 2 groups (:375-390,396-436): the C comparisons need the same per-group counts
+// nre_g(i,j) (tie coins are keyed by group, not by comparison), so they are counted once, kept in
+// HBM, and each comparison only classifies:  c-side = nre_k,  t-side = sum_g nre_g - nre_k  (:374).
+// Layout: plane g (g = C holds the sum) = [Gp/32 i-tiles][4 quarters][Gp genes j][8] u16, element
+// (it, q, j, e) = pair (32 it + 8 q + e, j): one 16-byte load or store per lane, coalesced over j.
+__device__ __forceinline__ size_t gc_index(int it, int q, int j, int Gp) { return (static_cast<size_t>(it * 4 + q) * Gp + j) * 8; }
+
+// block -> tile mapping shared by k1_pairs, k1_group_counts and k1_classify
+template <int RI, int RJ>
+__device__ __forceinline__ bool tile_of_block(const K1Args &a, int &i0, int &jc)
+{
+    const int slot = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int bu = kUnitH * a.Q;
+    const int u = (q / bu) * 8 + slot;
+    if (u >= a.n_units) return false;
+    const uint32_t um = a.unit_map[u];
+    const int wq = q % bu;
+    const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + wq / a.Q;
+    jc = static_cast<int>(um >> 16) * a.Q + wq % a.Q;
+    i0 = it * RI;
+    constexpr int CJ = kTileJ * RJ;
+    if (i0 >= a.Gp || jc * CJ >= a.Gp) return false;
+    return ((jc * CJ + CJ - 1) >> 6) >= (i0 >> 6);  // whole workgroups only: barriers inside
+}
+
+template <int RI, int RJ, bool TIES, bool LDSFEED>
+__global__ __launch_bounds__(256, (TIES && RJ > 1) ? 2 : 3) void k1_group_counts(K1Args a, uint16_t *__restrict__ planes, size_t plane_elems)
+{
+    static_assert(RI == 32, "four quarters of 8 rows per tile");
+    int i0, jc;
+    if (!tile_of_block<RI, RJ>(a, i0, jc)) return;
+    const int j0 = jc * (kTileJ * RJ) + threadIdx.x;
+    __shared__ float4v sm_lo[LDSFEED ? 2 * kStage * 8 : 1];
+    __shared__ float4v sm_hi[(LDSFEED && TIES) ? 2 * kStage * 8 : 1];
+    float2v gt[RJ][RI / 2], ge[RJ][RI / 2];
+    uint32_t tot[RJ][RI / 2];  // two u16 sums per register (sums are at most S < 65536)
 #pragma unroll
-    for (int r = 0; r < RJ; ++r) {
-        const int j = j0 + 256 * r;
-        const int bj = j >> 6;  // wave-uniform
-        if (j >= a.Gp || bj < bi) continue;
-        // only pairs i < j < G are real; everything else contributes zero bits
-        uint32_t vm = 0;
-        if (j < a.G) {
-            const int d = j - i0;  // rows i0+ii with ii < d are above the diagonal
-            vm = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1u));
-        }
-        const uint32_t wcL = cL[r] & vm, wcH = cH[r] & vm, wtL = tL[r] & vm, wtH = tH[r] & vm;
-        const bool diag = (bj == bi);
-        // forward bits: row i, 64-bit word of columns [64*bj, 64*bj+64) = ballot over the lanes
-        unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+    for (int r = 0; r < RJ; ++r)
 #pragma unroll
-        for (int ii = 0; ii < RI; ++ii) {
-            const unsigned long long b0 = __ballot((wcL >> ii) & 1u);
-            const unsigned long long b1 = __ballot((wcH >> ii) & 1u);
-            const unsigned long long b2 = __ballot((wtL >> ii) & 1u);
-            const unsigned long long b3 = __ballot((wtH >> ii) & 1u);
-            if (lane == ii) { f0 = b0; f1 = b1; f2 = b2; f3 = b3; }
-        }
-        if (lane < RI && i0 + lane < a.G) {
-            uint32_t *row = a.table + static_cast<size_t>(i0 + lane) * kPlanes * a.Wp + 2 * bj;
-            if (!diag) {
-                *reinterpret_cast<unsigned long long *>(row) = f0;
-                *reinterpret_cast<unsigned long long *>(row + a.Wp) = f1;
-                *reinterpret_cast<unsigned long long *>(row + 2 * a.Wp) = f2;
-                *reinterpret_cast<unsigned long long *>(row + 3 * a.Wp) = f3;
-            } else {
-                const unsigned long long f[4] = {f0, f1, f2, f3};
+        for (int h = 0; h < RI / 2; ++h) tot[r][h] = 0;
+    const int it = i0 / RI;
+    for (int g = 0; g < a.ngroups; ++g) {
+        if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi);
+        else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge);
+        uint16_t *plane = planes + static_cast<size_t>(g) * plane_elems;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if (static_cast<uint32_t>(f[p])) atomicOr(row + p * a.Wp, static_cast<uint32_t>(f[p]));
-                    if (static_cast<uint32_t>(f[p] >> 32)) atomicOr(row + p * a.Wp + 1, static_cast<uint32_t>(f[p] >> 32));
+        for (int r = 0; r < RJ; ++r) {
+            const int j = j0 + 256 * r;
+            uint32_t pk[RI / 2];
+#pragma unroll
+            for (int h = 0; h < RI / 2; ++h) {
+                uint32_t n0 = static_cast<uint32_t>(gt[r][h].x), n1 = static_cast<uint32_t>(gt[r][h].y);
+                if (TIES) {
+                    const uint32_t e0 = static_cast<uint32_t>(ge[r][h].x - gt[r][h].x), e1 = static_cast<uint32_t>(ge[r][h].y - gt[r][h].y);
+                    if (e0) n0 += tie_wins(a.seed, i0 + 2 * h, j, g, e0);
+                    if (e1) n1 += tie_wins(a.seed, i0 + 2 * h + 1, j, g, e1);
                 }
+                pk[h] = n0 | (n1 << 16);
+                tot[r][h] += pk[h];  // no carry between the halves: each half-sum stays below 2^16
             }
-        }
-        // mirror bits (:386): pair (j,i) is in state 2 - state(i,j) on both sides -> L and H swap
-        if (j < a.G) {
-            uint32_t *row = a.table + static_cast<size_t>(j) * kPlanes * a.Wp + (i0 >> 5);
-            if (!diag) {
-                row[0] = wcH; row[a.Wp] = wcL; row[2 * a.Wp] = wtH; row[3 * a.Wp] = wtL;
-            } else {
-                if (wcH) atomicOr(row, wcH);
-                if (wcL) atomicOr(row + a.Wp, wcL);
-                if (wtH) atomicOr(row + 2 * a.Wp, wtH);
-                if (wtL) atomicOr(row + 3 * a.Wp, wtL);
+            if (j < a.Gp) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<uint4 *>(plane + gc_index(it, q, j, a.Gp)) = uint4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
             }
         }
     }
+    uint16_t *plane = planes + static_cast<size_t>(a.ngroups) * plane_elems;
+#pragma unroll
+    for (int r = 0; r < RJ; ++r) {
+        const int j = j0 + 256 * r;
+        if (j < a.Gp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4 *>(plane + gc_index(it, q, j, a.Gp)) = uint4{tot[r][4 * q], tot[r][4 * q + 1], tot[r][4 * q + 2], tot[r][4 * q + 3]};
+        }
+    }
+}
+
+// Classify comparison k from the stored counts.  HBM-bound: 2 x 64 B read per (tile, gene j),
+// the class-table words written as in k1_pairs.
+template <int RI, int RJ>
+__global__ __launch_bounds__(256) void k1_classify(K1Args a, const uint16_t *__restrict__ planes, size_t plane_elems)
+{
+    int i0, jc;
+    if (!tile_of_block<RI, RJ>(a, i0, jc)) return;
+    const int lane = threadIdx.x & 63;
+    const int j0 = jc * (kTileJ * RJ) + threadIdx.x;
+    const int it = i0 / RI;
+    const uint16_t *pk = planes + static_cast<size_t>(a.gc) * plane_elems;
+    const uint16_t *pt = planes + static_cast<size_t>(a.ngroups) * plane_elems;
+    uint32_t cL[RJ], cH[RJ], tL[RJ], tH[RJ];
+#pragma unroll
+    for (int r = 0; r < RJ; ++r) {
+        const int j = j0 + 256 * r;
+        cL[r] = cH[r] = tL[r] = tH[r] = 0;
+        if (j < a.Gp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 vk = *reinterpret_cast<const uint4 *>(pk + gc_index(it, q, j, a.Gp));
+                const uint4 vt = *reinterpret_cast<const uint4 *>(pt + gc_index(it, q, j, a.Gp));
+                const uint32_t wk[4] = {vk.x, vk.y, vk.z, vk.w}, wt[4] = {vt.x, vt.y, vt.z, vt.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int nk = static_cast<int>((wk[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                    const int nt = static_cast<int>((wt[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) - nk;
+                    const int sc = side_state(nk, a.nc, a.m1), stt = side_state(nt, a.nt, a.m2);
+                    const int ii = 8 * q + e;
+                    cL[r] |= (sc == 0 ? 1u : 0u) << ii; cH[r] |= (sc == 2 ? 1u : 0u) << ii;
+                    tL[r] |= (stt == 0 ? 1u : 0u) << ii; tH[r] |= (stt == 2 ? 1u : 0u) << ii;
+                }
+            }
+        }
+    }
+    emit_tile<RI, RJ>(a, i0, j0, i0 >> 6, lane, cL, cH, tL, tH);
 }
 
 // Parity hook: same inner loop, writes the raw counts of a block of ordered pairs.
@@ -1080,8 +1208,28 @@ int32_t launch_k1(reo_ctx *c, int k)
     REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
     if (units.empty()) return REO_OK;
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
+    // > 2 groups: count every group once, then classify per comparison -- if the planes fit
+    const size_t plane_elems = static_cast<size_t>(c->Gp) * c->Gp;
+    bool shared = multi && c->share_counts;
+    if (shared && !c->gc_valid) {
+        size_t free_b = 0, total_b = 0;
+        REO_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const size_t need = plane_elems * (c->ngroups + 1) * sizeof(uint16_t);
+        const size_t have = c->gcounts.n * sizeof(uint16_t);
+        if (need > have && need - have + (size_t(4) << 30) > free_b) shared = false;  // keep 4 GiB for everything else
+    }
+    c->last_k1_shared = shared ? 1 : 0;
     tic(c, 1);
-    if (multi) {
+    if (shared) {
+        if (!c->gc_valid) {
+            if ((rc = c->gcounts.ensure(plane_elems * (c->ngroups + 1)))) { toc(c); return rc; }
+            if (c->has_ties) k1_group_counts<kTileI, kRJTies, true, kLdsTies><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+            else k1_group_counts<kTileI, kRJ, false, true><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+            c->gc_valid = true;
+        }
+        if (c->has_ties) k1_classify<kTileI, kRJTies><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+        else k1_classify<kTileI, kRJ><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+    } else if (multi) {
         if (c->has_ties) k1_pairs<kTileI, kRJTies, true, true, kLdsTies><<<grid, 256, 0, c->stream>>>(a);
         else k1_pairs<kTileI, kRJ, false, true, true><<<grid, 256, 0, c->stream>>>(a);
     } else {

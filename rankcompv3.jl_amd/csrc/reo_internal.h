@@ -117,6 +117,11 @@ struct reo_ctx {
     // class table: [G][4 planes][Wp] 32-bit words
     reo::DevBuf<uint32_t> table;
     int built_k = -1;
+    // one-vs-rest with > 2 groups: per-group pair counts shared by the comparisons (kernels.hip, k1_group_counts)
+    reo::DevBuf<uint16_t> gcounts;      // [ngroups + 1][Gp/32][4][Gp][8]
+    bool gc_valid = false;
+    int share_counts = 1;               // REO_SHARE_GROUP_COUNTS=0 recounts per comparison instead
+    int last_k1_shared = 0;             // reo_get_info: how the last class table was built
     int64_t tiles_owned = 0, tiles_total = 0;
     int k1_cj = 0, k1_q = 0;  // K1 geometry of the last build: genes j per workgroup, j-chunks per panel
 

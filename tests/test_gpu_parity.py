@@ -349,6 +349,48 @@ def test_three_group_golden_and_synthetic_one_vs_rest(pkg, oracle, golden):
             assert np.array_equal(run.res[:, 1 + 16 * cm["k"]: 16 + 16 * cm["k"]].astype(float), cm["result"])
 
 
+@pytest.mark.parametrize("family", ["t0", "t1"])
+def test_shared_group_counts_equal_recounting(pkg, oracle, family, monkeypatch):
+    """> 2 groups: the comparisons classify from per-group counts kept in HBM (counted once); the class
+    codes and tallies must equal both the per-comparison recount and the oracle, also on two shards."""
+    G, S, seed, C = 1100, 83, 0x5EED0011, 5
+    X = (pkg.synth.t0_ranks if family == "t0" else pkg.synth.t1_counts)(G, S, seed)
+    gid = np.random.default_rng(5).integers(0, C, S).astype(np.int32)
+    gid[:C] = np.arange(C)  # every group present
+    ref0 = pkg.synth.ref_mask(G, 300, seed)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REO_SHARE_GROUP_COUNTS", mode)
+        with pkg.Context(device=0, seed=seed) as ctx:
+            ctx.set_matrix(X); ctx.set_groups(gid, C); thr = ctx.compute_thresholds(0.05)
+            for k in (3, 0, 4, 1, 2):  # any order, the counts are cached after the first
+                ctx.build_pairs(k)
+                info = ctx.info()
+                assert info["shared_group_counts"] == int(mode)
+                assert (info["group_count_bytes"] > 0) == (mode == "1")
+                out[mode, k] = (ctx.get_codes(0, G, 0, G), ctx.tally(ref0))
+    for k in range(C):
+        assert np.array_equal(out["1", k][0], out["0", k][0]) and np.array_equal(out["1", k][1], out["0", k][1])
+        code = oracle.build_codes(X.astype(np.float64), gid, C, k, [int(thr[0, k]), int(thr[1, k])], seed)
+        assert np.array_equal(out["1", k][0], code)
+    # two shards: their tallies add up to the unsharded ones
+    monkeypatch.setenv("REO_SHARE_GROUP_COUNTS", "1")
+    for k in (2, 0):
+        tot = 0
+        for rank in range(2):
+            with pkg.Context(device=0, seed=seed) as ctx:
+                ctx.set_matrix(X); ctx.set_groups(gid, C); ctx.compute_thresholds(0.05); ctx.set_shard(rank, 2)
+                ctx.build_pairs(1); ctx.build_pairs(k)
+                tot = tot + _shard_raw(pkg, ctx, ref0, G)
+        assert np.array_equal(pkg.sharding.derive_tallies(tot, ref0), out["1", k][1])
+
+
+def _shard_raw(pkg, ctx, ref0, G):
+    """raw counters of one shard's partial class table (codes it does not own decode as 'unstable/unstable')."""
+    code = ctx.get_codes(0, G, 0, G)
+    return pkg.sharding.raw_counters(code, ref0)
+
+
 def test_reoa_bundled_test_data_end_to_end(pkg, oracle, tmp_path):
     """BASELINE config 1: reoa(use_testdata="yes") on the reference's bundled files (README.md:26-56)."""
     seed = 0x5EED0001
