@@ -130,7 +130,7 @@ template <int RI, int RJ, bool TIES>
 __device__ __forceinline__ void count_pass_lds(const uint4 *__restrict__ pos8, const float *__restrict__ lo,
                                                const float *__restrict__ hi, int Gp, int i0, int j, int s8b,
                                                int s8e, float2v (&gt)[RJ][RI / 2], float2v (&ge)[RJ][RI / 2],
-                                               float4v *sm_lo, float4v *sm_hi)
+                                               float4v *sm_lo, float4v *sm_hi, bool idle)
 {
     static_assert(RI == 32, "stage layout assumes 32 genes = 8 float4 per sample");
 #pragma unroll
@@ -159,7 +159,9 @@ __device__ __forceinline__ void count_pass_lds(const uint4 *__restrict__ pos8, c
         const float4v *al = sm_lo + buf * (kStage * 8);
         const float4v *ah = sm_hi + buf * (kStage * 8);
         const int ng = min(kStage, se - s0) >> 3;  // groups of 8 slots in this chunk
-        for (int g8 = 0; g8 < ng; ++g8) {
+        // idle (wave-uniform): none of this wave's genes j forms a real pair with the tile (padding columns
+        // of the last chunk, or columns left of the diagonal) -- it only helps staging and keeps the barriers
+        for (int g8 = 0; g8 < (idle ? 0 : ng); ++g8) {
             uint4 cur[RJ];
 #pragma unroll
             for (int r = 0; r < RJ; ++r) cur[r] = pb[r * 256];
@@ -280,6 +282,20 @@ struct K1Args {
 // state of one side: 0 = "i<j stable" (reference 1), 1 = unstable (2), 2 = "i>j stable" (3)  (:376-377)
 __device__ __forceinline__ int side_state(int n, int size, int m) { return n >= m ? 2 : ((size - n) >= m ? 0 : 1); }
 
+// true when every gene j of the wave (64 consecutive from jw, and jw + 256 r) is padding (>= G) or lies in a
+// 64-gene block left of the tile's block: such pairs are never emitted (emit_tile)
+template <int RJ>
+__device__ __forceinline__ bool wave_idle(int jw, int i0, int G)
+{
+    bool idle = true;
+#pragma unroll
+    for (int r = 0; r < RJ; ++r) {
+        const int j = jw + 256 * r;
+        if (j < G && (j >> 6) >= (i0 >> 6)) idle = false;
+    }
+    return idle;
+}
+
 // Tile epilogue: the lane holds, for each of its RJ genes j, four 32-bit words (bit ii = pair (i0+ii, j)):
 // control-side L/H and treat-side L/H.  Writes the forward words of rows i0..i0+31 (ballot over the
 // lanes) and the mirror words of rows j.
@@ -372,11 +388,12 @@ __global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : 3) : (MULTI 
     }
     __shared__ float4v sm_lo[LDSFEED ? 2 * kStage * 8 : 1];
     __shared__ float4v sm_hi[(LDSFEED && TIES) ? 2 * kStage * 8 : 1];
+    const bool idle = wave_idle<RJ>(j0 & ~63, i0, a.G);
 
     float2v gt[RJ][RI / 2], ge[RJ][RI / 2];
     uint32_t cL[RJ], cH[RJ], tL[RJ], tH[RJ];
 
-    if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge, sm_lo, sm_hi);
+    if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge, sm_lo, sm_hi, idle);
     else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge);
 #pragma unroll
     for (int r = 0; r < RJ; ++r) {
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : 3) : (MULTI 
         }
     }
     if (!MULTI) {
-        if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge, sm_lo, sm_hi);
+        if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge, sm_lo, sm_hi, idle);
         else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge);
 #pragma unroll
         for (int r = 0; r < RJ; ++r) {
@@ -423,7 +440,7 @@ __global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : 3) : (MULTI 
             for (int ii = 0; ii < RI; ++ii) tot[r][ii] = 0;
         for (int g = 0; g < a.ngroups; ++g) {
             if (g == a.gc) continue;
-            if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi);
+            if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi, idle);
             else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge);
 #pragma unroll
             for (int r = 0; r < RJ; ++r)
@@ -489,6 +506,7 @@ __global__ __launch_bounds__(256, (TIES && RJ > 1) ? 2 : 3) void k1_group_counts
     const int j0 = jc * (kTileJ * RJ) + threadIdx.x;
     __shared__ float4v sm_lo[LDSFEED ? 2 * kStage * 8 : 1];
     __shared__ float4v sm_hi[(LDSFEED && TIES) ? 2 * kStage * 8 : 1];
+    const bool idle = wave_idle<RJ>(j0 & ~63, i0, a.G);
     float2v gt[RJ][RI / 2], ge[RJ][RI / 2];
     uint32_t tot[RJ][RI / 2];  // two u16 sums per register (sums are at most S < 65536)
 #pragma unroll
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(256, (TIES && RJ > 1) ? 2 : 3) void k1_group_counts
         for (int h = 0; h < RI / 2; ++h) tot[r][h] = 0;
     const int it = i0 / RI;
     for (int g = 0; g < a.ngroups; ++g) {
-        if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi);
+        if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi, idle);
         else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge);
         uint16_t *plane = planes + static_cast<size_t>(g) * plane_elems;
 #pragma unroll
