@@ -3,7 +3,7 @@
 //   K1  k1_pairs    pair compare -> per-group counts -> stable-REO class ->
 //                   4 bit planes per ordered pair      (src/RankCompV3.jl:363-392)
 //   K2  k2_tally    class table x reference mask -> per-gene tallies   (:403)
-//       k2_delta    the same as an incremental update from the rows of the genes whose mask bit changed
+//       (delta form: the same launch updates the counters from the rows of the genes whose mask bit changed)
 //   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask, loop control (:404-425,225-259)
 //
 // All file:line citations are relative to /root/reference.
@@ -663,15 +663,9 @@ __device__ __forceinline__ void tally_word(uint32_t cl, uint32_t ch, uint32_t tl
 
 // own: with G-sharding, one bit per 16-byte chunk of a row and per 32-row block: set iff this shard
 // wrote anything there (the rest of its table is zero and need not be read); nullptr = everything.
-__global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st, const uint4 *__restrict__ table,
-                                                const uint4 *__restrict__ refbits, int G, int Wq,
-                                                const uint32_t *__restrict__ own, int own_words,
-                                                int32_t *__restrict__ raw, int slot, int32_t *__restrict__ modes)
+__device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, const uint4 *__restrict__ refbits, int G, int Wq,
+                                           const uint32_t *__restrict__ own, int own_words, int32_t *__restrict__ raw)
 {
-    if (st->done) return;
-    const bool full = !(slot >= 0 && st->delta_cnt[slot] <= kDeltaMax);
-    if (modes && blockIdx.x == 0 && threadIdx.x == 0) modes[st->passes] = full ? 1 : 0;  // for the stage timers
-    if (!full) return;  // k2_delta updates the counters instead
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= G) return;
@@ -706,13 +700,9 @@ __global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st
 // by the mirror rule (:386) column j of the table is row j with L and H swapped, so gene j entering
 // (leaving) the reference set adds (removes), for every gene i, the class bits found at bit i of ROW j:
 // one contiguous row per changed gene instead of the whole table.  Exact (integer sums).
-__global__ __launch_bounds__(256) void k2_delta(const IterState *__restrict__ st, const uint32_t *__restrict__ table,
-                                                int G, int Wp, const uint32_t *__restrict__ list, int slot,
-                                                int32_t *__restrict__ raw)
+__device__ __forceinline__ void delta_genes(const uint32_t *__restrict__ table, int G, int Wp, const uint32_t *__restrict__ list,
+                                            int n, int32_t *__restrict__ raw)
 {
-    if (st->done) return;
-    const int n = st->delta_cnt[slot];
-    if (n > kDeltaMax) return;  // k2_tally recounts from scratch
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= G) return;
     const int w = i >> 5, sh = i & 31;
@@ -732,6 +722,21 @@ __global__ __launch_bounds__(256) void k2_delta(const IterState *__restrict__ st
     a.x += d[0]; a.y += d[1]; a.z += d[2]; a.w += d[3];
     b.x += d[4]; b.y += d[5]; b.z += d[6]; b.w += d[7];
     o[0] = a; o[1] = b;
+}
+
+// The K2 stage of one pass: one launch, the device picks the form.  slot < 0: always a full scan.
+__global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st, const uint32_t *__restrict__ table,
+                                                const uint4 *__restrict__ refbits, int G, int Wp,
+                                                const uint32_t *__restrict__ own, int own_words,
+                                                int32_t *__restrict__ raw, int slot, const uint32_t *__restrict__ list,
+                                                int32_t *__restrict__ modes)
+{
+    if (st->done) return;
+    const int n = slot >= 0 ? st->delta_cnt[slot] : kDeltaMax + 1;
+    const bool full = n > kDeltaMax;
+    if (modes && blockIdx.x == 0 && threadIdx.x == 0) modes[st->passes] = full ? 1 : 0;  // for the stage timers
+    if (full) tally_rows(reinterpret_cast<const uint4 *>(table), refbits, G, Wp / 4, own, own_words, raw);
+    else if (blockIdx.x * 256 < G) delta_genes(table, G, Wp, list, n, raw);
 }
 
 // ---------------------------------------------------------------------------
@@ -1116,7 +1121,7 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
         ind = !(pval[i] <= pval_deg && q <= padj_deg);
     }
     if (i < Gp) nbytes[i] = ind ? 1 : 0;
-    // genes whose mask bit changes: the next pass can update its tallies from their rows alone (k2_delta)
+    // genes whose mask bit changes: the next pass can update its tallies from their rows alone (delta_genes)
     const bool changed = i < G && ind != (obytes[i] != 0);
     const unsigned long long cm = __ballot(changed);
     if (cm) {
@@ -1293,13 +1298,11 @@ int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits, int slot, bool allow_de
     const int G = static_cast<int>(c->G);
     int32_t *raw = c->world > 1 ? c->raw_local.p : c->raw.p;  // shards keep their own counters, the sum goes to raw
     tic(c, 2);
-    if (allow_delta)
-        k2_delta<<<(G + 255) / 256, 256, 0, c->stream>>>(c->state.p, c->table.p, G, c->Wp,
-                                                         c->delta_list.p + static_cast<size_t>(slot) * c->Gp, slot, raw);
-    k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(c->state.p, reinterpret_cast<const uint4 *>(c->table.p),
-                                                 reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp / 4,
+    k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(c->state.p, c->table.p, reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp,
                                                  c->world > 1 ? c->own_mask.p : nullptr, c->own_words, raw,
-                                                 allow_delta ? slot : -1, allow_delta ? c->modes.p : nullptr);
+                                                 allow_delta ? slot : -1,
+                                                 allow_delta ? c->delta_list.p + static_cast<size_t>(slot) * c->Gp : nullptr,
+                                                 allow_delta ? c->modes.p : nullptr);
     toc(c);
     c->t_ms[4] += 1.0;
     REO_HIP_CHECK(hipGetLastError());

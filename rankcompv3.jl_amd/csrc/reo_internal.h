@@ -32,7 +32,7 @@ struct IterState {
     int32_t i_iter;   // :397,423
     int32_t ticket;   // finished workgroups of k3_finalize
     int32_t nn_acc;   // running sum(inds)
-    int32_t delta_cnt[2];  // genes whose mask bit changes for the pass of that parity (see k2_delta)
+    int32_t delta_cnt[2];  // genes whose mask bit changes for the pass of that parity (see delta_genes in kernels.hip)
 };
 
 void set_error(const char *fmt, ...);
