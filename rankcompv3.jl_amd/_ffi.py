@@ -164,14 +164,16 @@ class Context:
         X = np.asarray(X)
         if X.ndim != 2:
             raise DimensionMismatch(REO_EINVAL, "expression matrix must be 2-D (genes x samples)")
-        if np.issubdtype(X.dtype, np.integer) or X.dtype == np.bool_:
-            Xf = np.asfortranarray(X, dtype=np.int64)
-            fn = self._L.reo_set_matrix_i64
+        integer = np.issubdtype(X.dtype, np.integer) or X.dtype == np.bool_
+        fn = self._L.reo_set_matrix_i64 if integer else self._L.reo_set_matrix_f64
+        want = np.int64 if integer else np.float64
+        G, S = X.shape
+        if X.dtype == want and G > 0 and S > 1 and X.strides[0] == 8 and X.strides[1] % 8 == 0 and X.strides[1] >= 8 * G:
+            Xf, ld = X, X.strides[1] // 8  # a column-major view (rows of a taller matrix): passed as is, like a Julia view
         else:
-            Xf = np.asfortranarray(X, dtype=np.float64)
-            fn = self._L.reo_set_matrix_f64
-        G, S = Xf.shape
-        check(fn(self._h, _ptr(Xf), G, S, max(G, 1)))
+            Xf = np.asfortranarray(X, dtype=want)
+            ld = max(G, 1)
+        check(fn(self._h, _ptr(Xf), G, S, ld))
         self.G, self.S = G, S
 
     def set_matrix_device(self, dev_ptr: int, G: int, S: int, ld: int, dtype: str, keepalive=None) -> None:

@@ -391,6 +391,34 @@ def _shard_raw(pkg, ctx, ref0, G):
     return pkg.sharding.raw_counters(code, ref0)
 
 
+def test_host_matrix_view_with_leading_dimension(pkg, oracle):
+    """A column-major host view with ld > G (rows of a taller matrix, like a Julia view) must arrive
+    intact: counts of blocks at both ends and in the middle of a 20 000-gene matrix."""
+    G, S, seed = 20000, 260, 0x5EED0012
+    big = np.asfortranarray(np.zeros((G + 24, S), dtype=np.int64))
+    big[:] = -7  # rows outside the view must never be read as data
+    Xc = pkg.synth.t1_counts(G, S, seed)
+    big[8:8 + G, :] = Xc
+    view = big[8:8 + G, :]
+    assert view.strides == (8, 8 * (G + 24))
+    gid, _ = pkg.encode_groups(pkg.synth.groups(S))
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(view)
+        ctx.set_groups(gid, 2)
+        for (i0, i1, j0, j1) in ((0, 40, 0, 40), (G - 40, G, G - 40, G), (9990, 10030, 40, 80)):
+            gt, eq = ctx.pair_counts(i0, i1, j0, j1)
+            egt, eeq = oracle.pair_counts(Xc.astype(np.float64), gid, 2, i0, i1, j0, j1)
+            assert np.array_equal(gt, egt) and np.array_equal(eq, eeq)
+    for dt in (np.float64,):  # the same through the Float64 entry point, contiguous
+        Xf = np.asfortranarray(Xc.astype(dt))
+        with pkg.Context(device=0, seed=seed) as ctx:
+            ctx.set_matrix(Xf)
+            ctx.set_groups(gid, 2)
+            gt, eq = ctx.pair_counts(100, 140, 19900, 19940)
+            egt, eeq = oracle.pair_counts(Xf, gid, 2, 100, 140, 19900, 19940)
+            assert np.array_equal(gt, egt) and np.array_equal(eq, eeq)
+
+
 def test_reoa_bundled_test_data_end_to_end(pkg, oracle, tmp_path):
     """BASELINE config 1: reoa(use_testdata="yes") on the reference's bundled files (README.md:26-56)."""
     seed = 0x5EED0001
