@@ -279,11 +279,9 @@ struct K1Args {
     int ngroups;
 };
 
-// state of one side: 0 = "i<j stable" (reference 1), 1 = unstable (2), 2 = "i>j stable" (3)  (:376-377)
-__device__ __forceinline__ int side_state(int n, int size, int m) { return n >= m ? 2 : ((size - n) >= m ? 0 : 1); }
 
 // true when every gene j of the wave (64 consecutive from jw, and jw + 256 r) is padding (>= G) or lies in a
-// 64-gene block left of the tile's block: such pairs are never emitted (emit_tile)
+// 64-gene block left of the tile's block: such pairs are never emitted (emit_side)
 template <int RJ>
 __device__ __forceinline__ bool wave_idle(int jw, int i0, int G)
 {
@@ -296,62 +294,71 @@ __device__ __forceinline__ bool wave_idle(int jw, int i0, int G)
     return idle;
 }
 
-// Tile epilogue: the lane holds, for each of its RJ genes j, four 32-bit words (bit ii = pair (i0+ii, j)):
-// control-side L/H and treat-side L/H.  Writes the forward words of rows i0..i0+31 (ballot over the
-// lanes) and the mirror words of rows j.
-template <int RI, int RJ>
-__device__ __forceinline__ void emit_tile(const K1Args &a, int i0, int j0, int bi, int lane, const uint32_t (&cL)[RJ],
-                                          const uint32_t (&cH)[RJ], const uint32_t (&tL)[RJ], const uint32_t (&tH)[RJ])
+// word = 2 * word + (bit `lane` of mask): v_addc_co_u32 takes the lane mask as its per-lane carry-in
+__device__ __forceinline__ void shift_in(uint32_t &w, unsigned long long mask)
+{
+    unsigned long long carry_out;
+    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(w), "=s"(carry_out) : "s"(mask));
+}
+
+// lane `l` of v = the wave-uniform x
+__device__ __forceinline__ void write_lane(uint32_t &v, uint32_t x, int l)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "i"(l));  // l must fold to a constant (unrolled loops)
+}
+
+// Epilogue of one side (control: planes 0/1, treat: planes 2/3) of a tile.  val(r, ii) is the count n of
+// pair (i0+ii, j0+256r) on this side; state H <=> n >= m, L <=> size - n >= m (:376-377).  Each predicate
+// is one v_cmp whose lane mask IS the forward word of row i0+ii (columns of this wave's 64-gene block);
+// the mirror word of row j (:386: L and H swap) grows by one bit per row with an add-with-carry from the
+// same mask.  Only pairs i < j < G are real; everything else contributes zero bits.  The diagonal 64x64
+// blocks are written by several tiles and use atomicOr on the pre-zeroed table.
+template <int RI, int RJ, typename T, typename F>
+__device__ __forceinline__ void emit_side(const K1Args &a, int i0, int j0, int bi, int lane, int pl, T hi_thr, T lo_thr, F val)
 {
 #pragma unroll
     for (int r = 0; r < RJ; ++r) {
         const int j = j0 + 256 * r;
-        const int bj = j >> 6;  // wave-uniform
-        if (j >= a.Gp || bj < bi) continue;
-        // only pairs i < j < G are real; everything else contributes zero bits
-        uint32_t vm = 0;
-        if (j < a.G) {
-            const int d = j - i0;  // rows i0+ii with ii < d are above the diagonal
-            vm = d >= 32 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << d) - 1u));
+        const int bj = __builtin_amdgcn_readfirstlane(j >> 6);  // wave-uniform, and the compiler should know it
+        if ((bj << 6) >= a.Gp || bj < bi) continue;
+        const int d = j - i0;                          // rows i0+ii with ii < d are above the diagonal
+        const bool near = (bj << 6) - i0 < RI;         // wave-uniform: some lane has d < 32
+        const unsigned long long lanes_ok = __ballot(j < a.G);
+        uint32_t wL = 0, wH = 0;
+        uint32_t fLlo = 0, fLhi = 0, fHlo = 0, fHhi = 0;  // lane ii: forward words of row i0+ii
+#pragma unroll
+        for (int ii = RI - 1; ii >= 0; --ii) {
+            const T n = val(r, ii);
+            const unsigned long long ok = near ? (__ballot(d > ii) & lanes_ok) : lanes_ok;
+            const unsigned long long mH = __ballot(n >= hi_thr) & ok;
+            const unsigned long long mL = __ballot(n <= lo_thr) & ok & ~mH;
+            shift_in(wH, mH);
+            shift_in(wL, mL);
+            write_lane(fHlo, static_cast<uint32_t>(mH), ii);
+            write_lane(fHhi, static_cast<uint32_t>(mH >> 32), ii);
+            write_lane(fLlo, static_cast<uint32_t>(mL), ii);
+            write_lane(fLhi, static_cast<uint32_t>(mL >> 32), ii);
         }
-        const uint32_t wcL = cL[r] & vm, wcH = cH[r] & vm, wtL = tL[r] & vm, wtH = tH[r] & vm;
         const bool diag = (bj == bi);
-        // forward bits: row i, 64-bit word of columns [64*bj, 64*bj+64) = ballot over the lanes
-        unsigned long long f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-#pragma unroll
-        for (int ii = 0; ii < RI; ++ii) {
-            const unsigned long long b0 = __ballot((wcL >> ii) & 1u);
-            const unsigned long long b1 = __ballot((wcH >> ii) & 1u);
-            const unsigned long long b2 = __ballot((wtL >> ii) & 1u);
-            const unsigned long long b3 = __ballot((wtH >> ii) & 1u);
-            if (lane == ii) { f0 = b0; f1 = b1; f2 = b2; f3 = b3; }
-        }
         if (lane < RI && i0 + lane < a.G) {
-            uint32_t *row = a.table + static_cast<size_t>(i0 + lane) * kPlanes * a.Wp + 2 * bj;
+            uint32_t *row = a.table + (static_cast<size_t>(i0 + lane) * kPlanes + pl) * a.Wp + 2 * bj;
             if (!diag) {
-                *reinterpret_cast<unsigned long long *>(row) = f0;
-                *reinterpret_cast<unsigned long long *>(row + a.Wp) = f1;
-                *reinterpret_cast<unsigned long long *>(row + 2 * a.Wp) = f2;
-                *reinterpret_cast<unsigned long long *>(row + 3 * a.Wp) = f3;
+                *reinterpret_cast<uint2 *>(row) = uint2{fLlo, fLhi};
+                *reinterpret_cast<uint2 *>(row + a.Wp) = uint2{fHlo, fHhi};
             } else {
-                const unsigned long long f[4] = {f0, f1, f2, f3};
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if (static_cast<uint32_t>(f[p])) atomicOr(row + p * a.Wp, static_cast<uint32_t>(f[p]));
-                    if (static_cast<uint32_t>(f[p] >> 32)) atomicOr(row + p * a.Wp + 1, static_cast<uint32_t>(f[p] >> 32));
-                }
+                if (fLlo) atomicOr(row, fLlo);
+                if (fLhi) atomicOr(row + 1, fLhi);
+                if (fHlo) atomicOr(row + a.Wp, fHlo);
+                if (fHhi) atomicOr(row + a.Wp + 1, fHhi);
             }
         }
-        // mirror bits (:386): pair (j,i) is in state 2 - state(i,j) on both sides -> L and H swap
-        if (j < a.G) {
-            uint32_t *row = a.table + static_cast<size_t>(j) * kPlanes * a.Wp + (i0 >> 5);
+        if (j < a.G) {  // mirror: pair (j, i) is in state 2 - state(i, j)
+            uint32_t *row = a.table + (static_cast<size_t>(j) * kPlanes + pl) * a.Wp + (i0 >> 5);
             if (!diag) {
-                row[0] = wcH; row[a.Wp] = wcL; row[2 * a.Wp] = wtH; row[3 * a.Wp] = wtL;
+                row[0] = wH; row[a.Wp] = wL;
             } else {
-                if (wcH) atomicOr(row, wcH);
-                if (wcL) atomicOr(row + a.Wp, wcL);
-                if (wtH) atomicOr(row + 2 * a.Wp, wtH);
-                if (wtL) atomicOr(row + 3 * a.Wp, wtL);
+                if (wH) atomicOr(row, wH);
+                if (wL) atomicOr(row + a.Wp, wL);
             }
         }
     }
@@ -360,7 +367,7 @@ __device__ __forceinline__ void emit_tile(const K1Args &a, int i0, int j0, int b
 // MULTI = one-vs-rest with more than two groups (:375-390): the treat side is every other group,
 // counted group by group because the tie coins are keyed by group.
 template <int RI, int RJ, bool TIES, bool MULTI, bool LDSFEED>
-__global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : 3) : (MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4 : 5))) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
+__global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : ((TIES || MULTI) ? 3 : 4)) : (MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4 : 5))) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
 {
     static_assert(RI == 32, "one mirror word per tile");
     const int lane = threadIdx.x & 63;
@@ -391,47 +398,30 @@ __global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : 3) : (MULTI 
     const bool idle = wave_idle<RJ>(j0 & ~63, i0, a.G);
 
     float2v gt[RJ][RI / 2], ge[RJ][RI / 2];
-    uint32_t cL[RJ], cH[RJ], tL[RJ], tH[RJ];
+    // count of pair (i0+ii, j0+256r) in group g from the accumulators, tie coins included (:72-77)
+    auto count_of = [&](int r, int ii, int g) -> int {
+        const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
+        int nre = static_cast<int>(fgt);
+        if (TIES) {
+            const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
+            const uint32_t neq = static_cast<uint32_t>(fge - fgt);
+            if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, g, neq);
+        }
+        return nre;
+    };
+    auto fcount_of = [&](int r, int ii) -> float { return (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x; };
 
+    // control side (:376): nothing of it has to survive the treat-side loop
     if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge, sm_lo, sm_hi, idle);
     else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge);
-#pragma unroll
-    for (int r = 0; r < RJ; ++r) {
-        cL[r] = 0; cH[r] = 0;
-#pragma unroll
-        for (int ii = 0; ii < RI; ++ii) {
-            const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
-            int nre = static_cast<int>(fgt);
-            if (TIES) {
-                const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
-                const uint32_t neq = static_cast<uint32_t>(fge - fgt);
-                if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, a.gc, neq);
-            }
-            const int st = side_state(nre, a.nc, a.m1);
-            cL[r] |= (st == 0 ? 1u : 0u) << ii;
-            cH[r] |= (st == 2 ? 1u : 0u) << ii;
-        }
-    }
+    if (TIES) emit_side<RI, RJ, int>(a, i0, j0, bi, lane, 0, a.m1, a.nc - a.m1, [&](int r, int ii) { return count_of(r, ii, a.gc); });
+    else emit_side<RI, RJ, float>(a, i0, j0, bi, lane, 0, static_cast<float>(a.m1), static_cast<float>(a.nc - a.m1), fcount_of);
+    // treat side (:377)
     if (!MULTI) {
         if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge, sm_lo, sm_hi, idle);
         else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge);
-#pragma unroll
-        for (int r = 0; r < RJ; ++r) {
-            tL[r] = 0; tH[r] = 0;
-#pragma unroll
-            for (int ii = 0; ii < RI; ++ii) {
-                const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
-                int nre = static_cast<int>(fgt);
-                if (TIES) {
-                    const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
-                    const uint32_t neq = static_cast<uint32_t>(fge - fgt);
-                    if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, a.gt, neq);
-                }
-                const int st = side_state(nre, a.nt, a.m2);
-                tL[r] |= (st == 0 ? 1u : 0u) << ii;
-                tH[r] |= (st == 2 ? 1u : 0u) << ii;
-            }
-        }
+        if (TIES) emit_side<RI, RJ, int>(a, i0, j0, bi, lane, 2, a.m2, a.nt - a.m2, [&](int r, int ii) { return count_of(r, ii, a.gt); });
+        else emit_side<RI, RJ, float>(a, i0, j0, bi, lane, 2, static_cast<float>(a.m2), static_cast<float>(a.nt - a.m2), fcount_of);
     } else {
         int tot[RJ][RI];  // not = sum(nre) - nre[k]  (:374)
 #pragma unroll
@@ -445,30 +435,10 @@ __global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : 3) : (MULTI 
 #pragma unroll
             for (int r = 0; r < RJ; ++r)
 #pragma unroll
-                for (int ii = 0; ii < RI; ++ii) {
-                    const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
-                    int nre = static_cast<int>(fgt);
-                    if (TIES) {
-                        const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
-                        const uint32_t neq = static_cast<uint32_t>(fge - fgt);
-                        if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, g, neq);
-                    }
-                    tot[r][ii] += nre;
-                }
+                for (int ii = 0; ii < RI; ++ii) tot[r][ii] += count_of(r, ii, g);
         }
-#pragma unroll
-        for (int r = 0; r < RJ; ++r) {
-            tL[r] = 0; tH[r] = 0;
-#pragma unroll
-            for (int ii = 0; ii < RI; ++ii) {
-                const int st = side_state(tot[r][ii], a.nt, a.m2);
-                tL[r] |= (st == 0 ? 1u : 0u) << ii;
-                tH[r] |= (st == 2 ? 1u : 0u) << ii;
-            }
-        }
+        emit_side<RI, RJ, int>(a, i0, j0, bi, lane, 2, a.m2, a.nt - a.m2, [&](int r, int ii) { return tot[r][ii]; });
     }
-
-    emit_tile<RI, RJ>(a, i0, j0, bi, lane, cL, cH, tL, tH);
 }
 
 // ---------------------------------------------------------------------------
@@ -564,30 +534,25 @@ __global__ __launch_bounds__(256) void k1_classify(K1Args a, const uint16_t *__r
     const int it = i0 / RI;
     const uint16_t *pk = planes + static_cast<size_t>(a.gc) * plane_elems;
     const uint16_t *pt = planes + static_cast<size_t>(a.ngroups) * plane_elems;
-    uint32_t cL[RJ], cH[RJ], tL[RJ], tH[RJ];
+    uint32_t wk[RJ][RI / 2], wt[RJ][RI / 2];  // two u16 counts per register
 #pragma unroll
     for (int r = 0; r < RJ; ++r) {
         const int j = j0 + 256 * r;
-        cL[r] = cH[r] = tL[r] = tH[r] = 0;
-        if (j < a.Gp) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 vk = *reinterpret_cast<const uint4 *>(pk + gc_index(it, q, j, a.Gp));
-                const uint4 vt = *reinterpret_cast<const uint4 *>(pt + gc_index(it, q, j, a.Gp));
-                const uint32_t wk[4] = {vk.x, vk.y, vk.z, vk.w}, wt[4] = {vt.x, vt.y, vt.z, vt.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int nk = static_cast<int>((wk[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
-                    const int nt = static_cast<int>((wt[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) - nk;
-                    const int sc = side_state(nk, a.nc, a.m1), stt = side_state(nt, a.nt, a.m2);
-                    const int ii = 8 * q + e;
-                    cL[r] |= (sc == 0 ? 1u : 0u) << ii; cH[r] |= (sc == 2 ? 1u : 0u) << ii;
-                    tL[r] |= (stt == 0 ? 1u : 0u) << ii; tH[r] |= (stt == 2 ? 1u : 0u) << ii;
-                }
+        for (int q = 0; q < 4; ++q) {
+            uint4 vk = {0, 0, 0, 0}, vt = {0, 0, 0, 0};
+            if (j < a.Gp) {
+                vk = *reinterpret_cast<const uint4 *>(pk + gc_index(it, q, j, a.Gp));
+                vt = *reinterpret_cast<const uint4 *>(pt + gc_index(it, q, j, a.Gp));
             }
+            wk[r][4 * q] = vk.x; wk[r][4 * q + 1] = vk.y; wk[r][4 * q + 2] = vk.z; wk[r][4 * q + 3] = vk.w;
+            wt[r][4 * q] = vt.x; wt[r][4 * q + 1] = vt.y; wt[r][4 * q + 2] = vt.z; wt[r][4 * q + 3] = vt.w;
         }
     }
-    emit_tile<RI, RJ>(a, i0, j0, i0 >> 6, lane, cL, cH, tL, tH);
+    auto nk_of = [&](int r, int ii) -> int { return static_cast<int>((wk[r][ii >> 1] >> (16 * (ii & 1))) & 0xFFFFu); };
+    auto nt_of = [&](int r, int ii) -> int { return static_cast<int>((wt[r][ii >> 1] >> (16 * (ii & 1))) & 0xFFFFu) - nk_of(r, ii); };
+    emit_side<RI, RJ, int>(a, i0, j0, i0 >> 6, lane, 0, a.m1, a.nc - a.m1, nk_of);
+    emit_side<RI, RJ, int>(a, i0, j0, i0 >> 6, lane, 2, a.m2, a.nt - a.m2, nt_of);
 }
 
 // Parity hook: same inner loop, writes the raw counts of a block of ordered pairs.
@@ -736,7 +701,7 @@ __global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st
     const bool full = n > kDeltaMax;
     if (modes && blockIdx.x == 0 && threadIdx.x == 0) modes[st->passes] = full ? 1 : 0;  // for the stage timers
     if (full) tally_rows(reinterpret_cast<const uint4 *>(table), refbits, G, Wp / 4, own, own_words, raw);
-    else if (blockIdx.x * 256 < G) delta_genes(table, G, Wp, list, n, raw);
+    else if (static_cast<int>(blockIdx.x) * 256 < G) delta_genes(table, G, Wp, list, n, raw);
 }
 
 // ---------------------------------------------------------------------------
