@@ -532,11 +532,11 @@ int32_t reo_get_timings(reo_ctx *c, double *ms, int32_t n)
 int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
 {
     if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
-    const int64_t v[14] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
+    const int64_t v[15] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
                            c->tiles_owned, c->tiles_total, kTileI, c->k1_cj, c->k1_q, kUnitH,
                            c->goff8.empty() ? 0 : c->goff8.back(), c->last_k1_shared,
-                           static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t))};
-    for (int i = 0; i < n && i < 14; ++i) info[i] = v[i];
+                           static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t)), c->transform_in_lds};
+    for (int i = 0; i < n && i < 15; ++i) info[i] = v[i];
     return REO_OK;
 }
 

@@ -113,6 +113,7 @@ struct reo_ctx {
     int own_words = 0;
     bool transformed = false;
     int has_ties = 0;
+    int transform_in_lds = 0;  // the last transform sorted each sample inside one workgroup's LDS (transform.hip)
 
     // class table: [G][4 planes][Wp] 32-bit words
     reo::DevBuf<uint32_t> table;

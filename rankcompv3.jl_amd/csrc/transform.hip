@@ -12,6 +12,7 @@
 // into the same two 16-bit integer compares for the pair kernel.  The band
 // edges are found with the reference's own predicate evaluated in the input's
 // arithmetic, so the result is exact, not approximate.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -121,6 +122,136 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
     hi[o] = static_cast<float>(h + 1);
 }
 
+// Scan of the whole matrix before any sorting: non-finite flag and the key bits that vary anywhere.
+template <class T>
+__global__ __launch_bounds__(256) void t_varbits(const T *__restrict__ X, int64_t ld, int G, int32_t *__restrict__ bad,
+                                                 unsigned long long *__restrict__ varbits)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    uint64_t diff = 0;
+    if (g < G) {
+        const T x = X[static_cast<int64_t>(g) + static_cast<int64_t>(blockIdx.y) * ld];
+        if (!Codec<T>::finite(x)) atomicOr(bad, 1);
+        diff = Codec<T>::enc(x) ^ Codec<T>::enc(X[0]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    if ((threadIdx.x & 63) == 0 && (diff & ~__hip_atomic_load(varbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
+        atomicOr(varbits, diff);
+}
+
+// One workgroup per sample, everything in LDS: when the varying key bits fit 31 bits and the genes fit
+// 1024 x IPT items, the sample's column is read once, sorted with a block radix sort (rocprim block
+// primitive, keys in registers, exchange through LDS), the tie bands are searched in the LDS copy of the
+// sorted keys, and lo / hi leave as whole coalesced rows.  HBM traffic: the matrix once in, pos / lo / hi
+// once out, instead of keys out, two sort passes in and out, keys in again.
+// Key = the varying bits (begin_bit .. begin_bit + nbits - 1) of the order-preserving code; bit `nbits`
+// marks padding items, which sort behind every gene.
+template <class T, int IPT>
+__global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
+                                                 const int32_t *__restrict__ slots, int G, int Gp, uint64_t key0,
+                                                 unsigned begin_bit, unsigned nbits, uint16_t *__restrict__ pos,
+                                                 float *__restrict__ lo, float *__restrict__ hi, int32_t *__restrict__ anytie)
+{
+    using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typename sorter::storage_type &storage = *reinterpret_cast<typename sorter::storage_type *>(smem);
+    const int t = threadIdx.x, c = blockIdx.x;
+    const T *col = X + static_cast<int64_t>(colmap[c]) * ld;
+    const int slot = slots[c];
+    const uint32_t mask = (1u << nbits) - 1u;
+    uint32_t k[IPT];
+    uint16_t v[IPT];
+#pragma unroll
+    for (int e = 0; e < IPT; ++e) {
+        const int i = e * 1024 + t;  // coalesced; which item holds which gene does not matter to the sort
+        if (i < G) { k[e] = static_cast<uint32_t>(Codec<T>::enc(col[i]) >> begin_bit) & mask; v[e] = static_cast<uint16_t>(i); }
+        else { k[e] = 1u << nbits; v[e] = 0xFFFFu; }
+    }
+    sorter().sort(k, v, storage, 0, nbits + 1);  // blocked: item e of thread t is sorted position t * IPT + e
+    __syncthreads();
+    uint32_t *skey = reinterpret_cast<uint32_t *>(smem);
+#pragma unroll
+    for (int e = 0; e < IPT; ++e) skey[t * IPT + e] = k[e];
+    __syncthreads();
+    const uint64_t base = key0 & ~(static_cast<uint64_t>(mask) << begin_bit);
+    auto value = [&](uint32_t kk) { return Codec<T>::dec(base | (static_cast<uint64_t>(kk) << begin_bit)); };
+    uint32_t band[IPT];  // l | (h + 1) << 16
+    bool tied = false;
+#pragma unroll
+    for (int e = 0; e < IPT; ++e) {
+        const int p = t * IPT + e;
+        band[e] = 0;
+        if (p >= G) continue;
+        const T x = value(k[e]);
+        int l = p, h = p;
+        if (p > 0 && Codec<T>::tie(value(skey[p - 1]), x)) {
+            int a = 0, b = p - 1;  // tie holds at b; first tied position
+            while (a < b) {
+                const int m = (a + b) >> 1;
+                if (Codec<T>::tie(value(skey[m]), x)) b = m; else a = m + 1;
+            }
+            l = a;
+        }
+        if (p + 1 < G && Codec<T>::tie(value(skey[p + 1]), x)) {
+            int a = p + 1, b = G - 1;  // tie holds at a; last tied position
+            while (a < b) {
+                const int m = (a + b + 1) >> 1;
+                if (Codec<T>::tie(value(skey[m]), x)) a = m; else b = m - 1;
+            }
+            h = a;
+        }
+        tied |= (l != p) | (h != p);
+        band[e] = static_cast<uint32_t>(l) | (static_cast<uint32_t>(h + 1) << 16);
+    }
+    if (tied && *anytie == 0) atomicOr(anytie, 1);
+    __syncthreads();  // every search in skey is done: the space becomes lo16 / hi16 indexed by gene
+    uint16_t *lo16 = reinterpret_cast<uint16_t *>(smem), *hi16 = lo16 + Gp;
+    for (int g = G + t; g < Gp; g += 1024) { lo16[g] = 0; hi16[g] = 0; }  // padded genes are below no band edge
+    uint16_t *prow = pos + static_cast<size_t>(slot >> 3) * Gp * 8 + (slot & 7);
+#pragma unroll
+    for (int e = 0; e < IPT; ++e) {
+        const int p = t * IPT + e;
+        if (p >= G) continue;
+        const int g = v[e];
+        lo16[g] = static_cast<uint16_t>(band[e] & 0xFFFFu);
+        hi16[g] = static_cast<uint16_t>(band[e] >> 16);
+        prow[static_cast<size_t>(g) * 8] = static_cast<uint16_t>(p);
+    }
+    __syncthreads();
+    float4 *lrow = reinterpret_cast<float4 *>(lo + static_cast<size_t>(slot) * Gp);
+    float4 *hrow = reinterpret_cast<float4 *>(hi + static_cast<size_t>(slot) * Gp);
+    for (int q = t; q < Gp / 4; q += 1024) {
+        const uint2 a = reinterpret_cast<const uint2 *>(lo16)[q], b = reinterpret_cast<const uint2 *>(hi16)[q];
+        lrow[q] = make_float4(static_cast<float>(a.x & 0xFFFFu), static_cast<float>(a.x >> 16), static_cast<float>(a.y & 0xFFFFu), static_cast<float>(a.y >> 16));
+        hrow[q] = make_float4(static_cast<float>(b.x & 0xFFFFu), static_cast<float>(b.x >> 16), static_cast<float>(b.y & 0xFFFFu), static_cast<float>(b.y >> 16));
+    }
+}
+
+template <class T, int IPT>
+int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, uint64_t key0, unsigned begin_bit, unsigned nbits, int32_t *d_anytie)
+{
+    using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
+    const size_t lds = std::max(sizeof(typename sorter::storage_type), static_cast<size_t>(4) * c->Gp);
+    static bool configured = false;  // per instantiation
+    if (!configured) {
+        REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp, key0,
+                                                                            begin_bit, nbits, c->pos.p, c->lo.p, c->hi.p, d_anytie);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+inline uint64_t host_enc(double x)
+{
+    uint64_t u;
+    memcpy(&u, &x, sizeof u);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+inline uint64_t host_enc(int64_t x) { return static_cast<uint64_t>(x) ^ 0x8000000000000000ULL; }
+
 struct SegOff {
     unsigned G;
     __host__ __device__ unsigned operator()(unsigned i) const { return i * G; }
@@ -168,6 +299,52 @@ int32_t transform_impl(reo_ctx *c)
     const size_t n = static_cast<size_t>(S8) * Gp;
     if ((rc = c->pos.ensure(n)) || (rc = c->lo.ensure(n)) || (rc = c->hi.ensure(n))) return rc;
     REO_HIP_CHECK(hipMemsetAsync(c->pos.p, 0xFF, n * sizeof(uint16_t), st));
+    const T *X = static_cast<const T *>(c->dX);
+
+    // scan: non-finite values, and which key bits vary at all (rank-like data: 15 bits)
+    {
+        dim3 grid((G + 255) / 256, S);
+        t_varbits<T><<<grid, 256, 0, st>>>(X, c->ld, G, d_flags.p, d_varbits);
+        REO_HIP_CHECK(hipGetLastError());
+        int32_t fl[4];
+        T x0;
+        REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, sizeof fl, hipMemcpyDeviceToHost, st));
+        REO_HIP_CHECK(hipMemcpyAsync(&x0, X, sizeof x0, hipMemcpyDeviceToHost, st));
+        REO_HIP_CHECK(hipStreamSynchronize(st));
+        if (fl[0]) {
+            set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
+                      "src/RankCompV3.jl:601)");
+            return REO_EINVAL;
+        }
+        unsigned long long vb;
+        memcpy(&vb, fl + 2, sizeof vb);
+        const unsigned begin_bit = vb ? static_cast<unsigned>(__builtin_ctzll(vb)) : 0u;
+        const unsigned nbits = vb ? 64u - static_cast<unsigned>(__builtin_clzll(vb)) - begin_bit : 1u;
+        const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort (A/B tests)
+        const bool in_lds = nbits <= 31 && G <= 24 * 1024 && !(env && env[0] == 's');
+        c->transform_in_lds = in_lds ? 1 : 0;
+        if (in_lds) {
+            // rows of the padding slots of every group (at most 7 each): below no band edge
+            for (int g = 0; g < c->ngroups; ++g) {
+                const int first = c->goff8[g] + (c->goff[g + 1] - c->goff[g]), cnt = c->goff8[g + 1] - first;
+                if (cnt > 0) {
+                    REO_HIP_CHECK(hipMemsetAsync(c->lo.p + static_cast<size_t>(first) * Gp, 0, static_cast<size_t>(cnt) * Gp * sizeof(float), st));
+                    REO_HIP_CHECK(hipMemsetAsync(c->hi.p + static_cast<size_t>(first) * Gp, 0, static_cast<size_t>(cnt) * Gp * sizeof(float), st));
+                }
+            }
+            const uint64_t key0 = host_enc(x0);
+            if (G <= 8 * 1024) rc = launch_sample<T, 8>(c, X, d_order.p, key0, begin_bit, nbits, d_flags.p + 1);
+            else if (G <= 20 * 1024) rc = launch_sample<T, 20>(c, X, d_order.p, key0, begin_bit, nbits, d_flags.p + 1);
+            else rc = launch_sample<T, 24>(c, X, d_order.p, key0, begin_bit, nbits, d_flags.p + 1);
+            if (rc) return rc;
+            int32_t tie_flag = 0;
+            REO_HIP_CHECK(hipMemcpyAsync(&tie_flag, d_flags.p + 1, sizeof tie_flag, hipMemcpyDeviceToHost, st));
+            REO_HIP_CHECK(hipStreamSynchronize(st));
+            c->has_ties = tie_flag;
+            c->transformed = true;
+            return REO_OK;
+        }
+    }
     REO_HIP_CHECK(hipMemsetAsync(c->lo.p, 0, n * sizeof(float), st));
     REO_HIP_CHECK(hipMemsetAsync(c->hi.p, 0, n * sizeof(float), st));
 
@@ -188,7 +365,6 @@ int32_t transform_impl(reo_ctx *c)
     DevBuf<unsigned char> &temp = c->t_temp;
     if ((rc = temp.ensure(std::max<size_t>(temp_bytes, 16)))) return rc;
 
-    const T *X = static_cast<const T *>(c->dX);
     for (int cb0 = 0; cb0 < S; cb0 += CB) {
         const int nc = std::min(CB, S - cb0);
         dim3 grid((G + 255) / 256, nc);

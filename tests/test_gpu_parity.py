@@ -419,6 +419,59 @@ def test_host_matrix_view_with_leading_dimension(pkg, oracle):
             assert np.array_equal(gt, egt) and np.array_equal(eq, eeq)
 
 
+def _counts_blocks(pkg, X, gid, ngroups, blocks, seed=3):
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X)
+        ctx.set_groups(gid, ngroups)
+        out = [ctx.pair_counts(*b) for b in blocks]
+        return out, ctx.info()
+
+
+@pytest.mark.parametrize("G", [8192, 8193, 20480, 20481, 24576, 24577])
+def test_transform_in_lds_and_segmented_agree_at_the_size_limits(pkg, oracle, G, monkeypatch):
+    """The per-sample LDS sort (<= 24 576 genes, <= 31 varying key bits) and the device-wide segmented sort
+    must give the same counts, and the oracle's, on both sides of every items-per-thread limit."""
+    S, seed = 11, 0x5EED0013
+    X = pkg.synth.t1_counts(G, S, seed)
+    gid = np.array([0, 1, 0, 1, 1, 0, 0, 1, 0, 1, 1], dtype=np.int32)
+    blocks = [(0, 40, 0, 40), (G - 40, G, G - 40, G), (G // 2, G // 2 + 24, 8, 40)]
+    monkeypatch.delenv("REO_TRANSFORM", raising=False)
+    a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
+    assert info_a["transform_in_lds"] == (1 if G <= 24576 else 0)
+    monkeypatch.setenv("REO_TRANSFORM", "segmented")
+    b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
+    assert info_b["transform_in_lds"] == 0
+    Xf = X.astype(np.float64)
+    for blk, (ga, ea), (gb, eb) in zip(blocks, a, b):
+        egt, eeq = oracle.pair_counts(Xf, gid, 2, *blk)
+        assert np.array_equal(ga, gb) and np.array_equal(ea, eb)
+        assert np.array_equal(ga, egt) and np.array_equal(ea, eeq)
+
+
+def test_transform_key_width_decides_the_path(pkg, oracle, monkeypatch):
+    """31 varying key bits still sort in LDS; 32 or more (wide integers, negative values, general
+    Float64) take the segmented sort; all of them match the oracle."""
+    monkeypatch.delenv("REO_TRANSFORM", raising=False)
+    rng = np.random.default_rng(99)
+    G, S = 700, 12
+    gid = np.array([0, 1] * 6, dtype=np.int32)
+    cases = {
+        "31 bits": (rng.integers(0, 2 ** 31, (G, S), dtype=np.int64), 1),
+        "33 bits": (rng.integers(0, 2 ** 33, (G, S), dtype=np.int64), 0),
+        "negatives": (rng.integers(-50, 50, (G, S), dtype=np.int64), 0),
+        "offset": (rng.integers(0, 1000, (G, S), dtype=np.int64) + (1 << 40), 1),   # high bits constant: still narrow
+        "floats": (rng.lognormal(2.0, 1.5, (G, S)), 0),
+        "float ranks": (rng.integers(0, 64, (G, S)).astype(np.float64) * 0.25, None),
+    }
+    for name, (X, want) in cases.items():
+        X[5] = X[6]  # some exact ties
+        (out,), info = _counts_blocks(pkg, X, gid, 2, [(0, G, 0, G)])
+        if want is not None:
+            assert info["transform_in_lds"] == want, name
+        egt, eeq = oracle.pair_counts(np.asarray(X, dtype=np.float64), gid, 2, 0, G, 0, G)
+        assert np.array_equal(out[0], egt) and np.array_equal(out[1], eeq), name
+
+
 def test_reoa_bundled_test_data_end_to_end(pkg, oracle, tmp_path):
     """BASELINE config 1: reoa(use_testdata="yes") on the reference's bundled files (README.md:26-56)."""
     seed = 0x5EED0001
