@@ -122,24 +122,6 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
     hi[o] = static_cast<float>(h + 1);
 }
 
-// Scan of the whole matrix before any sorting: non-finite flag and the key bits that vary anywhere.
-template <class T>
-__global__ __launch_bounds__(256) void t_varbits(const T *__restrict__ X, int64_t ld, int G, int32_t *__restrict__ bad,
-                                                 unsigned long long *__restrict__ varbits)
-{
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    uint64_t diff = 0;
-    if (g < G) {
-        const T x = X[static_cast<int64_t>(g) + static_cast<int64_t>(blockIdx.y) * ld];
-        if (!Codec<T>::finite(x)) atomicOr(bad, 1);
-        diff = Codec<T>::enc(x) ^ Codec<T>::enc(X[0]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
-    if ((threadIdx.x & 63) == 0 && (diff & ~__hip_atomic_load(varbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
-        atomicOr(varbits, diff);
-}
-
 // One workgroup per sample, everything in LDS: when the varying key bits fit 31 bits and the genes fit
 // 1024 x IPT items, the sample's column is read once, sorted with a block radix sort (rocprim block
 // primitive, keys in registers, exchange through LDS), the tie bands are searched in the LDS copy of the
@@ -147,11 +129,13 @@ __global__ __launch_bounds__(256) void t_varbits(const T *__restrict__ X, int64_
 // once out, instead of keys out, two sort passes in and out, keys in again.
 // Key = the varying bits (begin_bit .. begin_bit + nbits - 1) of the order-preserving code; bit `nbits`
 // marks padding items, which sort behind every gene.
+// flags: 0 non-finite input, 1 some tie, 4 some sample needs more than 31 key bits (the caller then
+// redoes the whole transform with the segmented sort).
 template <class T, int IPT>
 __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
-                                                 const int32_t *__restrict__ slots, int G, int Gp, uint64_t key0,
-                                                 unsigned begin_bit, unsigned nbits, uint16_t *__restrict__ pos,
-                                                 float *__restrict__ lo, float *__restrict__ hi, int32_t *__restrict__ anytie)
+                                                 const int32_t *__restrict__ slots, int G, int Gp,
+                                                 uint16_t *__restrict__ pos, float *__restrict__ lo,
+                                                 float *__restrict__ hi, int32_t *__restrict__ flags)
 {
     using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -159,13 +143,45 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     const int t = threadIdx.x, c = blockIdx.x;
     const T *col = X + static_cast<int64_t>(colmap[c]) * ld;
     const int slot = slots[c];
+    int32_t *anytie = flags + 1;
+    // the sample's own varying key bits (against its first gene): only those are sorted
+    const uint64_t key0 = Codec<T>::enc(col[0]);
+    uint64_t kk[IPT], diff = 0;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < IPT; ++e) {
+        const int i = e * 1024 + t;  // coalesced; which item holds which gene does not matter to the sort
+        kk[e] = key0;
+        if (i < G) {
+            const T x = col[i];
+            bad |= !Codec<T>::finite(x);
+            kk[e] = Codec<T>::enc(x);
+            diff |= kk[e] ^ key0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    unsigned long long *red = reinterpret_cast<unsigned long long *>(smem);
+    if ((t & 63) == 0) red[t >> 6] = diff;
+    if (__ballot(bad) != 0 && (t & 63) == 0) atomicOr(flags, 1);
+    __syncthreads();
+    diff = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) diff |= red[w];
+    __syncthreads();  // red is part of the sort's storage
+    const unsigned begin_bit = diff ? static_cast<unsigned>(__builtin_ctzll(diff)) : 0u;
+    const unsigned nbits = diff ? 64u - static_cast<unsigned>(__builtin_clzll(diff)) - begin_bit : 1u;
+    if (nbits > 31) {  // workgroup-uniform
+        if (t == 0) atomicOr(flags + 4, 1);
+        return;
+    }
     const uint32_t mask = (1u << nbits) - 1u;
     uint32_t k[IPT];
     uint16_t v[IPT];
 #pragma unroll
     for (int e = 0; e < IPT; ++e) {
-        const int i = e * 1024 + t;  // coalesced; which item holds which gene does not matter to the sort
-        if (i < G) { k[e] = static_cast<uint32_t>(Codec<T>::enc(col[i]) >> begin_bit) & mask; v[e] = static_cast<uint16_t>(i); }
+        const int i = e * 1024 + t;
+        if (i < G) { k[e] = static_cast<uint32_t>(kk[e] >> begin_bit) & mask; v[e] = static_cast<uint16_t>(i); }
         else { k[e] = 1u << nbits; v[e] = 0xFFFFu; }
     }
     sorter().sort(k, v, storage, 0, nbits + 1);  // blocked: item e of thread t is sorted position t * IPT + e
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
 }
 
 template <class T, int IPT>
-int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, uint64_t key0, unsigned begin_bit, unsigned nbits, int32_t *d_anytie)
+int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
 {
     using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
     const size_t lds = std::max(sizeof(typename sorter::storage_type), static_cast<size_t>(4) * c->Gp);
@@ -238,19 +254,11 @@ int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, uint64_t k
         REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp, key0,
-                                                                            begin_bit, nbits, c->pos.p, c->lo.p, c->hi.p, d_anytie);
+    t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
+                                                                            c->pos.p, c->lo.p, c->hi.p, d_flags);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
-
-inline uint64_t host_enc(double x)
-{
-    uint64_t u;
-    memcpy(&u, &x, sizeof u);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
-}
-inline uint64_t host_enc(int64_t x) { return static_cast<uint64_t>(x) ^ 0x8000000000000000ULL; }
 
 struct SegOff {
     unsigned G;
@@ -287,10 +295,10 @@ int32_t transform_impl(reo_ctx *c)
     // scratch lives in the context (grow-only): hipMalloc/hipFree per call cost milliseconds
     DevBuf<int32_t> &d_order = c->t_order, &d_flags = c->t_flags;
     int32_t rc;
-    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(4)) || (rc = c->t_slots.ensure(S))) return rc;
+    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(6)) || (rc = c->t_slots.ensure(S))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
     REO_HIP_CHECK(hipMemcpyAsync(c->t_slots.p, slots.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
-    REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 4 * sizeof(int32_t), st));
+    REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
     unsigned long long *d_varbits = reinterpret_cast<unsigned long long *>(d_flags.p + 2);
     if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff8_units.data(), sizeof(int32_t) * (c->ngroups + 1),
@@ -301,49 +309,38 @@ int32_t transform_impl(reo_ctx *c)
     REO_HIP_CHECK(hipMemsetAsync(c->pos.p, 0xFF, n * sizeof(uint16_t), st));
     const T *X = static_cast<const T *>(c->dX);
 
-    // scan: non-finite values, and which key bits vary at all (rank-like data: 15 bits)
-    {
-        dim3 grid((G + 255) / 256, S);
-        t_varbits<T><<<grid, 256, 0, st>>>(X, c->ld, G, d_flags.p, d_varbits);
-        REO_HIP_CHECK(hipGetLastError());
-        int32_t fl[4];
-        T x0;
+    // first choice: every sample sorted inside one workgroup's LDS (t_sample)
+    const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort (A/B tests)
+    c->transform_in_lds = 0;
+    if (G <= 24 * 1024 && !(env && env[0] == 's')) {
+        // rows of the padding slots of every group (at most 7 each): below no band edge
+        for (int g = 0; g < c->ngroups; ++g) {
+            const int first = c->goff8[g] + (c->goff[g + 1] - c->goff[g]), cnt = c->goff8[g + 1] - first;
+            if (cnt > 0) {
+                REO_HIP_CHECK(hipMemsetAsync(c->lo.p + static_cast<size_t>(first) * Gp, 0, static_cast<size_t>(cnt) * Gp * sizeof(float), st));
+                REO_HIP_CHECK(hipMemsetAsync(c->hi.p + static_cast<size_t>(first) * Gp, 0, static_cast<size_t>(cnt) * Gp * sizeof(float), st));
+            }
+        }
+        if (G <= 8 * 1024) rc = launch_sample<T, 8>(c, X, d_order.p, d_flags.p);
+        else if (G <= 20 * 1024) rc = launch_sample<T, 20>(c, X, d_order.p, d_flags.p);
+        else rc = launch_sample<T, 24>(c, X, d_order.p, d_flags.p);
+        if (rc) return rc;
+        int32_t fl[6];
         REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, sizeof fl, hipMemcpyDeviceToHost, st));
-        REO_HIP_CHECK(hipMemcpyAsync(&x0, X, sizeof x0, hipMemcpyDeviceToHost, st));
         REO_HIP_CHECK(hipStreamSynchronize(st));
         if (fl[0]) {
             set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
                       "src/RankCompV3.jl:601)");
             return REO_EINVAL;
         }
-        unsigned long long vb;
-        memcpy(&vb, fl + 2, sizeof vb);
-        const unsigned begin_bit = vb ? static_cast<unsigned>(__builtin_ctzll(vb)) : 0u;
-        const unsigned nbits = vb ? 64u - static_cast<unsigned>(__builtin_clzll(vb)) - begin_bit : 1u;
-        const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort (A/B tests)
-        const bool in_lds = nbits <= 31 && G <= 24 * 1024 && !(env && env[0] == 's');
-        c->transform_in_lds = in_lds ? 1 : 0;
-        if (in_lds) {
-            // rows of the padding slots of every group (at most 7 each): below no band edge
-            for (int g = 0; g < c->ngroups; ++g) {
-                const int first = c->goff8[g] + (c->goff[g + 1] - c->goff[g]), cnt = c->goff8[g + 1] - first;
-                if (cnt > 0) {
-                    REO_HIP_CHECK(hipMemsetAsync(c->lo.p + static_cast<size_t>(first) * Gp, 0, static_cast<size_t>(cnt) * Gp * sizeof(float), st));
-                    REO_HIP_CHECK(hipMemsetAsync(c->hi.p + static_cast<size_t>(first) * Gp, 0, static_cast<size_t>(cnt) * Gp * sizeof(float), st));
-                }
-            }
-            const uint64_t key0 = host_enc(x0);
-            if (G <= 8 * 1024) rc = launch_sample<T, 8>(c, X, d_order.p, key0, begin_bit, nbits, d_flags.p + 1);
-            else if (G <= 20 * 1024) rc = launch_sample<T, 20>(c, X, d_order.p, key0, begin_bit, nbits, d_flags.p + 1);
-            else rc = launch_sample<T, 24>(c, X, d_order.p, key0, begin_bit, nbits, d_flags.p + 1);
-            if (rc) return rc;
-            int32_t tie_flag = 0;
-            REO_HIP_CHECK(hipMemcpyAsync(&tie_flag, d_flags.p + 1, sizeof tie_flag, hipMemcpyDeviceToHost, st));
-            REO_HIP_CHECK(hipStreamSynchronize(st));
-            c->has_ties = tie_flag;
+        if (!fl[4]) {
+            c->has_ties = fl[1];
+            c->transform_in_lds = 1;
             c->transformed = true;
             return REO_OK;
         }
+        // some sample has keys wider than 31 bits: start over with the segmented sort
+        REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
     }
     REO_HIP_CHECK(hipMemsetAsync(c->lo.p, 0, n * sizeof(float), st));
     REO_HIP_CHECK(hipMemsetAsync(c->hi.p, 0, n * sizeof(float), st));
