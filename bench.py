@@ -42,8 +42,8 @@ VALU_CMP_PEAK = 3.93e13    # comparisons/s: 256 CU x 4 SIMD x 64 lanes x 2.4 GHz
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genes", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--family", default="t0", choices=["t0", "t1"])
