@@ -146,17 +146,19 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     int32_t *anytie = flags + 1;
     // the sample's own varying key bits (against its first gene): only those are sorted
     const uint64_t key0 = Codec<T>::enc(col[0]);
-    uint64_t kk[IPT], diff = 0;
+    constexpr bool kKeep = IPT <= 24;  // keep the 64-bit codes in registers, or read the column a second time (L2)
+    uint64_t kk[kKeep ? IPT : 1], diff = 0;
     bool bad = false;
 #pragma unroll
     for (int e = 0; e < IPT; ++e) {
         const int i = e * 1024 + t;  // coalesced; which item holds which gene does not matter to the sort
-        kk[e] = key0;
+        if (kKeep) kk[e] = key0;
         if (i < G) {
             const T x = col[i];
             bad |= !Codec<T>::finite(x);
-            kk[e] = Codec<T>::enc(x);
-            diff |= kk[e] ^ key0;
+            const uint64_t code = Codec<T>::enc(x);
+            if (kKeep) kk[e] = code;
+            diff |= code ^ key0;
         }
     }
 #pragma unroll
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
 #pragma unroll
     for (int e = 0; e < IPT; ++e) {
         const int i = e * 1024 + t;
-        if (i < G) { k[e] = static_cast<uint32_t>(kk[e] >> begin_bit) & mask; v[e] = static_cast<uint16_t>(i); }
+        if (i < G) { k[e] = static_cast<uint32_t>((kKeep ? kk[e] : Codec<T>::enc(col[i])) >> begin_bit) & mask; v[e] = static_cast<uint16_t>(i); }
         else { k[e] = 1u << nbits; v[e] = 0xFFFFu; }
     }
     sorter().sort(k, v, storage, 0, nbits + 1);  // blocked: item e of thread t is sorted position t * IPT + e
@@ -312,7 +314,7 @@ int32_t transform_impl(reo_ctx *c)
     // first choice: every sample sorted inside one workgroup's LDS (t_sample)
     const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort (A/B tests)
     c->transform_in_lds = 0;
-    if (G <= 24 * 1024 && !(env && env[0] == 's')) {
+    if (G <= 32 * 1024 && !(env && env[0] == 's')) {
         // rows of the padding slots of every group (at most 7 each): below no band edge
         for (int g = 0; g < c->ngroups; ++g) {
             const int first = c->goff8[g] + (c->goff[g + 1] - c->goff[g]), cnt = c->goff8[g + 1] - first;
@@ -323,7 +325,8 @@ int32_t transform_impl(reo_ctx *c)
         }
         if (G <= 8 * 1024) rc = launch_sample<T, 8>(c, X, d_order.p, d_flags.p);
         else if (G <= 20 * 1024) rc = launch_sample<T, 20>(c, X, d_order.p, d_flags.p);
-        else rc = launch_sample<T, 24>(c, X, d_order.p, d_flags.p);
+        else if (G <= 24 * 1024) rc = launch_sample<T, 24>(c, X, d_order.p, d_flags.p);
+        else rc = launch_sample<T, 32>(c, X, d_order.p, d_flags.p);
         if (rc) return rc;
         int32_t fl[6];
         REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, sizeof fl, hipMemcpyDeviceToHost, st));

@@ -427,9 +427,9 @@ def _counts_blocks(pkg, X, gid, ngroups, blocks, seed=3):
         return out, ctx.info()
 
 
-@pytest.mark.parametrize("G", [8192, 8193, 20480, 20481, 24576, 24577])
+@pytest.mark.parametrize("G", [8192, 8193, 20480, 20481, 24576, 24577, 32768, 32769])
 def test_transform_in_lds_and_segmented_agree_at_the_size_limits(pkg, oracle, G, monkeypatch):
-    """The per-sample LDS sort (<= 24 576 genes, <= 31 varying key bits) and the device-wide segmented sort
+    """The per-sample LDS sort (<= 32 768 genes, <= 31 varying key bits) and the device-wide segmented sort
     must give the same counts, and the oracle's, on both sides of every items-per-thread limit."""
     S, seed = 11, 0x5EED0013
     X = pkg.synth.t1_counts(G, S, seed)
@@ -437,7 +437,7 @@ def test_transform_in_lds_and_segmented_agree_at_the_size_limits(pkg, oracle, G,
     blocks = [(0, 40, 0, 40), (G - 40, G, G - 40, G), (G // 2, G // 2 + 24, 8, 40)]
     monkeypatch.delenv("REO_TRANSFORM", raising=False)
     a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
-    assert info_a["transform_in_lds"] == (1 if G <= 24576 else 0)
+    assert info_a["transform_in_lds"] == (1 if G <= 32768 else 0)
     monkeypatch.setenv("REO_TRANSFORM", "segmented")
     b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
     assert info_b["transform_in_lds"] == 0
