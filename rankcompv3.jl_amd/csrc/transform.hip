@@ -251,11 +251,8 @@ int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d
 {
     using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
     const size_t lds = std::max(sizeof(typename sorter::storage_type), static_cast<size_t>(4) * c->Gp);
-    static bool configured = false;  // per instantiation
-    if (!configured) {
-        REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    // every time: the attribute belongs to the (function, device) pair and a process may use several devices
+    REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
                                                                             c->pos.p, c->lo.p, c->hi.p, d_flags);
     REO_HIP_CHECK(hipGetLastError());
