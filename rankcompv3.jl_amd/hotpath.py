@@ -45,7 +45,6 @@ def label_genes(result: np.ndarray, pval_deg: float, padj_deg: float) -> np.ndar
 @dataclass
 class DegRun:
     """Everything the comparisons produced (the reference only keeps `res`)."""
-    res: np.ndarray                 # G x (1 + 16 C) object matrix, the reference's return value (:437)
     result: np.ndarray              # G x 15 Float64 of the first comparison
     labels: np.ndarray              # labels of the first comparison
     levels: list
@@ -55,6 +54,22 @@ class DegRun:
     timings: dict = field(default_factory=dict)
     info: dict = field(default_factory=dict)
     comparisons: list = field(default_factory=list)  # per comparison: dict(k, result, labels, iters_run, trace)
+    gene_names: object = None
+    _res: object = None
+
+    @property
+    def res(self) -> np.ndarray:
+        """G x (1 + 16 C) object matrix, the reference's return value (:430,437).  Built on first use: boxing
+        20 000 x 15 floats costs 10 ms of host time, more than the GPU spends on a small problem."""
+        if self._res is None:
+            r = self.result.shape[0]
+            res = np.empty((r, 1 + 16 * len(self.comparisons)), dtype=object)  # hcat(res, result, gene_up_down) per comparison
+            res[:, 0] = np.asarray(self.gene_names, dtype=object)
+            for q, cm in enumerate(self.comparisons):
+                res[:, 1 + 16 * q: 16 + 16 * q] = cm["result"]
+                res[:, 16 + 16 * q] = cm["labels"]
+            self._res = res
+        return self._res
 
 
 def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, *,
@@ -90,14 +105,9 @@ def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref
                           "iters_run": iters, "trace": trace})
         timings = ctx.timings() if profile else {}
         info = ctx.info()
-    res = np.empty((r, 1 + 16 * ncomp), dtype=object)  # hcat(res, result, gene_up_down) per comparison (:430)
-    res[:, 0] = np.asarray(gene_names, dtype=object)
-    for q, cm in enumerate(comps):
-        res[:, 1 + 16 * q: 16 + 16 * q] = cm["result"]
-        res[:, 16 + 16 * q] = cm["labels"]
     first = comps[0]
-    return DegRun(res=res, result=first["result"], labels=first["labels"], levels=levels, thresholds=thr,
-                  iters_run=first["iters_run"], trace=first["trace"], timings=timings, info=info, comparisons=comps)
+    return DegRun(result=first["result"], labels=first["labels"], levels=levels, thresholds=thr, iters_run=first["iters_run"],
+                  trace=first["trace"], timings=timings, info=info, comparisons=comps, gene_names=list(gene_names))
 
 
 def identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, **kw) -> np.ndarray:

@@ -98,7 +98,7 @@ def test_writers(R, pkg, tmp_path):
     res = np.zeros((2, 15))
     res[0] = [0.001, 0.01, 3, 0, 1, 0, 5, 0, 0, 2, 1, 1.5, 1.25, 0.5, 3.0]
     res[1] = [0.5, 1.0, 0, 0, 0, 0, 9, 0, 0, 0, 0, 0, 0, 0, 0]
-    run = pkg.DegRun(res=None, result=res, labels=np.array(["up", "no change"], dtype=object), levels=["x", "y"],
+    run = pkg.DegRun(result=res, labels=np.array(["up", "no change"], dtype=object), levels=["x", "y"],
                      thresholds=None, iters_run=1, comparisons=[{"k": 0, "result": res, "labels": np.array(["up", "no change"], dtype=object)}])
     df = R.write_outputs("fn_expr", prep, run, str(tmp_path))
     assert list(df.columns) == ["gene_name", "x_vs_y"] and df["x_vs_y"].tolist() == ["up", "no change"]
