@@ -2,6 +2,9 @@
 //
 //   K1  k1_pairs    pair compare -> per-group counts -> stable-REO class ->
 //                   4 bit planes per ordered pair      (src/RankCompV3.jl:363-392)
+//       k1_group_counts + k1_classify: the same for one-vs-rest over more than two groups
+//                   (:375-390) -- every group counted once, counts kept in HBM, one cheap
+//                   classification per comparison
 //   K2  k2_tally    class table x reference mask -> per-gene tallies   (:403)
 //       (delta form: the same launch updates the counters from the rows of the genes whose mask bit changed)
 //   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask, loop control (:404-425,225-259)
