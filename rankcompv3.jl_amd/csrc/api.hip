@@ -157,10 +157,10 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
     }
     if ((rc = c->raw.ensure(G * kRaw)) || (rc = c->raw_local.ensure(c->world > 1 ? G * kRaw : 1)) ||
         (rc = c->delta_list.ensure(2 * static_cast<size_t>(c->Gp))) || (rc = c->cont.ensure(G * 9)) || (rc = c->result.ensure(G * 15)) ||
-        (rc = c->sorted_d.ensure(G)) || (rc = c->sorted_p.ensure(G)) || (rc = c->rank_s.ensure(G)) ||
+        (rc = c->sorted_d.ensure((G + 63) / 64 * 64 + (G + 63) / 64)) || (rc = c->sorted_p.ensure(G)) || (rc = c->rank_s.ensure(G)) ||
         (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(64)) ||
         (rc = c->state.ensure(1)) ||
-        (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) ||
+        (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * (kSortChunk + kSortChunk / 32))) ||
         (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));

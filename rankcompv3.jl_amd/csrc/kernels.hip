@@ -839,7 +839,8 @@ constexpr int kSortThreads = kSortChunk / 4;
 
 __global__ __launch_bounds__(kSortThreads) void k3_sort_chunks(const IterState *__restrict__ st,
                                                                const double *__restrict__ d1, int G,
-                                                               double *__restrict__ cv, uint16_t *__restrict__ ci)
+                                                               double *__restrict__ cv, uint16_t *__restrict__ ci,
+                                                               double *__restrict__ splitters)
 {
     if (st->done) return;
     __shared__ double sv[kSortChunk];
@@ -890,6 +891,8 @@ __global__ __launch_bounds__(kSortThreads) void k3_sort_chunks(const IterState *
 #undef REO_CX
 #pragma unroll
     for (int e = 0; e < 4; ++e) { cv[base + x0 + e] = v[e]; ci[base + x0 + e] = static_cast<uint16_t>(id[e]); }
+    // every 32nd element once more, packed: k3_merge_rank stages these into LDS with contiguous loads
+    if ((t & 7) == 0) splitters[blockIdx.x * (kSortChunk / 32) + (t >> 3)] = v[0];
 }
 
 // Rank of an element = its position in its own chunk + the number of smaller elements in every
@@ -905,12 +908,13 @@ constexpr int kSplit = kSortChunk / 32;  // splitters per chunk
 __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *__restrict__ st, const double *__restrict__ cv,
                                                      const uint16_t *__restrict__ ci, int G, int nchunk,
                                                      int a0, int b0, uint32_t *__restrict__ rs,
-                                                     double *__restrict__ sorted_d, double *__restrict__ part)
+                                                     double *__restrict__ sorted_d, double *__restrict__ part,
+                                                     const double *__restrict__ splitters, double *__restrict__ sorted_spl)
 {
     if (st->done) return;
     __shared__ double slice[kMergeThreads / kMergeLanes];
     __shared__ double spl[(65536 / kSortChunk) * kSplit];  // [chunk][kSplit]: 2048 splitters at most (G <= 65535)
-    for (int t = threadIdx.x; t < nchunk * kSplit; t += kMergeThreads) spl[t] = cv[(t / kSplit) * kSortChunk + ((t % kSplit) << 5)];
+    for (int t = threadIdx.x; t < nchunk * kSplit; t += kMergeThreads) spl[t] = splitters[t];  // = cv[chunk][32 m], packed
     __syncthreads();
     const int e = blockIdx.x * (kMergeThreads / kMergeLanes) + threadIdx.x / kMergeLanes;  // element (position in the chunked array)
     const int sub = threadIdx.x % kMergeLanes;
@@ -948,6 +952,7 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *
         const int rank = p + count;
         rs[gene] = rank;
         sorted_d[rank] = v;
+        if ((rank & 63) == 0) sorted_spl[rank >> 6] = v;  // packed splitters for k3_abs_rank
         in = rank >= a0 && rank <= b0;  // inside the 5 %-95 % slice of :411
     }
     // moments (count, mean, M2) of this block's elements that fall into the slice; combined in k3_abs_rank
@@ -983,7 +988,8 @@ __device__ __forceinline__ int bound_2level(const double *__restrict__ a, int n,
 // rank order for the BH step.
 __global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__ st, const double *__restrict__ d1,
                                                    const uint32_t *__restrict__ rs,
-                                                   const double *__restrict__ sorted_d, int G,
+                                                   const double *__restrict__ sorted_d,
+                                                   const double *__restrict__ sorted_spl, int G,
                                                    const double *__restrict__ part, int npart,
                                                    uint32_t *__restrict__ ra, double *__restrict__ pval,
                                                    double *__restrict__ sorted_p, double *__restrict__ scal)
@@ -992,7 +998,7 @@ __global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__
     __shared__ double red[256];
     __shared__ double spl[1024];  // every 64th element of the sorted vector (G <= 65535)
     const int nspl = (G + 63) >> 6;
-    for (int t = threadIdx.x; t < nspl; t += 256) spl[t] = sorted_d[t << 6];
+    for (int t = threadIdx.x; t < nspl; t += 256) spl[t] = sorted_spl[t];  // = sorted_d[64 t], packed
     double nb = 0.0, sb = 0.0;
     for (int t = threadIdx.x; t < npart; t += 256) { const double n_ = part[3 * t]; nb += n_; sb += n_ * part[3 * t + 1]; }
     const double n = block_sum_256(nb, red);  // (also the barrier that publishes spl)
@@ -1297,11 +1303,13 @@ int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int 
     const int nchunk = (G + kSortChunk - 1) / kSortChunk;
     const int nmerge = (nchunk * kSortChunk + kMergeThreads / kMergeLanes - 1) / (kMergeThreads / kMergeLanes);
     k3_derive<<<nb, 256, 0, c->stream>>>(c->state.p, c->raw.p, c->refbytes[cur].p, G, nullptr, res, 1, c->state.p, 1 - cur);
-    k3_sort_chunks<<<nchunk, kSortThreads, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p);
+    double *chunk_spl = c->chunk_v.p + static_cast<size_t>(nchunk) * kSortChunk;  // [nchunk][kSortChunk / 32]
+    double *sorted_spl = c->sorted_d.p + ((c->G + 63) / 64) * 64;               // [ceil(G / 64)]
+    k3_sort_chunks<<<nchunk, kSortThreads, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p, chunk_spl);
     k3_merge_rank<<<nmerge, kMergeThreads, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
                                                            static_cast<int>(a - 1), static_cast<int>(b - 1),
-                                                           c->rank_s.p, c->sorted_d.p, c->part.p);
-    k3_abs_rank<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->sorted_d.p, G, c->part.p, nmerge,
+                                                           c->rank_s.p, c->sorted_d.p, c->part.p, chunk_spl, sorted_spl);
+    k3_abs_rank<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->sorted_d.p, sorted_spl, G, c->part.p, nmerge,
                                            c->rank_a.p, res, c->sorted_p.p, c->scal.p);
     k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(c->state.p, c->sorted_p.p, G, c->blockmin.p);
     k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(c->state.p, res, c->sorted_p.p, c->blockmin.p, c->rank_a.p, G,
