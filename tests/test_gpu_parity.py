@@ -659,6 +659,21 @@ def test_maximum_gene_count_65535(pkg, oracle):
         assert 1 <= iters <= 4 and np.isfinite(res).all()
 
 
+def test_full_identify_degs_at_65535_genes(pkg, oracle):
+    """The whole path at the u16 limit (G = 65535, tie-rich counts, 16 samples): transform on the segmented
+    path, tie-rich K1, 64 sort chunks in K3; trace and tallies bit-exact, statistics within tolerance."""
+    G, S, seed = 65535, 16, 0x5EED0021
+    X = pkg.synth.t1_counts(G, S, seed)
+    group = np.array(["a", "b"] * 8, dtype=object)
+    gid, lev = pkg.encode_groups(group)
+    ref0 = pkg.synth.ref_mask(G, 3000, seed)
+    run = pkg.run_identify_degs(X, group, list(range(G)), 0.05, 1.0, 0.05, ref0, 12, 5, seed=seed, device=0)
+    exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.05, 1.0, 0.05, ref0, 12, 5, seed)
+    assert run.iters_run == iters and run.trace == trace and iters >= 2
+    assert run.info["transform_in_lds"] == 0 and run.info["has_ties"] == 1
+    _check_result(run.result, exp)
+
+
 @pytest.mark.parametrize("case", ["two_samples", "one_vs_nine", "empty_ref", "full_ref", "g11", "constant", "one_group_all_ties"])
 def test_edge_cases_against_oracle(pkg, oracle, case):
     rng = np.random.default_rng(hash(case) % 2 ** 32)
