@@ -1077,10 +1077,10 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
     __shared__ double bm[64];
     if (static_cast<int>(threadIdx.x) < nb) bm[threadIdx.x] = blockmin[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) {  // tail[b] = minimum over the blocks after b
+    if (static_cast<int>(threadIdx.x) <= nb) {  // tail[b] = minimum over the blocks after b (one thread per b)
         double run = INFINITY;
-        tail[nb] = run;
-        for (int b = nb - 1; b >= 0; --b) { tail[b] = run; const double m = bm[b]; run = m < run ? m : run; }
+        for (int k = threadIdx.x + 1; k < nb; ++k) { const double m = bm[k]; run = m < run ? m : run; }
+        tail[threadIdx.x] = run;
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1106,13 +1106,19 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
         if (changed && at < kDeltaMax) dlist[at] = (static_cast<uint32_t>(i) << 1) | (ind ? 1u : 0u);
     }
     const unsigned long long m = __ballot(ind);
-    if ((threadIdx.x & 63) == 0 && i < Gp) {
-        nbits[i >> 5] = static_cast<uint32_t>(m);
-        nbits[(i >> 5) + 1] = static_cast<uint32_t>(m >> 32);
-        if (m) atomicAdd(&st->nn_acc, __popcll(m));
+    __shared__ int wave_nn[4];
+    if ((threadIdx.x & 63) == 0) {
+        if (i < Gp) {
+            nbits[i >> 5] = static_cast<uint32_t>(m);
+            nbits[(i >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+        }
+        wave_nn[threadIdx.x >> 6] = __popcll(m);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // one atomic per workgroup, not per wave: 313 serialised updates of one word were a third of this kernel
+        const int nn_blk = wave_nn[0] + wave_nn[1] + wave_nn[2] + wave_nn[3];
+        if (nn_blk) atomicAdd(&st->nn_acc, nn_blk);
         __threadfence();
         const int t = atomicAdd(&st->ticket, 1);
         if (t == static_cast<int>(gridDim.x) - 1) {
