@@ -797,16 +797,16 @@ __global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ s
     derive_gene(raw, refbytes, st->nref, G, i, cont, result, with_stats != 0);
 }
 
+// Sum over the 256 threads of a workgroup, the same bits in every thread and every workgroup: an
+// xor-butterfly inside each wave (a + b == b + a, so all lanes of a wave agree at every step), then the
+// four wave sums in a fixed order.  Two barriers (the second lets `red` be reused at once).
 __device__ __forceinline__ double block_sum_256(double v, double *red)
 {
-    red[threadIdx.x] = v;
-    __syncthreads();
 #pragma unroll
-    for (int o = 128; o > 0; o >>= 1) {
-        if (static_cast<int>(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    const double r = red[0];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = (red[0] + red[1]) + (red[2] + red[3]);
     __syncthreads();
     return r;
 }
@@ -958,13 +958,19 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *
     // moments (count, mean, M2) of this block's elements that fall into the slice; combined in k3_abs_rank
     if (sub == 0) slice[threadIdx.x / kMergeLanes] = in ? v : NAN;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double n = 0.0, sum = 0.0;
-        for (int t = 0; t < kMergeThreads / kMergeLanes; ++t) { const double x = slice[t]; if (x == x) { n += 1.0; sum += x; } }
+    if (threadIdx.x < 64) {  // first wave: fixed-order butterfly over the workgroup's elements (NaN = not in the slice)
+        constexpr int kElems = kMergeThreads / kMergeLanes;
+        static_assert(kElems <= 64, "one wave reduces the workgroup's slice values");
+        const double x = static_cast<int>(threadIdx.x) < kElems ? slice[threadIdx.x] : NAN;
+        const bool has = x == x;
+        double n = has ? 1.0 : 0.0, sum = has ? x : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n += __shfl_xor(n, o, 64); sum += __shfl_xor(sum, o, 64); }
         const double mean = n > 0.0 ? sum / n : 0.0;
-        double m2 = 0.0;
-        for (int t = 0; t < kMergeThreads / kMergeLanes; ++t) { const double x = slice[t]; if (x == x) m2 += (x - mean) * (x - mean); }
-        part[3 * blockIdx.x] = n; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = m2;
+        double m2 = has ? (x - mean) * (x - mean) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+        if (threadIdx.x == 0) { part[3 * blockIdx.x] = n; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = m2; }
     }
 }
 
