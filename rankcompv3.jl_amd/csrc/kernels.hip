@@ -1048,18 +1048,22 @@ __global__ __launch_bounds__(1024) void k3_bh_local(const IterState *__restrict_
                                                     int G, double *__restrict__ blockmin)
 {
     if (st->done) return;
-    __shared__ double red[1024];
+    __shared__ double wmin[16];
     const int r = blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double v = r < G ? sorted_p[r] * (static_cast<double>(G) / static_cast<double>(r + 1)) : INFINITY;
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const double w = threadIdx.x + o < 1024 ? red[threadIdx.x + o] : INFINITY;
-        __syncthreads();
-        v = w < v ? w : v;
-        red[threadIdx.x] = v;
-        __syncthreads();
+    // reverse cumulative minimum inside the wave (min is exact: any order gives the same bits) ...
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double w = __shfl_down(v, o, 64);
+        if (lane + o < 64) v = w < v ? w : v;
     }
+    if (lane == 0) wmin[wave] = v;  // minimum of the whole wave
+    __syncthreads();
+    // ... then over the waves behind this one
+    double t = INFINITY;
+    for (int k = wave + 1; k < 16; ++k) { const double w = wmin[k]; t = w < t ? w : t; }
+    v = t < v ? t : v;
     if (r < G) sorted_p[r] = v;
     if (threadIdx.x == 0) blockmin[blockIdx.x] = v;
 }
