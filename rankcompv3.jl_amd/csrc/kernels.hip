@@ -835,7 +835,8 @@ __device__ __forceinline__ void cmpx(double &v, uint32_t &i, double pv, uint32_t
 // (kSortChunk / 4 threads).  Exchange distances 1 and 2 stay inside the thread, distances 4..128 go
 // through wave shuffles, and only the stages with distance >= 256 (partner in another wave) use
 // LDS + a barrier.
-constexpr int kSortThreads = kSortChunk / 4;
+constexpr int kSortE = 1;  // elements per thread (K3 per 128 passes at 20 000 genes: 4 -> 6.58 ms, 2 -> 6.56, 1 -> 6.49)
+constexpr int kSortThreads = kSortChunk / kSortE;
 
 __global__ __launch_bounds__(kSortThreads) void k3_sort_chunks(const IterState *__restrict__ st,
                                                                const double *__restrict__ d1, int G,
@@ -843,56 +844,60 @@ __global__ __launch_bounds__(kSortThreads) void k3_sort_chunks(const IterState *
                                                                double *__restrict__ splitters)
 {
     if (st->done) return;
+    constexpr int E = kSortE;
     __shared__ double sv[kSortChunk];
     __shared__ uint16_t si[kSortChunk];
     const int t = threadIdx.x, base = blockIdx.x * kSortChunk;
-    const int x0 = 4 * t;  // element index of this thread's first slot
-    double v[4];
-    uint32_t id[4];
+    const int x0 = E * t;  // element index of this thread's first slot
+    double v[E];
+    uint32_t id[E];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < E; ++e) {
         v[e] = base + x0 + e < G ? d1[base + x0 + e] : INFINITY;  // padding sorts to the end of the last chunk
         id[e] = x0 + e;
     }
-#define REO_CX(a, b)                                                                      \
-    {                                                                                     \
-        const bool up_ = ((x0 + (a)) & k) == 0;                                           \
-        if ((v[a] > v[b]) == up_) {                                                       \
-            const double tv_ = v[a]; v[a] = v[b]; v[b] = tv_;                             \
-            const uint32_t ti_ = id[a]; id[a] = id[b]; id[b] = ti_;                       \
-        }                                                                                 \
-    }
     for (int k = 2; k <= kSortChunk; k <<= 1) {
-        const bool up = (x0 & k) == 0;  // for k >= 4 all four slots share the direction
-        for (int j = k >> 1; j >= 256; j >>= 1) {
-            const int m = j >> 2;  // partner thread distance (>= 64: another wave)
+        const bool up = (x0 & k) == 0;  // for k >= E all slots of a thread share the direction
+        for (int j = k >> 1; j >= 64 * E; j >>= 1) {
+            const int m = j / E;  // partner thread distance (>= 64: another wave)
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { sv[x0 + e] = v[e]; si[x0 + e] = static_cast<uint16_t>(id[e]); }
+            for (int e = 0; e < E; ++e) { sv[x0 + e] = v[e]; si[x0 + e] = static_cast<uint16_t>(id[e]); }
             __syncthreads();
-            const int px = 4 * (t ^ m);
+            const int px = E * (t ^ m);
             const bool keep_min = ((t & m) == 0) == up;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cmpx(v[e], id[e], sv[px + e], si[px + e], keep_min);
+            for (int e = 0; e < E; ++e) cmpx(v[e], id[e], sv[px + e], si[px + e], keep_min);
         }
-        for (int j = (k >> 1) < 128 ? (k >> 1) : 128; j >= 4; j >>= 1) {
-            const int m = j >> 2;  // 1..32: inside the wave
+        for (int j = (k >> 1) < 32 * E ? (k >> 1) : 32 * E; j >= E; j >>= 1) {
+            const int m = j / E;  // 1..32: inside the wave
             const bool keep_min = ((t & m) == 0) == up;
-            double pv[4];
-            uint32_t pi[4];
+            double pv[E];
+            uint32_t pi[E];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { pv[e] = __shfl_xor(v[e], m, 64); pi[e] = __shfl_xor(id[e], m, 64); }
+            for (int e = 0; e < E; ++e) { pv[e] = __shfl_xor(v[e], m, 64); pi[e] = __shfl_xor(id[e], m, 64); }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cmpx(v[e], id[e], pv[e], pi[e], keep_min);
+            for (int e = 0; e < E; ++e) cmpx(v[e], id[e], pv[e], pi[e], keep_min);
         }
-        if (k >= 4) { REO_CX(0, 2) REO_CX(1, 3) }
-        REO_CX(0, 1) REO_CX(2, 3)
+#pragma unroll
+        for (int j = E >> 1; j >= 1; j >>= 1) {  // partners inside the thread
+            if (j >= k) continue;
+#pragma unroll
+            for (int a = 0; a < E; ++a) {
+                if (a & j) continue;
+                const int b = a + j;
+                const bool up_ = ((x0 + a) & k) == 0;
+                if ((v[a] > v[b]) == up_) {
+                    const double tv = v[a]; v[a] = v[b]; v[b] = tv;
+                    const uint32_t ti = id[a]; id[a] = id[b]; id[b] = ti;
+                }
+            }
+        }
     }
-#undef REO_CX
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { cv[base + x0 + e] = v[e]; ci[base + x0 + e] = static_cast<uint16_t>(id[e]); }
+    for (int e = 0; e < E; ++e) { cv[base + x0 + e] = v[e]; ci[base + x0 + e] = static_cast<uint16_t>(id[e]); }
     // every 32nd element once more, packed: k3_merge_rank stages these into LDS with contiguous loads
-    if ((t & 7) == 0) splitters[blockIdx.x * (kSortChunk / 32) + (t >> 3)] = v[0];
+    if ((x0 & 31) == 0) splitters[blockIdx.x * (kSortChunk / 32) + (x0 >> 5)] = v[0];
 }
 
 // Rank of an element = its position in its own chunk + the number of smaller elements in every
