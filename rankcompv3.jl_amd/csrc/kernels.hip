@@ -900,6 +900,27 @@ __global__ __launch_bounds__(kSortThreads) void k3_sort_chunks(const IterState *
     if ((x0 & 31) == 0) splitters[blockIdx.x * (kSortChunk / 32) + (x0 >> 5)] = v[0];
 }
 
+// A search in a sorted array a[0..n) for the count of elements that sort before v (`<` when strict, `<=`
+// otherwise), in two levels: a coarse search over every 2^LOG-th element staged in LDS narrows it to a
+// half-open index range [l, h) of fewer than 2^LOG elements, then LOG halving steps in global memory finish.
+// The two levels are separate calls so that a thread with several searches can run their global steps in
+// lockstep: the loads of one step are independent, so k searches cost one round trip per step, not k.
+struct Range { int l, h; };
+
+template <int LOG>
+__device__ __forceinline__ Range coarse_range(const double *spl, int nspl, int n, double v, bool strict)
+{
+    int lo = 0, hi = nspl;  // splitter m = a[m << LOG]
+    while (lo < hi) { const int m = (lo + hi) >> 1; const double w = spl[m]; if (strict ? (w < v) : (w <= v)) lo = m + 1; else hi = m; }
+    if (lo == 0) return Range{0, 0};
+    return Range{((lo - 1) << LOG) + 1, min(n, lo << LOG)};
+}
+
+__device__ __forceinline__ void halve(Range &r, double w, double v, bool strict)
+{
+    if (r.l < r.h) { const int m = (r.l + r.h) >> 1; if (strict ? (w < v) : (w <= v)) r.l = m + 1; else r.h = m; }
+}
+
 // Rank of an element = its position in its own chunk + the number of smaller elements in every
 // other chunk.  A group of kMergeLanes lanes serves one element: each lane searches different
 // chunks (two-level: every 32nd element of every chunk sits in LDS as a splitter; log2(kSortChunk/32)
@@ -929,25 +950,21 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *
     const double v = live ? cv[e] : 0.0;
     int count = 0;
     if (gene < G) {
-        for (int cc = sub; cc < nchunk; cc += kMergeLanes) {
-            if (cc == c) continue;
-            const int n = min(kSortChunk, G - cc * kSortChunk);  // valid elements of that chunk
-            const double *sp = spl + cc * kSplit;
-            int a = 0, b = (n + 31) >> 5;
-            while (a < b) {  // number of splitters that sort before v
-                const int m = (a + b) >> 1;
-                const double w = sp[m];
-                if (cc < c ? (w <= v) : (w < v)) a = m + 1; else b = m;
+        // this lane's chunks, two at a time so that the five global steps of both searches overlap
+        for (int cc = sub; cc < nchunk; cc += 2 * kMergeLanes) {
+            const int c2 = cc + kMergeLanes;
+            const bool on1 = cc != c, on2 = c2 < nchunk && c2 != c;
+            const int n1 = min(kSortChunk, G - cc * kSortChunk), n2 = on2 ? min(kSortChunk, G - c2 * kSortChunk) : 0;
+            const bool s1 = cc > c, s2 = c2 > c;  // equal values of earlier chunks sort first
+            Range r1 = on1 ? coarse_range<5>(spl + cc * kSplit, (n1 + 31) >> 5, n1, v, s1) : Range{0, 0};
+            Range r2 = on2 ? coarse_range<5>(spl + c2 * kSplit, (n2 + 31) >> 5, n2, v, s2) : Range{0, 0};
+            const double *ch1 = cv + cc * kSortChunk, *ch2 = cv + (on2 ? c2 : cc) * kSortChunk;
+#pragma unroll
+            for (int step = 0; step < 5; ++step) {
+                const double w1 = ch1[min((r1.l + r1.h) >> 1, kSortChunk - 1)], w2 = ch2[min((r2.l + r2.h) >> 1, kSortChunk - 1)];
+                halve(r1, w1, v, s1); halve(r2, w2, v, s2);
             }
-            if (a == 0) continue;
-            int lo = ((a - 1) << 5) + 1, hi = min(n, a << 5);  // the answer lies in (32(a-1), 32a]
-            const double *ch = cv + cc * kSortChunk;
-            while (lo < hi) {
-                const int m = (lo + hi) >> 1;
-                const double w = ch[m];
-                if (cc < c ? (w <= v) : (w < v)) lo = m + 1; else hi = m;
-            }
-            count += lo;
+            count += r1.l + r2.l;
         }
     }
 #pragma unroll
@@ -977,19 +994,6 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *
         for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
         if (threadIdx.x == 0) { part[3 * blockIdx.x] = n; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = m2; }
     }
-}
-
-// count of elements < v (strict = true) or <= v (strict = false) in the sorted array a[0..n): a coarse
-// search over every 64th element staged in LDS, then at most six steps in global memory
-__device__ __forceinline__ int bound_2level(const double *__restrict__ a, int n, const double *spl, int nspl,
-                                            double v, bool strict)
-{
-    int lo = 0, hi = nspl;  // splitter m = a[64 m]
-    while (lo < hi) { const int m = (lo + hi) >> 1; const double w = spl[m]; if (strict ? (w < v) : (w <= v)) lo = m + 1; else hi = m; }
-    if (lo == 0) return 0;
-    int l = ((lo - 1) << 6) + 1, h = min(n, lo << 6);
-    while (l < h) { const int m = (l + h) >> 1; const double w = a[m]; if (strict ? (w < v) : (w <= v)) l = m + 1; else h = m; }
-    return l;
 }
 
 // |delta1| ranks (= rank of pval ascending), then se = std of the 5 %-95 % slice of the sorted delta1
@@ -1025,11 +1029,18 @@ __global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__
     if (i >= G) return;
     const double v = d1[i];
     const int r = rs[i];
-    const int lbv = bound_2level(sorted_d, G, spl, nspl, v, true);
-    const int ubn = bound_2level(sorted_d, G, spl, nspl, -v, false);
+    // three counts in the sorted vector: < v, <= -v, <= v; their six global steps run in lockstep
+    Range r1 = coarse_range<6>(spl, nspl, G, v, true), r2 = coarse_range<6>(spl, nspl, G, -v, false),
+          r3 = coarse_range<6>(spl, nspl, G, v, false);
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+        const double w1 = sorted_d[min((r1.l + r1.h) >> 1, G - 1)], w2 = sorted_d[min((r2.l + r2.h) >> 1, G - 1)],
+                     w3 = sorted_d[min((r3.l + r3.h) >> 1, G - 1)];
+        halve(r1, w1, v, true); halve(r2, w2, -v, false); halve(r3, w3, v, false);
+    }
+    const int lbv = r1.l, ubn = r2.l, ubv = r3.l;
     int rank;
     if (v > 0.0) {  // larger |w|: w > v or w < -v; ties: the negatives -v first, then equals of v in sorted order
-        const int ubv = bound_2level(sorted_d, G, spl, nspl, v, false);
         rank = (G - ubv) + ubn + (r - lbv);
     } else {        // larger |w|: w < v or w > -v
         rank = lbv + (G - ubn) + (r - lbv);
