@@ -133,14 +133,20 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
 // redoes the whole transform with the segmented sort).
 template <class T, int IPT>
 __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
-                                                 const int32_t *__restrict__ slots, int G, int Gp,
+                                                 const int32_t *__restrict__ slots, int G, int Gp, int S,
                                                  uint16_t *__restrict__ pos, float *__restrict__ lo,
                                                  float *__restrict__ hi, int32_t *__restrict__ flags)
 {
     using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typename sorter::storage_type &storage = *reinterpret_cast<typename sorter::storage_type *>(smem);
-    const int t = threadIdx.x, c = blockIdx.x;
+    const int t = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs.  The 8 samples of one 16-byte pos group are written
+    // as 2-byte pieces by 8 different workgroups; only when those run on the SAME XCD do the pieces meet in
+    // one L2 and leave as whole lines.  Measured WRITE_SIZE with c = blockIdx.x: 896 MB for 200 MB of output.
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int c = (((q >> 3) << 3) + xcd) * 8 + (q & 7);  // 8 consecutive workgroups of an XCD = 8 consecutive samples
+    if (c >= S) return;
     const T *col = X + static_cast<int64_t>(colmap[c]) * ld;
     const int slot = slots[c];
     int32_t *anytie = flags + 1;
@@ -253,8 +259,9 @@ int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d
     const size_t lds = std::max(sizeof(typename sorter::storage_type), static_cast<size_t>(4) * c->Gp);
     // every time: the attribute belongs to the (function, device) pair and a process may use several devices
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
-                                                                            c->pos.p, c->lo.p, c->hi.p, d_flags);
+    const unsigned grid = static_cast<unsigned>((c->S + 63) / 64 * 64);  // whole 8 x 8 (XCD, sample) groups
+    t_sample<T, IPT><<<grid, 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp, static_cast<int>(c->S),
+                                                     c->pos.p, c->lo.p, c->hi.p, d_flags);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
