@@ -230,7 +230,8 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     }
     if (tied && *anytie == 0) atomicOr(anytie, 1);
     __syncthreads();  // every search in skey is done: the space becomes lo16 / hi16 indexed by gene
-    uint16_t *lo16 = reinterpret_cast<uint16_t *>(smem), *hi16 = lo16 + Gp;
+    constexpr bool kStagePos = IPT <= 24;  // 6 bytes of LDS per gene fit beside nothing else up to 24 576 genes
+    uint16_t *lo16 = reinterpret_cast<uint16_t *>(smem), *hi16 = lo16 + Gp, *pos16 = hi16 + Gp;
     for (int g = G + t; g < Gp; g += 1024) { lo16[g] = 0; hi16[g] = 0; }  // padded genes are below no band edge
     uint16_t *prow = pos + static_cast<size_t>(slot >> 3) * Gp * 8 + (slot & 7);
 #pragma unroll
@@ -240,9 +241,12 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         const int g = v[e];
         lo16[g] = static_cast<uint16_t>(band[e] & 0xFFFFu);
         hi16[g] = static_cast<uint16_t>(band[e] >> 16);
-        prow[static_cast<size_t>(g) * 8] = static_cast<uint16_t>(p);
+        if (kStagePos) pos16[g] = static_cast<uint16_t>(p);
+        else prow[static_cast<size_t>(g) * 8] = static_cast<uint16_t>(p);
     }
     __syncthreads();
+    if (kStagePos)  // genes in order: a wave's 64 two-byte pieces fall into 16 consecutive lines, not 64 random ones
+        for (int g = t; g < G; g += 1024) prow[static_cast<size_t>(g) * 8] = pos16[g];
     float4 *lrow = reinterpret_cast<float4 *>(lo + static_cast<size_t>(slot) * Gp);
     float4 *hrow = reinterpret_cast<float4 *>(hi + static_cast<size_t>(slot) * Gp);
     for (int q = t; q < Gp / 4; q += 1024) {
@@ -256,7 +260,7 @@ template <class T, int IPT>
 int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
 {
     using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
-    const size_t lds = std::max(sizeof(typename sorter::storage_type), static_cast<size_t>(4) * c->Gp);
+    const size_t lds = std::max(sizeof(typename sorter::storage_type), static_cast<size_t>(IPT <= 24 ? 6 : 4) * c->Gp);
     // every time: the attribute belongs to the (function, device) pair and a process may use several devices
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const unsigned grid = static_cast<unsigned>((c->S + 63) / 64 * 64);  // whole 8 x 8 (XCD, sample) groups
