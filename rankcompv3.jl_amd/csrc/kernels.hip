@@ -631,8 +631,10 @@ __device__ __forceinline__ void tally_word(uint32_t cl, uint32_t ch, uint32_t tl
 
 // own: with G-sharding, one bit per 16-byte chunk of a row and per 32-row block: set iff this shard
 // wrote anything there (the rest of its table is zero and need not be read); nullptr = everything.
+// raw2 (sharded runs): a second copy of the counters, the one the all-reduce then sums in place
 __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, const uint4 *__restrict__ refbits, int G, int Wq,
-                                           const uint32_t *__restrict__ own, int own_words, int32_t *__restrict__ raw)
+                                           const uint32_t *__restrict__ own, int own_words, int32_t *__restrict__ raw,
+                                           int32_t *__restrict__ raw2)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -660,6 +662,10 @@ __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, cons
         int4 *o = reinterpret_cast<int4 *>(raw + static_cast<size_t>(row) * kRaw);
         o[0] = make_int4(c[0], c[1], c[2], c[3]);
         o[1] = make_int4(c[4], c[5], c[6], c[7]);
+        if (raw2) {
+            int4 *o2 = reinterpret_cast<int4 *>(raw2 + static_cast<size_t>(row) * kRaw);
+            o2[0] = o[0]; o2[1] = o[1];
+        }
     }
 }
 
@@ -669,7 +675,7 @@ __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, cons
 // (leaving) the reference set adds (removes), for every gene i, the class bits found at bit i of ROW j:
 // one contiguous row per changed gene instead of the whole table.  Exact (integer sums).
 __device__ __forceinline__ void delta_genes(const uint32_t *__restrict__ table, int G, int Wp, const uint32_t *__restrict__ list,
-                                            int n, int32_t *__restrict__ raw)
+                                            int n, int32_t *__restrict__ raw, int32_t *__restrict__ raw2)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= G) return;
@@ -690,21 +696,25 @@ __device__ __forceinline__ void delta_genes(const uint32_t *__restrict__ table, 
     a.x += d[0]; a.y += d[1]; a.z += d[2]; a.w += d[3];
     b.x += d[4]; b.y += d[5]; b.z += d[6]; b.w += d[7];
     o[0] = a; o[1] = b;
+    if (raw2) {
+        int4 *o2 = reinterpret_cast<int4 *>(raw2 + static_cast<size_t>(i) * kRaw);
+        o2[0] = a; o2[1] = b;
+    }
 }
 
 // The K2 stage of one pass: one launch, the device picks the form.  slot < 0: always a full scan.
 __global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st, const uint32_t *__restrict__ table,
                                                 const uint4 *__restrict__ refbits, int G, int Wp,
                                                 const uint32_t *__restrict__ own, int own_words,
-                                                int32_t *__restrict__ raw, int slot, const uint32_t *__restrict__ list,
-                                                int32_t *__restrict__ modes)
+                                                int32_t *__restrict__ raw, int32_t *__restrict__ raw2, int slot,
+                                                const uint32_t *__restrict__ list, int32_t *__restrict__ modes)
 {
     if (st->done) return;
     const int n = slot >= 0 ? st->delta_cnt[slot] : kDeltaMax + 1;
     const bool full = n > kDeltaMax;
     if (modes && blockIdx.x == 0 && threadIdx.x == 0) modes[st->passes] = full ? 1 : 0;  // for the stage timers
-    if (full) tally_rows(reinterpret_cast<const uint4 *>(table), refbits, G, Wp / 4, own, own_words, raw);
-    else if (static_cast<int>(blockIdx.x) * 256 < G) delta_genes(table, G, Wp, list, n, raw);
+    if (full) tally_rows(reinterpret_cast<const uint4 *>(table), refbits, G, Wp / 4, own, own_words, raw, raw2);
+    else if (static_cast<int>(blockIdx.x) * 256 < G) delta_genes(table, G, Wp, list, n, raw, raw2);
 }
 
 // ---------------------------------------------------------------------------
@@ -1306,14 +1316,13 @@ int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits, int slot, bool allow_de
     tic(c, 2);
     k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(c->state.p, c->table.p, reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp,
                                                  c->world > 1 ? c->own_mask.p : nullptr, c->own_words, raw,
+                                                 c->world > 1 ? c->raw.p : nullptr,  // the copy the all-reduce sums in place
                                                  allow_delta ? slot : -1,
                                                  allow_delta ? c->delta_list.p + static_cast<size_t>(slot) * c->Gp : nullptr,
                                                  allow_delta ? c->modes.p : nullptr);
     toc(c);
     c->t_ms[4] += 1.0;
     REO_HIP_CHECK(hipGetLastError());
-    if (c->world > 1)
-        REO_HIP_CHECK(hipMemcpyAsync(c->raw.p, c->raw_local.p, sizeof(int32_t) * kRaw * c->G, hipMemcpyDeviceToDevice, c->stream));
     return REO_OK;
 }
 
