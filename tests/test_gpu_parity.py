@@ -472,6 +472,38 @@ def test_transform_key_width_decides_the_path(pkg, oracle, monkeypatch):
         assert np.array_equal(out[0], egt) and np.array_equal(out[1], eeq), name
 
 
+def test_plain_c_client_of_the_abi(pkg, oracle, tmp_path):
+    """include/reo_hip.h from a C program (no Python, no torch in that process): compile tests/abi/abi_client.c
+    with gcc, run it, and compare what it prints with the oracle and with the ctypes path."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "rankcompv3.jl_amd")
+    exe = str(tmp_path / "abi_client")
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    subprocess.run([gcc, "-O1", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi", "abi_client.c"),
+                    "-L" + libdir, "-lreo_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    G, S, seed = 300, 26, 0x5EED0031
+    X = pkg.synth.t1_counts(G, S, seed)
+    gid = np.array([0, 1] * 13, dtype=np.int32)
+    ref0 = pkg.synth.ref_mask(G, 90, seed)
+    text = "%d %d 2 %d 0.05 1.0 0.05 9 1\n" % (G, S, seed)
+    text += " ".join(map(str, gid)) + "\n" + " ".join(str(int(v)) for v in ref0) + "\n"
+    text += " ".join(map(str, np.asfortranarray(X).ravel(order="F"))) + "\n"
+    out = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    passes = int(lines[0].split()[1])
+    trace = [tuple(int(v) for v in ln.split()[1:]) for ln in lines[1:1 + passes]]
+    res = np.array([[float(v) for v in ln.split()] for ln in lines[1 + passes:]])
+    exp, iters, etrace = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.05, 1.0, 0.05, ref0, 9, 1, seed)
+    assert passes == iters and trace == etrace
+    _check_result(res, exp)
+    run = pkg.run_identify_degs(X, gid, list(range(G)), 0.05, 1.0, 0.05, ref0, 9, 1, seed=seed, device=0)
+    assert np.array_equal(res, run.result), "the C client and the ctypes path must agree to the last bit"
+
+
 def test_reoa_bundled_test_data_end_to_end(pkg, oracle, tmp_path):
     """BASELINE config 1: reoa(use_testdata="yes") on the reference's bundled files (README.md:26-56)."""
     seed = 0x5EED0001
