@@ -118,6 +118,35 @@ __device__ __forceinline__ void acc4v(float2v &c0, float2v &c1, float2v a0, floa
             : "v"(a0), "v"(a1), "v"(bb));
 }
 
+// acc4v for two lane operands at once (RJ = 2): one asm statement of eight instructions, four independent chains
+template <bool HI>
+__device__ __forceinline__ void acc8v(float2v &c0, float2v &c1, float2v &d0, float2v &d1, float2v a0, float2v a1, float2v bb0, float2v bb1)
+{
+    float2v t0, t1, t2, t3;
+    if (HI)
+        asm("v_pk_add_f32 %4, %8, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %5, %9, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %6, %8, %11 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %7, %9, %11 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %0, %0, %4\n\t"
+            "v_pk_add_f32 %1, %1, %5\n\t"
+            "v_pk_add_f32 %2, %2, %6\n\t"
+            "v_pk_add_f32 %3, %3, %7"
+            : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(a0), "v"(a1), "v"(bb0), "v"(bb1));
+    else
+        asm("v_pk_add_f32 %4, %8, %10 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %5, %9, %10 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %6, %8, %11 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %7, %9, %11 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+            "v_pk_add_f32 %0, %0, %4\n\t"
+            "v_pk_add_f32 %1, %1, %5\n\t"
+            "v_pk_add_f32 %2, %2, %6\n\t"
+            "v_pk_add_f32 %3, %3, %7"
+            : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(a0), "v"(a1), "v"(bb0), "v"(bb1));
+}
+
 typedef float float4v __attribute__((ext_vector_type(4)));
 constexpr int kStage = 32;  // sample slots per LDS stage of the band edges
 
@@ -184,10 +213,15 @@ __device__ __forceinline__ void count_pass_lds(const uint4 *__restrict__ pos8, c
                     for (int q = 0; q < 8; ++q) {
                         const float4v a = al[srel * 8 + q];  // broadcast read: every lane the same address
                         const float2v a0 = {a.x, a.y}, a1 = {a.z, a.w};
+                        if (RJ == 2) {
+                            if (half) acc8v<true>(gt[0][2 * q], gt[0][2 * q + 1], gt[RJ - 1][2 * q], gt[RJ - 1][2 * q + 1], a0, a1, bb[0], bb[RJ - 1]);
+                            else acc8v<false>(gt[0][2 * q], gt[0][2 * q + 1], gt[RJ - 1][2 * q], gt[RJ - 1][2 * q + 1], a0, a1, bb[0], bb[RJ - 1]);
+                        } else {
 #pragma unroll
-                        for (int r = 0; r < RJ; ++r) {
-                            if (half) acc4v<true>(gt[r][2 * q], gt[r][2 * q + 1], a0, a1, bb[r]);
-                            else acc4v<false>(gt[r][2 * q], gt[r][2 * q + 1], a0, a1, bb[r]);
+                            for (int r = 0; r < RJ; ++r) {
+                                if (half) acc4v<true>(gt[r][2 * q], gt[r][2 * q + 1], a0, a1, bb[r]);
+                                else acc4v<false>(gt[r][2 * q], gt[r][2 * q + 1], a0, a1, bb[r]);
+                            }
                         }
                         if (TIES) {
                             const float4v h = ah[srel * 8 + q];
