@@ -245,6 +245,51 @@ def test_full_size_properties_20000x1000(pkg):
         assert (np.diff(res[o, 1]) >= -1e-15).all() and (res[:, 1] >= res[:, 0] - 1e-15).all()
 
 
+def _expected_block_codes(oracle, X, gid, thr, seed, i0, i1, j0, j1):
+    """Class codes of a block of ordered pairs from the oracle's counts and tie coins (two groups, k = 0)."""
+    gt, eq = oracle.pair_counts(X, gid, 2, i0, i1, j0, j1)
+    sizes = np.bincount(gid, minlength=2)
+    out = np.empty((i1 - i0, j1 - j0), dtype=np.uint8)
+    for a in range(i1 - i0):
+        for b in range(j1 - j0):
+            i, j = i0 + a, j0 + b
+            if i == j:
+                out[a, b] = 255
+                continue
+            lo, hi = (i, j) if i < j else (j, i)  # the reference evaluates the pair with the smaller gene first (:366-392)
+            g2, e2 = (gt[a, b], eq[a, b]) if i < j else (None, None)
+            if i > j:  # counts of the ordered pair (lo, hi)
+                g2 = sizes - gt[a, b] - eq[a, b]
+                e2 = eq[a, b]
+            st = []
+            for g in range(2):
+                n = int(g2[g]) + (oracle.tie_wins(seed, lo, hi, g, int(e2[g])) if e2[g] else 0)
+                m = int(thr[0, 0]) if g == 0 else int(thr[1, 0])
+                st.append(2 if n >= m else (0 if sizes[g] - n >= m else 1))
+            c = 3 * st[0] + st[1]
+            out[a, b] = c if i < j else 8 - c
+    return out
+
+
+@pytest.mark.parametrize("family", ["t0", "t1"])
+def test_full_size_class_codes_on_sampled_blocks(pkg, oracle, family):
+    """BASELINE config 3 size: the class table of the production pair kernel against codes derived from the
+    oracle's counts and tie coins, on blocks far from the diagonal, on it, and in the padded last chunk."""
+    G, S, seed = 20000, 1000, 0x5EED0003
+    X = (pkg.synth.t0_ranks if family == "t0" else pkg.synth.t1_counts)(G, S, seed)
+    group = pkg.synth.groups(S)
+    ctx, gid, ng = _setup(pkg, X, group, seed)
+    Xf = np.asfortranarray(X.astype(np.float64))
+    with ctx:
+        thr = ctx.get_thresholds()
+        ctx.build_pairs(0)
+        assert ctx.info()["has_ties"] == (0 if family == "t0" else 1)
+        for (i0, j0, n) in [(0, 19960, 40), (10000, 10000, 48), (19952, 19952, 48), (777, 15000, 32), (15000, 777, 32), (19968, 31, 32)]:
+            got = ctx.get_codes(i0, i0 + n, j0, j0 + n)
+            exp = _expected_block_codes(oracle, Xf, gid, thr, seed, i0, i0 + n, j0, j0 + n)
+            assert np.array_equal(got, exp), (family, i0, j0)
+
+
 def test_two_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle):
     """G-sharding: two contexts (shards 0/2 and 1/2) on one GPU, their all-reduce hooks joined by a
     thread barrier.  Owned pairs carry the oracle's codes, the others are empty, and the summed
