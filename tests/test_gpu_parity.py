@@ -245,10 +245,13 @@ def test_full_size_properties_20000x1000(pkg):
         assert (np.diff(res[o, 1]) >= -1e-15).all() and (res[:, 1] >= res[:, 0] - 1e-15).all()
 
 
-def _expected_block_codes(oracle, X, gid, thr, seed, i0, i1, j0, j1):
-    """Class codes of a block of ordered pairs from the oracle's counts and tie coins (two groups, k = 0)."""
-    gt, eq = oracle.pair_counts(X, gid, 2, i0, i1, j0, j1)
-    sizes = np.bincount(gid, minlength=2)
+def _expected_block_codes(oracle, X, gid, thr, seed, i0, i1, j0, j1, ngroups=2, k=0):
+    """Class codes of a block of ordered pairs from the oracle's counts and tie coins: comparison k =
+    group k against every other sample (:374-377); thr is the 2 x ngroups threshold matrix (:362)."""
+    gt, eq = oracle.pair_counts(X, gid, ngroups, i0, i1, j0, j1)
+    sizes = np.bincount(gid, minlength=ngroups)
+    S = int(sizes.sum())
+    m1, m2 = int(thr[0, k]), int(thr[1, k])
     out = np.empty((i1 - i0, j1 - j0), dtype=np.uint8)
     for a in range(i1 - i0):
         for b in range(j1 - j0):
@@ -257,16 +260,14 @@ def _expected_block_codes(oracle, X, gid, thr, seed, i0, i1, j0, j1):
                 out[a, b] = 255
                 continue
             lo, hi = (i, j) if i < j else (j, i)  # the reference evaluates the pair with the smaller gene first (:366-392)
-            g2, e2 = (gt[a, b], eq[a, b]) if i < j else (None, None)
-            if i > j:  # counts of the ordered pair (lo, hi)
-                g2 = sizes - gt[a, b] - eq[a, b]
-                e2 = eq[a, b]
-            st = []
-            for g in range(2):
-                n = int(g2[g]) + (oracle.tie_wins(seed, lo, hi, g, int(e2[g])) if e2[g] else 0)
-                m = int(thr[0, 0]) if g == 0 else int(thr[1, 0])
-                st.append(2 if n >= m else (0 if sizes[g] - n >= m else 1))
-            c = 3 * st[0] + st[1]
+            g2 = gt[a, b].astype(np.int64) if i < j else sizes - gt[a, b] - eq[a, b]  # counts of the ordered pair (lo, hi)
+            e2 = eq[a, b]
+            nre = [int(g2[g]) + (oracle.tie_wins(seed, lo, hi, g, int(e2[g])) if e2[g] else 0) for g in range(ngroups)]
+            nk, nt = nre[k], sum(nre) - nre[k]
+            sk, st_ = int(sizes[k]), S - int(sizes[k])
+            ic = 2 if nk >= m1 else (0 if sk - nk >= m1 else 1)
+            it = 2 if nt >= m2 else (0 if st_ - nt >= m2 else 1)
+            c = 3 * ic + it
             out[a, b] = c if i < j else 8 - c
     return out
 
@@ -288,6 +289,24 @@ def test_full_size_class_codes_on_sampled_blocks(pkg, oracle, family):
             got = ctx.get_codes(i0, i0 + n, j0, j0 + n)
             exp = _expected_block_codes(oracle, Xf, gid, thr, seed, i0, i0 + n, j0, j0 + n)
             assert np.array_equal(got, exp), (family, i0, j0)
+
+
+def test_full_size_one_vs_rest_codes_on_sampled_blocks(pkg, oracle):
+    """Three groups at 20 000 genes: the shared per-group counts + classification kernels against codes derived
+    from the oracle's counts and tie coins, every comparison, blocks far from / on the diagonal and in the padding."""
+    G, S, seed, C = 20000, 150, 0x5EED0041, 3
+    X = pkg.synth.t1_counts(G, S, seed)
+    gid = (np.arange(S) % C).astype(np.int32)
+    Xf = np.asfortranarray(X.astype(np.float64))
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, C); thr = ctx.compute_thresholds(0.05)
+        for k in (1, 0, 2):
+            ctx.build_pairs(k)
+            assert ctx.info()["shared_group_counts"] == 1
+            for (i0, j0, n) in [(0, 19968, 32), (10016, 10016, 40), (19960, 19960, 40), (15000, 777, 24)]:
+                got = ctx.get_codes(i0, i0 + n, j0, j0 + n)
+                exp = _expected_block_codes(oracle, Xf, gid, thr, seed, i0, i0 + n, j0, j0 + n, ngroups=C, k=k)
+                assert np.array_equal(got, exp), (k, i0, j0)
 
 
 def test_two_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle):
