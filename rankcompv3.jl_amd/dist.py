@@ -26,15 +26,25 @@ def allreduce_hook(device=None, group=None, via_host: bool = False):
     import torch
     import torch.distributed as dist
 
+    cache: dict = {}  # (ptr, count, stream) -> (stream object, tensor view): the library passes the same triple every pass
+
     def fn(ptr: int, count: int, stream: int = 0) -> None:
         if device is None:
             buf = (ctypes.c_int32 * count).from_address(ptr)
             t = torch.from_numpy(np.ctypeslib.as_array(buf))
             dist.all_reduce(t, group=group)
             return
-        ext = torch.cuda.ExternalStream(stream, device=device) if stream else torch.cuda.current_stream(device)
+        key = (ptr, count, stream)
+        hit = cache.get(key)
+        if hit is None:  # wrapping the raw pointer costs tens of microseconds; a step calls the hook 128 times
+            ext = torch.cuda.ExternalStream(stream, device=device) if stream else torch.cuda.current_stream(device)
+            with torch.cuda.stream(ext):
+                t = torch.as_tensor(_RawDev(ptr, count), device=device)
+            if len(cache) > 16:
+                cache.clear()
+            hit = cache[key] = (ext, t)
+        ext, t = hit
         with torch.cuda.stream(ext):
-            t = torch.as_tensor(_RawDev(ptr, count), device=device)
             if via_host:
                 ext.synchronize()
                 h = t.cpu()

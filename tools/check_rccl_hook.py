@@ -39,4 +39,20 @@ with pkg.Context(device=0, seed=seed) as ctx:
     cont = ctx.tally(ref)
     res, iters, trace = ctx.identify_degs(ref, 1.0, 0.05, 6, 1)
     print("rccl hook ok: tally rows", cont.shape, "passes", iters, "trace", trace[-1])
+# cost of the hook per pass at bench size: shard 0 of a forced 2-shard context, 128 forced passes, against the
+# same shard with a no-op hook (the single-rank RCCL all-reduce moves no data: what is measured is the enqueue path)
+import time
+G, S, seed = 20000, 1000, 0x5EED0003
+X = pkg.synth.t0_ranks(G, S, seed); gid, lev = pkg.encode_groups(pkg.synth.groups(S)); ref = pkg.synth.ref_mask(G, 3000, seed)
+for name, h in (("no-op hook", lambda ptr, count, stream=0: None), ("RCCL hook  ", hook)):
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+        ctx.set_shard(0, 2); ctx.set_allreduce(h)
+        ctx.build_pairs(0)
+        best = 1e9
+        for rep in range(4):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            res, iters, trace = ctx.identify_degs(ref, 1.0, 0.05, 128, 0)
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        print("%s: 128 passes %.2f ms = %.1f us per pass" % (name, best * 1e3, best * 1e6 / 128))
 dist.destroy_process_group()
