@@ -168,7 +168,7 @@ def main() -> None:
                    "genes": G, "samples": S, "iterations": iters, "sharding": f"pair tiles over {world} GPU(s)"},
         "converged": {"value": units * max(1, args.steps) / dtc, "ms_per_step": dtc / max(1, args.steps) * 1e3,
                       "n_conv": 5, "iterations": iters_c, "final_trace": list(trace_c[-1]) if trace_c else None},
-        "stages_ms_per_step": {k: tm[k] / args.steps for k in ("transform_ms", "k1_ms", "k2_ms", "k2_full_ms", "k2_delta_ms", "k3_ms", "iter_ms", "allreduce_ms")},
+        "stages_ms_per_step": {k: tm[k] / args.steps for k in ("transform_ms", "k1_ms", "k2_ms", "k2_full_ms", "k2_delta_ms", "k3_ms", "iter_ms", "exchange_ms")},
         "roofline": dominant, "roofline_k1": k1, "roofline_k2": k2,
         "final_trace": list(trace[-1]) if trace else None,
         "has_ties": info["has_ties"],

@@ -37,7 +37,7 @@ enum reo_status {
     REO_OK = 0,
     REO_EINVAL = -1, /* bad argument / shape mismatch / reference error path */
     REO_EHIP = -2,   /* HIP runtime failure (including "no GPU")           */
-    REO_ECOMM = -3,  /* the all-reduce hook reported failure               */
+    REO_ECOMM = -3,  /* RCCL or the all-reduce hook failed / table not exchanged */
     REO_ENOMEM = -4  /* host or device allocation failed                   */
 };
 
@@ -55,21 +55,38 @@ const char *reo_last_error(void);
 int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed);
 void reo_destroy(reo_ctx *ctx);
 
-/* G-sharding for multi-GPU runs (one context per GPU): this context builds
- * and tallies only the pair tiles it owns out of `world` shards.  Default
- * (0, 1) = everything.  Replaces nothing in the reference (it has no
- * multi-device path); see DESIGN.md "Multi-GPU". */
+/* ---- several GPUs ---------------------------------------------------------------------------------------
+ * The reference is one process with shared-memory threads (src/RankCompV3.jl:368,402) and has no multi-device
+ * path; this is the build's own.  The pair tiles of the G x G triangle are dealt to `world` shards; every shard
+ * builds the class-table words of its tiles, ONE integer sum per class table (the shards' bits are disjoint)
+ * gives every shard the whole table, and the iteration passes run with no further collective.
+ *
+ * (a) one process, all GPUs: reo_create_multi(&ctx, n_gpus (0 = all visible), seed) returns a context that is
+ *     used exactly like a one-GPU context; it drives one device context each, sums the tables onto device 0
+ *     with RCCL (ncclReduce) inside reo_build_pairs and runs the passes there.
+ * (b) one process per GPU: rank 0 calls reo_comm_unique_id and hands the 128 bytes to the other ranks by any
+ *     means; every rank calls reo_comm_init_rank(ctx, id, rank, world) (ncclCommInitRank + reo_set_shard).
+ *     reo_build_pairs then ends with an ncclAllReduce of the table on the context's stream; all ranks get
+ *     identical results.
+ * (c) bring your own collective: reo_set_shard + reo_set_allreduce (hook below).  */
+enum { REO_UNIQUE_ID_BYTES = 128 };
+int32_t reo_create_multi(reo_ctx **out, int32_t n_gpus, uint64_t seed);
+int32_t reo_comm_unique_id(void *id /* REO_UNIQUE_ID_BYTES */);
+int32_t reo_comm_init_rank(reo_ctx *ctx, const void *id, int32_t rank, int32_t world);
+
+/* This context builds only the pair tiles it owns out of `world` shards.  Default (0, 1) = everything.
+ * With world > 1 and neither a communicator nor a hook attached, reo_build_pairs leaves the shard's own part
+ * of the table (reo_get_codes shows it; pairs of other shards read as class 4) and reo_tally /
+ * reo_identify_degs refuse with REO_ECOMM. */
 int32_t reo_set_shard(reo_ctx *ctx, int32_t rank, int32_t world);
 
-/* Hook called once per pass, between the tally kernel and the statistics kernels, when world > 1:
- * it must arrange for `count` int32 values at device pointer `dev_buf` to be summed in place across
- * all shards, ORDERED ON `stream` (a hipStream_t): everything the library enqueued on `stream` before
- * the call has to precede the sum, and the sum has to precede whatever is enqueued on `stream`
- * afterwards.  The library does not synchronise the host around the call, so a hook that enqueues
+/* Hook called once per reo_build_pairs when world > 1 and no communicator is attached: it must arrange for
+ * `count` int32 values at device pointer `dev_buf` (the class table) to be summed in place across all shards,
+ * ORDERED ON `stream` (a hipStream_t): everything the library enqueued on `stream` before the call has to
+ * precede the sum, and the sum has to precede whatever is enqueued on `stream` afterwards.  A hook that enqueues
  * the collective on `stream` (RCCL ncclAllReduce(..., stream), or torch.distributed.all_reduce under
- * torch.cuda.stream(ExternalStream(stream))) keeps whole batches of passes in flight; a hook that
- * works on the host must synchronise `stream` itself before and after.  Return 0 on success.  Every
- * shard must call its hook the same number of times (they do: all shards see identical data). */
+ * torch.cuda.stream(ExternalStream(stream))) needs no host synchronisation; a hook that works on the host must
+ * synchronise `stream` itself before and after.  Return 0 on success. */
 typedef int32_t (*reo_allreduce_fn)(void *dev_buf, int64_t count, void *stream, void *user);
 int32_t reo_set_allreduce(reo_ctx *ctx, reo_allreduce_fn fn, void *user);
 
@@ -109,8 +126,8 @@ int32_t reo_build_pairs(reo_ctx *ctx, int32_t k);
 /* Parity hook: deterministic per-pair per-group counts for the ordered pairs
  * (i, j), i in [i0,i1), j in [j0,j1): n_gt = #samples with x_i > x_j and not
  * tied, n_eq = #tied samples (|x_i - x_j| < 0.1, src/RankCompV3.jl:72), each
- * laid out [(i-i0)][(j-j0)][group].  Computed by the same device loop as
- * reo_build_pairs.  Needs matrix + groups only. */
+ * laid out [(i-i0)][(j-j0)][group].  Computed from the same bit planes with the
+ * same borrow chain as reo_build_pairs.  Needs matrix + groups only. */
 int32_t reo_pair_counts(reo_ctx *ctx, int64_t i0, int64_t i1, int64_t j0, int64_t j1,
                         uint16_t *n_gt, uint16_t *n_eq);
 
@@ -167,7 +184,7 @@ int32_t reo_pseudobulk_csc_i64(reo_ctx *ctx, int64_t G, int64_t C, const int64_t
  * kernel K1, 2 tally stage K2 (full scan or incremental update, sum), 3 iteration passes in total (K2 + the
  * statistics kernels K3, sum), 4 number of K2 launches (passes enqueued after
  * convergence return at once and are counted too), 5 number of K1 launches,
- * 6 all-reduce hook wall time, 7 pseudo-bulk kernel, 8 K2 stage of the passes that scanned the whole table (sum), 9 their
+ * 6 exchange of the class table between shards (HIP events), 7 pseudo-bulk kernel, 8 K2 stage of the passes that scanned the whole table (sum), 9 their
  * number, 10 K2 stage of the passes that updated the tallies incrementally (sum). */
 enum { REO_NTIMINGS = 12 };
 int32_t reo_set_profiling(reo_ctx *ctx, int32_t on);

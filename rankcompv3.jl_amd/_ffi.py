@@ -21,6 +21,7 @@ NTIMINGS = 12
 # every symbol include/reo_hip.h declares
 SYMBOLS = [
     "reo_version", "reo_last_error", "reo_create", "reo_destroy", "reo_set_shard", "reo_set_allreduce",
+    "reo_create_multi", "reo_comm_unique_id", "reo_comm_init_rank",
     "reo_set_matrix_f64", "reo_set_matrix_i64", "reo_set_matrix_dev_f64", "reo_set_matrix_dev_i64",
     "reo_set_groups", "reo_compute_thresholds", "reo_set_thresholds", "reo_get_thresholds", "reo_threshold",
     "reo_build_pairs", "reo_pair_counts", "reo_get_codes", "reo_tally", "reo_identify_degs", "reo_mccullagh",
@@ -79,6 +80,9 @@ def lib() -> ctypes.CDLL:
         "reo_create": (i32, [ctypes.POINTER(vp), i32, u64]),
         "reo_destroy": (None, [vp]),
         "reo_set_shard": (i32, [vp, i32, i32]),
+        "reo_create_multi": (i32, [ctypes.POINTER(vp), i32, u64]),
+        "reo_comm_unique_id": (i32, [vp]),
+        "reo_comm_init_rank": (i32, [vp, vp, i32, i32]),
         "reo_set_allreduce": (i32, [vp, ALLREDUCE_FN, vp]),
         "reo_set_matrix_f64": (i32, [vp, vp, i64, i64, i64]),
         "reo_set_matrix_i64": (i32, [vp, vp, i64, i64, i64]),
@@ -130,13 +134,26 @@ def _ptr(a: np.ndarray) -> int:
     return a.ctypes.data
 
 
-class Context:
-    """One reo_ctx: one GPU, one expression matrix."""
+UNIQUE_ID_BYTES = 128
 
-    def __init__(self, device: int = -1, seed: int = 0):
+
+def comm_unique_id() -> bytes:
+    """reo_comm_unique_id: the 128 bytes rank 0 hands to every rank of a one-process-per-GPU run."""
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    check(lib().reo_comm_unique_id(buf))
+    return buf.raw
+
+
+class Context:
+    """One reo_ctx: one GPU (or, with n_gpus, all GPUs of this process behind one handle), one expression matrix."""
+
+    def __init__(self, device: int = -1, seed: int = 0, n_gpus: int | None = None):
         self._h = ctypes.c_void_p()
         self._L = lib()
-        check(self._L.reo_create(ctypes.byref(self._h), int(device), int(seed) & 0xFFFFFFFFFFFFFFFF))
+        if n_gpus is None:
+            check(self._L.reo_create(ctypes.byref(self._h), int(device), int(seed) & 0xFFFFFFFFFFFFFFFF))
+        else:  # reo_create_multi: 0 = all visible devices
+            check(self._L.reo_create_multi(ctypes.byref(self._h), int(n_gpus), int(seed) & 0xFFFFFFFFFFFFFFFF))
         self._keep = []  # keeps callbacks / device tensors alive
         self.G = self.S = 0
         self.ngroups = 0
@@ -206,9 +223,15 @@ class Context:
     def set_shard(self, rank: int, world: int) -> None:
         check(self._L.reo_set_shard(self._h, int(rank), int(world)))
 
+    def comm_init_rank(self, unique_id: bytes, rank: int, world: int) -> None:
+        """In-library RCCL: join the communicator of `unique_id` as shard `rank` of `world` (sets the shard too)."""
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise DimensionMismatch(REO_EINVAL, "unique id must be 128 bytes")
+        check(self._L.reo_comm_init_rank(self._h, ctypes.c_char_p(unique_id), int(rank), int(world)))
+
     def set_allreduce(self, fn) -> None:
-        """fn(dev_ptr: int, count: int, stream: int) -> None: sum int32[count] in place across shards,
-        ordered on the HIP stream `stream` (see include/reo_hip.h)."""
+        """fn(dev_ptr: int, count: int, stream: int) -> None: sum int32[count] (the class table) in place across
+        shards, ordered on the HIP stream `stream` (see include/reo_hip.h)."""
         def _cb(ptr, count, stream, _user):
             try:
                 fn(int(ptr), int(count), int(stream or 0))
@@ -302,7 +325,7 @@ class Context:
         ms = np.zeros(NTIMINGS, dtype=np.float64)
         check(self._L.reo_get_timings(self._h, _ptr(ms), NTIMINGS))
         return {"transform_ms": ms[0], "k1_ms": ms[1], "k2_ms": ms[2], "iter_ms": ms[3], "k3_ms": max(ms[3] - ms[2], 0.0), "k2_launches": int(ms[4]),
-                "k1_launches": int(ms[5]), "allreduce_ms": ms[6], "pseudobulk_ms": ms[7], "k2_full_ms": ms[8],
+                "k1_launches": int(ms[5]), "exchange_ms": ms[6], "pseudobulk_ms": ms[7], "k2_full_ms": ms[8],
                 "k2_full_launches": int(ms[9]), "k2_delta_ms": ms[10]}
 
     def info(self) -> dict:

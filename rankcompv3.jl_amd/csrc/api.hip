@@ -141,8 +141,7 @@ static int32_t ensure_transform(reo_ctx *c)
         return REO_EINVAL;
     }
     if (c->transformed) return REO_OK;
-    constexpr int kPad = kTileJ * (kRJ > kRJTies ? kRJ : kRJTies);
-    c->Gp = static_cast<int>((c->G + kPad - 1) / kPad) * kPad;  // every lane's genes exist
+    c->Gp = static_cast<int>((c->G + kGenePad - 1) / kGenePad) * kGenePad;  // every lane's genes exist
     c->Wp = c->Gp / 32;
     return run_transform(c);
 }
@@ -155,7 +154,7 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         if ((rc = c->refbits[t].ensure(c->Wp))) return rc;
         if ((rc = c->refbytes[t].ensure(c->Gp))) return rc;
     }
-    if ((rc = c->raw.ensure(G * kRaw)) || (rc = c->raw_local.ensure(c->world > 1 ? G * kRaw : 1)) ||
+    if ((rc = c->raw.ensure(G * kRaw)) ||
         (rc = c->delta_list.ensure(2 * static_cast<size_t>(c->Gp))) || (rc = c->cont.ensure(G * 9)) || (rc = c->result.ensure(G * 15)) ||
         (rc = c->sorted_d.ensure((G + 63) / 64 * 64 + (G + 63) / 64)) || (rc = c->sorted_p.ensure(G)) || (rc = c->rank_s.ensure(G)) ||
         (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(64)) ||
@@ -188,14 +187,36 @@ static int32_t init_state(reo_ctx *c, int32_t nref)
     return REO_OK;
 }
 
-static int32_t allreduce_raw(reo_ctx *c)
+// Several shards (world > 1): every shard has built the class-table words of its own pair tiles and left the rest
+// zero; the bits are disjoint, so an integer sum over the shards IS the whole table.  One exchange per class table
+// (in-library RCCL all-reduce when a communicator is attached, else the caller's hook); after it every shard holds
+// the complete table and runs the iteration passes on its own, with no further collective.
+static int32_t exchange_table(reo_ctx *c)
 {
+    c->table_complete = c->world <= 1;
     if (c->world <= 1) return REO_OK;
-    if (!c->ar) { set_error("world = %d but no all-reduce hook is set (reo_set_allreduce)", c->world); return REO_ECOMM; }
-    const auto t0 = std::chrono::steady_clock::now();
-    const int32_t rc = c->ar(c->raw.p, c->G * kRaw, c->stream, c->ar_user);  // stream-ordered, no host sync here
-    c->t_ms[6] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (rc) { set_error("all-reduce hook failed with %d", rc); return REO_ECOMM; }
+    const int64_t count = static_cast<int64_t>(c->G) * kPlanes * c->Wp;
+    int32_t rc = comm_allreduce_table(c, count);  // comm.hip: REO_OK when it did the exchange, 1 when no communicator is attached
+    if (rc < 0) return rc;
+    if (rc == 1) {
+        if (!c->ar) return REO_OK;  // no exchange configured: the partial table can still be inspected (reo_get_codes)
+        tic(c, 6);
+        rc = c->ar(c->table.p, count, c->stream, c->ar_user);  // stream-ordered, no host sync here
+        toc(c);
+        if (rc) { set_error("all-reduce hook failed with %d", rc); return REO_ECOMM; }
+    }
+    c->table_complete = true;
+    return REO_OK;
+}
+
+static int32_t need_complete_table(reo_ctx *c)
+{
+    if (c->built_k < 0) { set_error("no class table: call reo_build_pairs first"); return REO_EINVAL; }
+    if (!c->table_complete) {
+        set_error("shard %d of %d holds only its own part of the class table: attach a communicator (reo_comm_init_rank) or an "
+                  "all-reduce hook (reo_set_allreduce) before reo_build_pairs", c->rank, c->world);
+        return REO_ECOMM;
+    }
     return REO_OK;
 }
 
@@ -241,16 +262,20 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
 void reo_destroy(reo_ctx *c)
 {
     if (!c) return;
+    for (reo_ctx *p : c->peers) reo_destroy(p);
+    c->peers.clear();
     (void)hipSetDevice(c->device);
+    comm_release(c);
     (void)hipStreamSynchronize(c->stream);
     collect_timings(c);
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
     c->table.release();
     c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
-    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release(); c->own_mask.release();
+    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release();
+    c->t_pos16.release(); c->t_lo16.release(); c->t_hi16.release(); c->gcounts.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
-    c->raw.release(); c->raw_local.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
+    c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
     c->state.release(); c->trace.release(); c->modes.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
@@ -262,9 +287,11 @@ int32_t reo_set_shard(reo_ctx *c, int32_t rank, int32_t world)
 {
     if (!c) { set_error("null context"); return REO_EINVAL; }
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad shard %d of %d", rank, world); return REO_EINVAL; }
+    if (!c->peers.empty()) { set_error("a multi-GPU context (reo_create_multi) shards by itself"); return REO_EINVAL; }
     c->rank = rank; c->world = world;
     c->built_k = -1;
     c->gc_valid = false;
+    c->table_complete = false;
     return REO_OK;
 }
 
@@ -275,10 +302,30 @@ int32_t reo_set_allreduce(reo_ctx *c, reo_allreduce_fn fn, void *user)
     return REO_OK;
 }
 
-int32_t reo_set_matrix_f64(reo_ctx *c, const double *X, int64_t G, int64_t S, int64_t ld) { return set_matrix(c, X, G, S, ld, 1, false); }
-int32_t reo_set_matrix_i64(reo_ctx *c, const int64_t *X, int64_t G, int64_t S, int64_t ld) { return set_matrix(c, X, G, S, ld, 2, false); }
-int32_t reo_set_matrix_dev_f64(reo_ctx *c, const void *dX, int64_t G, int64_t S, int64_t ld) { return set_matrix(c, dX, G, S, ld, 1, true); }
-int32_t reo_set_matrix_dev_i64(reo_ctx *c, const void *dX, int64_t G, int64_t S, int64_t ld) { return set_matrix(c, dX, G, S, ld, 2, true); }
+// multi-GPU context: every device gets its own copy of the matrix (host source: one upload each; device source:
+// a peer copy from the leader's buffer)
+static int32_t set_matrix_all(reo_ctx *c, const void *X, int64_t G, int64_t S, int64_t ld, int dtype, bool on_device)
+{
+    int32_t rc = set_matrix(c, X, G, S, ld, dtype, on_device);
+    for (size_t d = 0; d < (c ? c->peers.size() : 0) && !rc; ++d) {
+        reo_ctx *p = c->peers[d];
+        if (!on_device) { rc = set_matrix(p, X, G, S, ld, dtype, false); continue; }
+        if ((rc = use(p)) || (rc = p->dX_owned.ensure(static_cast<size_t>(G) * S * 8))) break;
+        for (int64_t s = 0; s < S && !rc; ++s)  // column by column: the source may have a leading dimension
+            if (hipMemcpyPeerAsync(p->dX_owned.p + s * G * 8, p->device, static_cast<const unsigned char *>(X) + s * ld * 8, c->device, G * 8, p->stream) != hipSuccess) {
+                set_error("peer copy of the matrix to device %d failed", p->device); rc = REO_EHIP;
+            }
+        if (!rc && hipStreamSynchronize(p->stream) != hipSuccess) { set_error("peer copy failed"); rc = REO_EHIP; }
+        if (!rc) { invalidate(p); p->G = G; p->S = S; p->dtype = dtype; p->dX = p->dX_owned.p; p->ld = G; }
+    }
+    if (c && !c->peers.empty()) (void)hipSetDevice(c->device);
+    return rc;
+}
+
+int32_t reo_set_matrix_f64(reo_ctx *c, const double *X, int64_t G, int64_t S, int64_t ld) { return set_matrix_all(c, X, G, S, ld, 1, false); }
+int32_t reo_set_matrix_i64(reo_ctx *c, const int64_t *X, int64_t G, int64_t S, int64_t ld) { return set_matrix_all(c, X, G, S, ld, 2, false); }
+int32_t reo_set_matrix_dev_f64(reo_ctx *c, const void *dX, int64_t G, int64_t S, int64_t ld) { return set_matrix_all(c, dX, G, S, ld, 1, true); }
+int32_t reo_set_matrix_dev_i64(reo_ctx *c, const void *dX, int64_t G, int64_t S, int64_t ld) { return set_matrix_all(c, dX, G, S, ld, 2, true); }
 
 int32_t reo_set_groups(reo_ctx *c, const int32_t *group_id, int64_t len, int32_t ngroups)
 {
@@ -304,6 +351,7 @@ int32_t reo_set_groups(reo_ctx *c, const int32_t *group_id, int64_t len, int32_t
     c->ngroups = ngroups;
     c->thr_set = false;
     invalidate(c);
+    for (reo_ctx *p : c->peers) { p->group_id = c->group_id; p->ngroups = ngroups; p->thr_set = false; invalidate(p); }
     return REO_OK;
 }
 
@@ -326,6 +374,7 @@ int32_t reo_compute_thresholds(reo_ctx *c, double pval_reo)
     }
     c->thr_set = true;
     c->built_k = -1;
+    for (reo_ctx *p : c->peers) { p->thr = c->thr; p->thr_set = true; p->built_k = -1; }
     return REO_OK;
 }
 
@@ -335,6 +384,7 @@ int32_t reo_set_thresholds(reo_ctx *c, const int32_t *m)
     c->thr.assign(m, m + 2 * c->ngroups);
     c->thr_set = true;
     c->built_k = -1;
+    for (reo_ctx *p : c->peers) { p->thr = c->thr; p->thr_set = true; p->built_k = -1; }
     return REO_OK;
 }
 
@@ -345,7 +395,8 @@ int32_t reo_get_thresholds(reo_ctx *c, int32_t *m)
     return REO_OK;
 }
 
-int32_t reo_build_pairs(reo_ctx *c, int32_t k)
+// transform + this context's share of the pair tiles, finished on return; no exchange
+static int32_t build_local(reo_ctx *c, int32_t k)
 {
     int32_t rc = use(c);
     if (rc) return rc;
@@ -353,8 +404,22 @@ int32_t reo_build_pairs(reo_ctx *c, int32_t k)
     if (!c->thr_set) { set_error("thresholds not set (reo_compute_thresholds)"); return REO_EINVAL; }
     if (k < 0 || k >= c->ngroups) { set_error("comparison %d outside [0,%d)", k, c->ngroups); return REO_EINVAL; }
     if ((rc = c->table.ensure(static_cast<size_t>(c->G) * kPlanes * c->Wp))) return rc;
+    c->built_k = -1;
     if ((rc = launch_k1(c, k))) return rc;
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return REO_OK;
+}
+
+int32_t reo_build_pairs(reo_ctx *c, int32_t k)
+{
+    int32_t rc;
+    if (c && !c->peers.empty()) {
+        if ((rc = multi_build_pairs(c, k, build_local))) return rc;
+    } else {
+        if ((rc = build_local(c, k))) return rc;
+        if ((rc = exchange_table(c))) return rc;
+        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     c->t_ms[5] += 1.0;
     collect_timings(c);
     c->built_k = k;
@@ -409,14 +474,13 @@ int32_t reo_tally(reo_ctx *c, const uint8_t *ref_mask, int32_t *cont)
 {
     int32_t rc = use(c);
     if (rc) return rc;
-    if (c->built_k < 0) { set_error("no class table: call reo_build_pairs first"); return REO_EINVAL; }
+    if ((rc = need_complete_table(c))) return rc;
     if (!ref_mask || !cont) { set_error("null argument"); return REO_EINVAL; }
     if ((rc = ensure_iter_buffers(c))) return rc;
     int32_t nref = 0;
     if ((rc = upload_ref(c, ref_mask, 0, &nref))) return rc;
     if ((rc = init_state(c, nref))) return rc;
     if ((rc = launch_k2(c, c->refbits[0].p, 0, false))) return rc;
-    if ((rc = allreduce_raw(c))) return rc;
     if ((rc = launch_derive(c, c->refbytes[0].p, 0))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(cont, c->cont.p, sizeof(int32_t) * 9 * c->G, hipMemcpyDeviceToHost, c->stream));
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -429,7 +493,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
 {
     int32_t rc = use(c);
     if (rc) return rc;
-    if (c->built_k < 0) { set_error("no class table: call reo_build_pairs first"); return REO_EINVAL; }
+    if ((rc = need_complete_table(c))) return rc;
     if (!ref0 || !result) { set_error("null argument"); return REO_EINVAL; }
     if ((rc = ensure_iter_buffers(c))) return rc;
     const int64_t G = c->G;
@@ -450,10 +514,8 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     REO_HIP_CHECK(hipMemsetAsync(c->result.p, 0, sizeof(double) * 15 * G, c->stream));  // zeros(r,15), :398
     // The loop control of :400,418-424 lives in device memory (IterState): passes are
     // enqueued in batches and every kernel of a pass returns at once after convergence,
-    // so the host only looks at the state once per batch.  With more than one shard the
-    // all-reduce hook is called between K2 and K3 of every pass; it is stream-ordered, so the
-    // batches stay (after convergence the remaining passes of a batch still call the hook on
-    // every shard alike, and their kernels return at once).
+    // so the host only looks at the state once per batch.  (Shards of a multi-GPU run hold the whole
+    // class table after reo_build_pairs and run these passes independently and identically.)
     const int batch = 8;
     int enq = 0, passes = 0;
     while (enq < n_iter) {  // :400
@@ -462,7 +524,6 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         for (int t = enq; t < enq + nb; ++t) {
             const int cur = t & 1;  // pass t reads mask buffer t&1 and writes the other (ref_gene_vec = inds, :424)
             if ((rc = launch_k2(c, c->refbits[cur].p, cur, true))) return rc;
-            if ((rc = allreduce_raw(c))) return rc;
             if ((rc = launch_stats(c, cur, pval_deg, padj_deg, n_conv, a, b))) return rc;
         }
         toc(c);
@@ -510,6 +571,7 @@ int32_t reo_set_profiling(reo_ctx *c, int32_t on)
 {
     if (!c) { set_error("null context"); return REO_EINVAL; }
     c->profiling = on != 0;
+    for (reo_ctx *p : c->peers) p->profiling = c->profiling;
     return REO_OK;
 }
 
@@ -534,7 +596,7 @@ int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
     if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
     const int64_t v[15] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
                            c->tiles_owned, c->tiles_total, kTileI, c->k1_cj, c->k1_q, kUnitH,
-                           c->goff8.empty() ? 0 : c->goff8.back(), c->last_k1_shared,
+                           c->goff32.empty() ? 0 : c->goff32.back(), c->last_k1_shared,
                            static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t)), c->transform_in_lds};
     for (int i = 0; i < n && i < 15; ++i) info[i] = v[i];
     return REO_OK;

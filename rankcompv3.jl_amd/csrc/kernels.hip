@@ -12,11 +12,12 @@
 // All file:line citations are relative to /root/reference.
 //
 // Data layout in HBM
-//   pos  u16 [S8/8][Gp][8]  position of gene g in its sample's sorted order, 8 sample slots per
-//                   16 bytes (lane operand; groups padded to multiples of 8 slots with 0xFFFF)
-//   lo   f32 [S8][Gp]  first position of g's tie band   (wave-uniform operand: staged through LDS,
-//                   or s_load in the scalar-fed variant)
-//   hi   f32 [S8][Gp]  one past the last position of g's tie band (both exact integers < 2^16)
+//   P   uint4 [nblk][4][Gp]  bit planes of pos (position of gene g in its sample's sorted order) over blocks of
+//                   32 samples: planes 4q..4q+3 of gene g in block b at (b * 4 + q) * Gp + g (lane operand;
+//                   groups padded to whole blocks)
+//   AL  uint4 [nblk][Gp][4]  the 16 plane words of lo (first position of g's tie band) of gene g in block b,
+//                   plane k in word (k + 15) % 16 (tile operand: staged through LDS)
+//   AH  likewise for hi (one past the last position of g's tie band); padding samples have lo = hi = 0
 //   table u32 [G][4][Wp]  bit planes cL cH tL tH of row i: bit j of plane cL is
 //                   set iff pair (i,j) is "i<j stable" in ctrl (ic==1), cH iff
 //                   ic==3, tL/tH likewise for treat.  4 bits per ORDERED pair,
@@ -57,278 +58,171 @@ __device__ uint32_t tie_wins(uint64_t seed, uint32_t i, uint32_t j, uint32_t g, 
 }
 
 // ---------------------------------------------------------------------------
-// K1 inner loop.  Lane = gene j, the RI genes i of the tile are wave-uniform.
-// All values are integers below 2^16, exact in fp32, so
-//     [pos_j < lo_i] = clamp(lo_i - pos_j, 0, 1)
-// is one subtraction with the clamp output modifier and the count is one add;
-// both are issued packed (v_pk_add_f32: two band edges per instruction).
-// Measured on MI355X (tools/microbench_cmp*.hip), ns per 64 comparisons per SIMD:
-// v_pk_add_f32 clamp + v_pk_add_f32 1.80, v_sub_f32 clamp + v_add_f32 2.09,
-// v_cmp + v_addc 3.50 (every VALU op that writes or reads a lane mask in SGPRs
-// issues at half rate), v_cmp + s_bcnt1 + s_add (the ballot/popcount form) 3.81.
-// n_gt(i,j) = #{s : pos_j < lo_i},  n_ge(i,j) = #{s : pos_j < hi_i}.
-// The lane operand comes 8 samples at a time (one coalesced 16-byte load per
-// lane, 1 KiB per wave) and the next group is fetched while this one is used.
-typedef float float2v __attribute__((ext_vector_type(2)));
+// K1 inner loop, bit-sliced.  The transform hands over pos / lo / hi as bit planes over blocks of 32 samples
+// (plane k, word of a block: bit s = bit k of the 16-bit number of sample 32 b + s).  For one pair and one block
+//     lt = [pos_j < lo_i] for 32 samples  =  the borrow of lo_i - pos_j, bit by bit from the LSB:
+//     lt <- majority(~p_k, u_k, lt)                       one v_bitop3_b32 (truth table 0x8e) per bit plane
+//     n_gt += popcount(lt)                                one v_bcnt_u32_b32 per 32 samples
+// i.e. (NB + 1) / 32 instructions per comparison instead of the two packed float ops of round 1.  Measured on
+// MI355X (tools/microbench_bitop.hip, tools/k1b_proto.hip): v_bitop3_b32 with three VGPR sources issues at full
+// rate (1.0-1.2 ns per wave-instruction per SIMD), at half rate with an SGPR source or when its three sources share
+// a VGPR bank, and v_bcnt / v_lshl_add at half rate; v_bfi_b32 + v_xor_b32 (two ops per bit) is no faster than
+// the float form.  Lane = gene j (RJ genes per lane, 64 apart), the 32 genes i of the tile are wave-uniform and
+// their planes are staged through LDS (ordinary 16-byte vector loads one stage ahead, double-buffered, one
+// barrier per stage; read back with broadcast ds_read_b128).  Counts are kept packed, two 16-bit counts per
+// register (rows 2h and 2h+1): a side never has more than 65 535 samples.
+// n_gt(i,j) = #{s : pos_j < lo_i},  n_ge(i,j) = #{s : pos_j < hi_i}  (ties: n_eq = n_ge - n_gt).
+constexpr int kStageB = 4;  // 32-sample blocks per LDS stage of the tile operand
 
-// acc[0..3] += clamp(a[0..3] - b, 0, 1) for four wave-uniform a (two SGPR pairs) and the per-lane b
-// held in the LOW (HI = false) or HIGH (HI = true) half of the VGPR pair bb.  One v_pk_add_f32 with
-// negated, half-broadcast second operand and the clamp modifier makes two flags; a second one adds
-// them to the counts.  Two independent chains per block so that no result is consumed by the very
-// next instruction.  Kept in asm because hipcc, left alone, hoists a whole sample group of flags
-// and then spills; non-volatile so that the loads that feed it remain scalar (s_load).
-template <bool HI>
-__device__ __forceinline__ void acc4(float2v &c0, float2v &c1, float2v a0, float2v a1, float2v bb)
+// four independent borrow chains per bit plane (no result is consumed by the next instruction):
+// chain c combines lane operand p[c] with tile operand a[c]
+__device__ __forceinline__ void chains_first(uint32_t (&l)[4], uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3,
+                                             uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
 {
-    float2v t0, t1;
-    if (HI)
-        asm("v_pk_add_f32 %2, %4, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %3, %5, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %0, %0, %2\n\t"
-            "v_pk_add_f32 %1, %1, %3"
-            : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
-            : "s"(a0), "s"(a1), "v"(bb));
-    else
-        asm("v_pk_add_f32 %2, %4, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %3, %5, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %0, %0, %2\n\t"
-            "v_pk_add_f32 %1, %1, %3"
-            : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
-            : "s"(a0), "s"(a1), "v"(bb));
+    asm volatile("v_bitop3_b32 %0, %4, %8, %4 bitop3:0x0c\n\t"    // ~p & u
+                 "v_bitop3_b32 %1, %5, %9, %5 bitop3:0x0c\n\t"
+                 "v_bitop3_b32 %2, %6, %10, %6 bitop3:0x0c\n\t"
+                 "v_bitop3_b32 %3, %7, %11, %7 bitop3:0x0c"
+                 : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
 }
 
-// Same as acc4 with the band edges in VGPR pairs (they come from LDS broadcast reads).
-template <bool HI>
-__device__ __forceinline__ void acc4v(float2v &c0, float2v &c1, float2v a0, float2v a1, float2v bb)
+__device__ __forceinline__ void chains_next(uint32_t (&l)[4], uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3,
+                                            uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3)
 {
-    float2v t0, t1;
-    if (HI)
-        asm("v_pk_add_f32 %2, %4, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %3, %5, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %0, %0, %2\n\t"
-            "v_pk_add_f32 %1, %1, %3"
-            : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
-            : "v"(a0), "v"(a1), "v"(bb));
-    else
-        asm("v_pk_add_f32 %2, %4, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %3, %5, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %0, %0, %2\n\t"
-            "v_pk_add_f32 %1, %1, %3"
-            : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
-            : "v"(a0), "v"(a1), "v"(bb));
+    asm volatile("v_bitop3_b32 %0, %4, %8, %0 bitop3:0x8e\n\t"    // majority(~p, u, lt)
+                 "v_bitop3_b32 %1, %5, %9, %1 bitop3:0x8e\n\t"
+                 "v_bitop3_b32 %2, %6, %10, %2 bitop3:0x8e\n\t"
+                 "v_bitop3_b32 %3, %7, %11, %3 bitop3:0x8e"
+                 : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
 }
 
-// acc4v for two lane operands at once (RJ = 2): one asm statement of eight instructions, four independent chains
-template <bool HI>
-__device__ __forceinline__ void acc8v(float2v &c0, float2v &c1, float2v &d0, float2v &d1, float2v a0, float2v a1, float2v bb0, float2v bb1)
+// the 16 plane words of one gene as registers; A planes are stored one word off (plane k in word (k + 15) % 16)
+struct Planes16 {
+    uint32_t w[16];
+    __device__ __forceinline__ void set(int q, uint4 v) { w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+};
+__device__ __forceinline__ constexpr int a_word(int k) { return (k + 15) & 15; }
+
+// unsigned count of row ii (0..31) from the packed accumulators
+__device__ __forceinline__ uint32_t unpack16(const uint32_t (&acc)[kTileI / 2], int ii)
 {
-    float2v t0, t1, t2, t3;
-    if (HI)
-        asm("v_pk_add_f32 %4, %8, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %5, %9, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %6, %8, %11 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %7, %9, %11 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %0, %0, %4\n\t"
-            "v_pk_add_f32 %1, %1, %5\n\t"
-            "v_pk_add_f32 %2, %2, %6\n\t"
-            "v_pk_add_f32 %3, %3, %7"
-            : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-            : "v"(a0), "v"(a1), "v"(bb0), "v"(bb1));
-    else
-        asm("v_pk_add_f32 %4, %8, %10 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %5, %9, %10 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %6, %8, %11 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %7, %9, %11 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-            "v_pk_add_f32 %0, %0, %4\n\t"
-            "v_pk_add_f32 %1, %1, %5\n\t"
-            "v_pk_add_f32 %2, %2, %6\n\t"
-            "v_pk_add_f32 %3, %3, %7"
-            : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-            : "v"(a0), "v"(a1), "v"(bb0), "v"(bb1));
+    return (ii & 1) ? (acc[ii >> 1] >> 16) : (acc[ii >> 1] & 0xFFFFu);
 }
 
-typedef float float4v __attribute__((ext_vector_type(4)));
-constexpr int kStage = 32;  // sample slots per LDS stage of the band edges
-
-// LDS-fed form of the pair loop for the whole workgroup (every thread must call it: it has barriers).
-// The band edges of the tile's 32 genes are staged through LDS in chunks of kStage sample slots:
-// ordinary 16-byte vector loads, issued one chunk ahead (vmcnt is ordered, so unlike scalar loads
-// they can stay in flight across the compute phase), double-buffered, one barrier per chunk.  Each
-// wave reads a sample's 32 edges back with broadcast ds_read_b128 and runs the same packed
-// clamp/add pairs on VGPR operands.  With RJ = 2 genes per lane the LDS pipe is about half busy.
-// Measured reason for this form: with scalar loads (count_pass) 31 % of K1's time is exposed s_load
-// latency -- SMEM returns out of order, so a wave can keep only one generation of loads in flight.
-template <int RI, int RJ, bool TIES>
-__device__ __forceinline__ void count_pass_lds(const uint4 *__restrict__ pos8, const float *__restrict__ lo,
-                                               const float *__restrict__ hi, int Gp, int i0, int j, int s8b,
-                                               int s8e, float2v (&gt)[RJ][RI / 2], float2v (&ge)[RJ][RI / 2],
-                                               float4v *sm_lo, float4v *sm_hi, bool idle)
+// Whole-workgroup pair loop over blocks [bb, be) (every thread must call it: it has barriers).
+// gt[r][h] / ge[r][h]: packed counts of rows 2h, 2h+1 against the lane's gene r.  Tie-free: 4 genes per lane, one
+// chain each; with ties: 2 genes per lane, two chains each (lo and hi).  idle (wave-uniform): none of this wave's
+// genes forms a real pair with the tile -- the wave only helps staging and keeps the barriers.
+template <int RJ, int NB, bool TIES>
+__device__ __forceinline__ void count_pass(const uint4 *__restrict__ P, const uint4 *__restrict__ AL, const uint4 *__restrict__ AH,
+                                           int Gp, int i0, int jl, int bb, int be, uint32_t (&gt)[RJ][kTileI / 2],
+                                           uint32_t (&ge)[TIES ? RJ : 1][kTileI / 2], uint4 *sm_lo, uint4 *sm_hi, bool idle)
 {
-    static_assert(RI == 32, "stage layout assumes 32 genes = 8 float4 per sample");
+    static_assert((TIES && RJ == 2) || (!TIES && RJ == 4), "four chains per bit plane");
+    constexpr int RI = kTileI, NQ = (NB + 3) / 4;
+    constexpr int kStageQ = kStageB * RI * 4;        // uint4 per stage
+    constexpr int kPerThread = kStageQ / 256;
 #pragma unroll
     for (int r = 0; r < RJ; ++r)
 #pragma unroll
-        for (int ii = 0; ii < RI / 2; ++ii) { gt[r][ii] = float2v{0.f, 0.f}; ge[r][ii] = float2v{0.f, 0.f}; }
-    const int sb = s8b * 8, se = s8e * 8;  // sample slots
-    if (sb >= se) return;
-    const int srow = threadIdx.x >> 3, scol = threadIdx.x & 7;  // staging role: sample row, float4 column
-    auto stage_load = [&](int s0, float4v &vl, float4v &vh) {
-        const int s = min(s0 + srow, se - 1);
-        vl = *reinterpret_cast<const float4v *>(lo + static_cast<size_t>(s) * Gp + i0 + 4 * scol);
-        if (TIES) vh = *reinterpret_cast<const float4v *>(hi + static_cast<size_t>(s) * Gp + i0 + 4 * scol);
+        for (int h = 0; h < RI / 2; ++h) { gt[r][h] = 0; if (TIES) ge[r][h] = 0; }
+    if (bb >= be) return;
+    uint4 sl[kPerThread], sh[TIES ? kPerThread : 1];
+    auto stage_load = [&](int b0) {
+#pragma unroll
+        for (int e = 0; e < kPerThread; ++e) {
+            const int idx = threadIdx.x + 256 * e;
+            const int b = min(b0 + idx / (RI * 4), be - 1);
+            const size_t o = (static_cast<size_t>(b) * Gp + i0) * 4 + idx % (RI * 4);
+            sl[e] = AL[o];
+            if (TIES) sh[e] = AH[o];
+        }
     };
-    float4v vl, vh;
-    stage_load(sb, vl, vh);
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < kPerThread; ++e) {
+            sm_lo[buf * kStageQ + threadIdx.x + 256 * e] = sl[e];
+            if (TIES) sm_hi[buf * kStageQ + threadIdx.x + 256 * e] = sh[e];
+        }
+    };
+    stage_load(bb);
     __syncthreads();  // the previous pass may still be reading the stage buffers
-    sm_lo[srow * 8 + scol] = vl;
-    if (TIES) sm_hi[srow * 8 + scol] = vh;
+    stage_store(0);
     __syncthreads();
-    const uint4 *pb = pos8 + static_cast<size_t>(s8b) * Gp + j;  // lane's genes: j, j + 256, ...
     int buf = 0;
-    for (int s0 = sb; s0 < se; s0 += kStage) {
-        const bool more = s0 + kStage < se;
-        if (more) stage_load(s0 + kStage, vl, vh);  // in flight during this chunk's compute
-        const float4v *al = sm_lo + buf * (kStage * 8);
-        const float4v *ah = sm_hi + buf * (kStage * 8);
-        const int ng = min(kStage, se - s0) >> 3;  // groups of 8 slots in this chunk
-        // idle (wave-uniform): none of this wave's genes j forms a real pair with the tile (padding columns
-        // of the last chunk, or columns left of the diagonal) -- it only helps staging and keeps the barriers
-        for (int g8 = 0; g8 < (idle ? 0 : ng); ++g8) {
-            uint4 cur[RJ];
+    for (int b0 = bb; b0 < be; b0 += kStageB) {
+        const bool more = b0 + kStageB < be;
+        if (more) stage_load(b0 + kStageB);  // in flight during this stage's compute
+        const int nb = idle ? 0 : min(kStageB, be - b0);
+        for (int s = 0; s < nb; ++s) {
+            Planes16 p[RJ];
 #pragma unroll
-            for (int r = 0; r < RJ; ++r) cur[r] = pb[r * 256];
-            pb += Gp;
+            for (int r = 0; r < RJ; ++r)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float2v bb[RJ];
+                for (int q = 0; q < NQ; ++q) p[r].set(q, P[(static_cast<size_t>(b0 + s) * 4 + q) * Gp + jl + 64 * r]);
+            const uint4 *al = sm_lo + buf * kStageQ + s * RI * 4;
+            const uint4 *ah = sm_hi + buf * kStageQ + s * RI * 4;
+#pragma clang loop unroll(full)
+            for (int i = 0; i < RI; ++i) {
+                Planes16 a, c;
 #pragma unroll
-                for (int r = 0; r < RJ; ++r) {
-                    const uint32_t w = kk == 0 ? cur[r].x : kk == 1 ? cur[r].y : kk == 2 ? cur[r].z : cur[r].w;
-                    bb[r] = float2v{static_cast<float>(w & 0xFFFFu), static_cast<float>(w >> 16)};
+                for (int q = 0; q < 4; ++q) {
+                    if (q < 3 && 4 * q + 1 > NB - 1) continue;  // words of planes beyond NB (word 15 = plane 0 is always read)
+                    a.set(q, al[i * 4 + q]);                    // broadcast read: every lane the same address
+                    if (TIES) c.set(q, ah[i * 4 + q]);
                 }
+                uint32_t l[4];
+                if (TIES) {
+                    chains_first(l, p[0].w[0], p[1].w[0], p[0].w[0], p[1].w[0], a.w[a_word(0)], a.w[a_word(0)], c.w[a_word(0)], c.w[a_word(0)]);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int srel = g8 * 8 + kk * 2 + half;
+                    for (int k = 1; k < NB; ++k)
+                        chains_next(l, p[0].w[k], p[1].w[k], p[0].w[k], p[1].w[k], a.w[a_word(k)], a.w[a_word(k)], c.w[a_word(k)], c.w[a_word(k)]);
+                } else {
+                    chains_first(l, p[0].w[0], p[1].w[0], p[RJ - 2].w[0], p[RJ - 1].w[0], a.w[a_word(0)], a.w[a_word(0)], a.w[a_word(0)], a.w[a_word(0)]);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float4v a = al[srel * 8 + q];  // broadcast read: every lane the same address
-                        const float2v a0 = {a.x, a.y}, a1 = {a.z, a.w};
-                        if (RJ == 2) {
-                            if (half) acc8v<true>(gt[0][2 * q], gt[0][2 * q + 1], gt[RJ - 1][2 * q], gt[RJ - 1][2 * q + 1], a0, a1, bb[0], bb[RJ - 1]);
-                            else acc8v<false>(gt[0][2 * q], gt[0][2 * q + 1], gt[RJ - 1][2 * q], gt[RJ - 1][2 * q + 1], a0, a1, bb[0], bb[RJ - 1]);
-                        } else {
+                    for (int k = 1; k < NB; ++k)
+                        chains_next(l, p[0].w[k], p[1].w[k], p[RJ - 2].w[k], p[RJ - 1].w[k], a.w[a_word(k)], a.w[a_word(k)], a.w[a_word(k)], a.w[a_word(k)]);
+                }
+                // counts of row i: low half of the packed register for even rows, high half for odd rows
 #pragma unroll
-                            for (int r = 0; r < RJ; ++r) {
-                                if (half) acc4v<true>(gt[r][2 * q], gt[r][2 * q + 1], a0, a1, bb[r]);
-                                else acc4v<false>(gt[r][2 * q], gt[r][2 * q + 1], a0, a1, bb[r]);
-                            }
-                        }
-                        if (TIES) {
-                            const float4v h = ah[srel * 8 + q];
-                            const float2v h0 = {h.x, h.y}, h1 = {h.z, h.w};
-#pragma unroll
-                            for (int r = 0; r < RJ; ++r) {
-                                if (half) acc4v<true>(ge[r][2 * q], ge[r][2 * q + 1], h0, h1, bb[r]);
-                                else acc4v<false>(ge[r][2 * q], ge[r][2 * q + 1], h0, h1, bb[r]);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // one sample's band edges (32 VGPRs) live at a time
+                for (int ch = 0; ch < 4; ++ch) {
+                    uint32_t &dst = TIES ? (ch < 2 ? gt[ch][i >> 1] : ge[ch - 2][i >> 1]) : gt[ch % RJ][i >> 1];
+                    if (i & 1) dst += static_cast<uint32_t>(__builtin_popcount(l[ch])) << 16;
+                    else dst += static_cast<uint32_t>(__builtin_popcount(l[ch]));
                 }
             }
         }
-        if (more) {
-            sm_lo[(buf ^ 1) * (kStage * 8) + srow * 8 + scol] = vl;
-            if (TIES) sm_hi[(buf ^ 1) * (kStage * 8) + srow * 8 + scol] = vh;
-        }
+        if (more) stage_store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 }
 
-template <int RI, int RJ, bool TIES>
-__device__ __forceinline__ void count_pass(const uint4 *__restrict__ pos8, const float *__restrict__ lo,
-                                           const float *__restrict__ hi, int Gp, int i0, int j, int s8b,
-                                           int s8e, float2v (&gt)[RJ][RI / 2], float2v (&ge)[RJ][RI / 2])
-{
-#pragma unroll
-    for (int r = 0; r < RJ; ++r)
-#pragma unroll
-        for (int ii = 0; ii < RI / 2; ++ii) { gt[r][ii] = float2v{0.f, 0.f}; ge[r][ii] = float2v{0.f, 0.f}; }
-    if (s8b >= s8e) return;
-    const uint4 *pb = pos8 + static_cast<size_t>(s8b) * Gp + j;  // lane's genes: j, j + 256, ...
-    const float2v *pl = reinterpret_cast<const float2v *>(lo + static_cast<size_t>(s8b) * 8 * Gp + i0);
-    const float2v *ph = reinterpret_cast<const float2v *>(hi + static_cast<size_t>(s8b) * 8 * Gp + i0);
-    const int row = Gp / 2;  // float2 per sample row
-    uint4 cur[RJ], nxt[RJ];
-#pragma unroll
-    for (int r = 0; r < RJ; ++r) cur[r] = pb[r * 256];
-    for (int s8 = s8b; s8 < s8e; ++s8) {
-        pb += Gp;
-#pragma unroll
-        for (int r = 0; r < RJ; ++r) nxt[r] = (s8 + 1 < s8e) ? pb[r * 256] : cur[r];  // wave-uniform condition
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {  // two samples per dword of the lane operand
-            float2v bb[RJ];
-#pragma unroll
-            for (int r = 0; r < RJ; ++r) {
-                const uint32_t w = kk == 0 ? cur[r].x : kk == 1 ? cur[r].y : kk == 2 ? cur[r].z : cur[r].w;
-                bb[r] = float2v{static_cast<float>(w & 0xFFFFu), static_cast<float>(w >> 16)};
-            }
-#pragma unroll
-            for (int ii = 0; ii < RI / 2; ii += 2) {
-#pragma unroll
-                for (int r = 0; r < RJ; ++r) {
-                    acc4<false>(gt[r][ii], gt[r][ii + 1], pl[ii], pl[ii + 1], bb[r]);
-                    if (TIES) acc4<false>(ge[r][ii], ge[r][ii + 1], ph[ii], ph[ii + 1], bb[r]);
-                }
-            }
-            pl += row; ph += row;
-#pragma unroll
-            for (int ii = 0; ii < RI / 2; ii += 2) {
-#pragma unroll
-                for (int r = 0; r < RJ; ++r) {
-                    acc4<true>(gt[r][ii], gt[r][ii + 1], pl[ii], pl[ii + 1], bb[r]);
-                    if (TIES) acc4<true>(ge[r][ii], ge[r][ii + 1], ph[ii], ph[ii + 1], bb[r]);
-                }
-            }
-            pl += row; ph += row;
-        }
-#pragma unroll
-        for (int r = 0; r < RJ; ++r) cur[r] = nxt[r];
-    }
-}
-
 struct K1Args {
-    const uint4 *pos8;
-    const float *lo;
-    const float *hi;
+    const uint4 *P;    // pos planes (lane operand)
+    const uint4 *AL;   // lo planes (tile operand)
+    const uint4 *AH;   // hi planes
     uint32_t *table;
     const uint32_t *unit_map;  // work unit -> panel << 16 | i-range
     int G, Gp, Wp;
-    int cb, ce, tb, te;  // ctrl / treat ranges in units of 8 sample slots
+    int cb, ce, tb, te;  // ctrl / treat ranges in 32-sample blocks
     int gc, gt;          // their group ids (tie-stream key)
     int nc, nt;          // group sizes gsi1, gsi2 (:358-359)
     int m1, m2;          // threshold[1,k], threshold[2,k] (:362)
     uint64_t seed;
     int n_units, Q;      // units owned by this shard; j-chunks per panel
-    const int32_t *goff; // MULTI: group offsets in units of 8 sample slots (ngroups + 1)
+    const int32_t *goff; // MULTI: group offsets in blocks (ngroups + 1)
     int ngroups;
 };
 
-
-// true when every gene j of the wave (64 consecutive from jw, and jw + 256 r) is padding (>= G) or lies in a
-// 64-gene block left of the tile's block: such pairs are never emitted (emit_side)
+// true when every gene j of the wave (64 RJ consecutive genes from jw) is padding (>= G) or lies in a 64-gene
+// block left of the tile's block: such pairs are never emitted (emit_side)
 template <int RJ>
 __device__ __forceinline__ bool wave_idle(int jw, int i0, int G)
 {
-    bool idle = true;
-#pragma unroll
-    for (int r = 0; r < RJ; ++r) {
-        const int j = jw + 256 * r;
-        if (j < G && (j >> 6) >= (i0 >> 6)) idle = false;
-    }
-    return idle;
+    return jw >= G || ((jw + 64 * RJ - 1) >> 6) < (i0 >> 6);
 }
 
 // word = 2 * word + (bit `lane` of mask): v_addc_co_u32 takes the lane mask as its per-lane carry-in
@@ -345,17 +239,17 @@ __device__ __forceinline__ void write_lane(uint32_t &v, uint32_t x, int l)
 }
 
 // Epilogue of one side (control: planes 0/1, treat: planes 2/3) of a tile.  val(r, ii) is the count n of
-// pair (i0+ii, j0+256r) on this side; state H <=> n >= m, L <=> size - n >= m (:376-377).  Each predicate
+// pair (i0+ii, jl+64r) on this side; state H <=> n >= m, L <=> size - n >= m (:376-377).  Each predicate
 // is one v_cmp whose lane mask IS the forward word of row i0+ii (columns of this wave's 64-gene block);
 // the mirror word of row j (:386: L and H swap) grows by one bit per row with an add-with-carry from the
 // same mask.  Only pairs i < j < G are real; everything else contributes zero bits.  The diagonal 64x64
 // blocks are written by several tiles and use atomicOr on the pre-zeroed table.
-template <int RI, int RJ, typename T, typename F>
-__device__ __forceinline__ void emit_side(const K1Args &a, int i0, int j0, int bi, int lane, int pl, T hi_thr, T lo_thr, F val)
+template <int RI, int RJ, typename F>
+__device__ __forceinline__ void emit_side(const K1Args &a, int i0, int jl, int bi, int lane, int pl, int hi_thr, int lo_thr, F val)
 {
 #pragma unroll
     for (int r = 0; r < RJ; ++r) {
-        const int j = j0 + 256 * r;
+        const int j = jl + 64 * r;
         const int bj = __builtin_amdgcn_readfirstlane(j >> 6);  // wave-uniform, and the compiler should know it
         if ((bj << 6) >= a.Gp || bj < bi) continue;
         const int d = j - i0;                          // rows i0+ii with ii < d are above the diagonal
@@ -365,7 +259,7 @@ __device__ __forceinline__ void emit_side(const K1Args &a, int i0, int j0, int b
         uint32_t fLlo = 0, fLhi = 0, fHlo = 0, fHhi = 0;  // lane ii: forward words of row i0+ii
 #pragma unroll
         for (int ii = RI - 1; ii >= 0; --ii) {
-            const T n = val(r, ii);
+            const int n = val(r, ii);
             const unsigned long long ok = near ? (__ballot(d > ii) & lanes_ok) : lanes_ok;
             const unsigned long long mH = __ballot(n >= hi_thr) & ok;
             const unsigned long long mL = __ballot(n <= lo_thr) & ok & ~mH;
@@ -401,80 +295,86 @@ __device__ __forceinline__ void emit_side(const K1Args &a, int i0, int j0, int b
     }
 }
 
-// MULTI = one-vs-rest with more than two groups (:375-390): the treat side is every other group,
-// counted group by group because the tie coins are keyed by group.
-template <int RI, int RJ, bool TIES, bool MULTI, bool LDSFEED>
-__global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : ((TIES || MULTI) ? 3 : 4)) : (MULTI ? (TIES ? 2 : 3) : ((TIES || RJ > 1) ? 4 : 5))) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
+// block -> tile mapping shared by k1_pairs, k1_group_counts and k1_classify.  Work order (speed only, never
+// correctness): a unit = kUnitH i-tiles x Q j-chunks.  Workgroups are dealt round-robin over the 8 XCDs, so
+// workgroup b belongs to "XCD slot" b & 7; each slot walks whole units, i-tile-major inside a unit, which keeps
+// the unit's pos panel (Q chunks of 256 RJ genes x nblk blocks x 64 B) in that XCD's L2 while the tile operand
+// streams past once.  jl = this lane's first gene (its others are jl + 64 r): a wave owns 64 RJ consecutive genes.
+template <int RI, int RJ>
+__device__ __forceinline__ bool tile_of_block(const K1Args &a, int &i0, int &jl)
 {
-    static_assert(RI == 32, "one mirror word per tile");
-    const int lane = threadIdx.x & 63;
-    // Work order (speed only, never correctness): a unit = kUnitH i-tiles x Q j-chunks.  Workgroups
-    // are dealt round-robin over the 8 XCDs, so workgroup b belongs to "XCD slot" b & 7; each slot
-    // walks whole units, i-tile-major inside a unit, which keeps the unit's pos panel (Q chunks of
-    // 256*RJ genes x S samples x 2 B) in that XCD's L2 while the band-edge rows stream past once.
     const int slot = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int bu = kUnitH * a.Q;
     const int u = (q / bu) * 8 + slot;
-    if (u >= a.n_units) return;
+    if (u >= a.n_units) return false;
     const uint32_t um = a.unit_map[u];
     const int wq = q % bu;
     const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + wq / a.Q;
     const int jc = static_cast<int>(um >> 16) * a.Q + wq % a.Q;
-    const int i0 = it * RI;
-    constexpr int CJ = kTileJ * RJ;  // genes j per workgroup
-    if (i0 >= a.Gp || jc * CJ >= a.Gp) return;
-    const int j0 = jc * CJ + threadIdx.x;  // this lane's genes are j0 + 256 r
-    const int bi = i0 >> 6;                // 64-gene blocks
-    if (LDSFEED) {  // barriers inside: only a whole workgroup may leave
-        if (((jc * CJ + CJ - 1) >> 6) < bi) return;
-    } else {
-        if (((j0 + 256 * (RJ - 1)) >> 6) < bi) return;  // every gene of this wave is strictly below the diagonal
-    }
-    __shared__ float4v sm_lo[LDSFEED ? 2 * kStage * 8 : 1];
-    __shared__ float4v sm_hi[(LDSFEED && TIES) ? 2 * kStage * 8 : 1];
-    const bool idle = wave_idle<RJ>(j0 & ~63, i0, a.G);
+    i0 = it * RI;
+    constexpr int CJ = kTileJ * RJ;
+    if (i0 >= a.Gp || jc * CJ >= a.Gp) return false;
+    jl = jc * CJ + (threadIdx.x >> 6) * (64 * RJ) + (threadIdx.x & 63);
+    return ((jc * CJ + CJ - 1) >> 6) >= (i0 >> 6);  // whole workgroups only: barriers inside
+}
 
-    float2v gt[RJ][RI / 2], ge[RJ][RI / 2];
-    // count of pair (i0+ii, j0+256r) in group g from the accumulators, tie coins included (:72-77)
-    auto count_of = [&](int r, int ii, int g) -> int {
-        const float fgt = (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x;
-        int nre = static_cast<int>(fgt);
-        if (TIES) {
-            const float fge = (ii & 1) ? ge[r][ii >> 1].y : ge[r][ii >> 1].x;
-            const uint32_t neq = static_cast<uint32_t>(fge - fgt);
-            if (neq) nre += tie_wins(a.seed, i0 + ii, j0 + 256 * r, g, neq);
-        }
-        return nre;
-    };
-    auto fcount_of = [&](int r, int ii) -> float { return (ii & 1) ? gt[r][ii >> 1].y : gt[r][ii >> 1].x; };
+// count of pair (i0+ii, jl+64r) in group g from the packed accumulators, tie coins included (:72-77)
+template <int RJ, bool TIES>
+__device__ __forceinline__ int count_with_coins(const uint32_t (&gt)[RJ][kTileI / 2], const uint32_t (&ge)[TIES ? RJ : 1][kTileI / 2],
+                                                uint64_t seed, int i0, int jl, int r, int ii, int g)
+{
+    int nre = static_cast<int>(unpack16(gt[r], ii));
+    if (TIES) {
+        const uint32_t neq = unpack16(ge[r], ii) - static_cast<uint32_t>(nre);
+        if (neq) nre += tie_wins(seed, i0 + ii, jl + 64 * r, g, neq);
+    }
+    return nre;
+}
+
+// MULTI = one-vs-rest with more than two groups (:375-390) without the shared per-group counts: the treat side
+// is every other group, counted group by group because the tie coins are keyed by group.
+template <int NB, bool TIES, bool MULTI>
+__global__ __launch_bounds__(256, MULTI ? 2 : 3) void k1_pairs(K1Args a)  // waves per SIMD wanted -> VGPR cap
+{
+    constexpr int RI = kTileI, RJ = TIES ? kRJTies : kRJ;
+    int i0, jl;
+    if (!tile_of_block<RI, RJ>(a, i0, jl)) return;
+    const int lane = threadIdx.x & 63, bi = i0 >> 6;
+    __shared__ uint4 sm_lo[2 * kStageB * RI * 4];
+    __shared__ uint4 sm_hi[TIES ? 2 * kStageB * RI * 4 : 1];
+    const bool idle = wave_idle<RJ>(jl & ~63, i0, a.G);
+    uint32_t gt[RJ][RI / 2], ge[TIES ? RJ : 1][RI / 2];
 
     // control side (:376): nothing of it has to survive the treat-side loop
-    if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge, sm_lo, sm_hi, idle);
-    else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.cb, a.ce, gt, ge);
-    if (TIES) emit_side<RI, RJ, int>(a, i0, j0, bi, lane, 0, a.m1, a.nc - a.m1, [&](int r, int ii) { return count_of(r, ii, a.gc); });
-    else emit_side<RI, RJ, float>(a, i0, j0, bi, lane, 0, static_cast<float>(a.m1), static_cast<float>(a.nc - a.m1), fcount_of);
+    count_pass<RJ, NB, TIES>(a.P, a.AL, a.AH, a.Gp, i0, jl, a.cb, a.ce, gt, ge, sm_lo, sm_hi, idle);
+    emit_side<RI, RJ>(a, i0, jl, bi, lane, 0, a.m1, a.nc - a.m1,
+                      [&](int r, int ii) { return count_with_coins<RJ, TIES>(gt, ge, a.seed, i0, jl, r, ii, a.gc); });
     // treat side (:377)
     if (!MULTI) {
-        if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge, sm_lo, sm_hi, idle);
-        else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.tb, a.te, gt, ge);
-        if (TIES) emit_side<RI, RJ, int>(a, i0, j0, bi, lane, 2, a.m2, a.nt - a.m2, [&](int r, int ii) { return count_of(r, ii, a.gt); });
-        else emit_side<RI, RJ, float>(a, i0, j0, bi, lane, 2, static_cast<float>(a.m2), static_cast<float>(a.nt - a.m2), fcount_of);
+        count_pass<RJ, NB, TIES>(a.P, a.AL, a.AH, a.Gp, i0, jl, a.tb, a.te, gt, ge, sm_lo, sm_hi, idle);
+        emit_side<RI, RJ>(a, i0, jl, bi, lane, 2, a.m2, a.nt - a.m2,
+                          [&](int r, int ii) { return count_with_coins<RJ, TIES>(gt, ge, a.seed, i0, jl, r, ii, a.gt); });
     } else {
-        int tot[RJ][RI];  // not = sum(nre) - nre[k]  (:374)
+        uint32_t tot[RJ][RI / 2];  // not = sum(nre) - nre[k]  (:374), two 16-bit sums per register (each at most S < 65536)
 #pragma unroll
         for (int r = 0; r < RJ; ++r)
 #pragma unroll
-            for (int ii = 0; ii < RI; ++ii) tot[r][ii] = 0;
+            for (int h = 0; h < RI / 2; ++h) tot[r][h] = 0;
         for (int g = 0; g < a.ngroups; ++g) {
             if (g == a.gc) continue;
-            if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi, idle);
-            else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge);
+            count_pass<RJ, NB, TIES>(a.P, a.AL, a.AH, a.Gp, i0, jl, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi, idle);
 #pragma unroll
             for (int r = 0; r < RJ; ++r)
 #pragma unroll
-                for (int ii = 0; ii < RI; ++ii) tot[r][ii] += count_of(r, ii, g);
+                for (int h = 0; h < RI / 2; ++h) {
+                    if (TIES) {
+                        const uint32_t n0 = count_with_coins<RJ, TIES>(gt, ge, a.seed, i0, jl, r, 2 * h, g);
+                        const uint32_t n1 = count_with_coins<RJ, TIES>(gt, ge, a.seed, i0, jl, r, 2 * h + 1, g);
+                        tot[r][h] += n0 | (n1 << 16);
+                    } else tot[r][h] += gt[r][h];  // no carry between the halves
+                }
         }
-        emit_side<RI, RJ, int>(a, i0, j0, bi, lane, 2, a.m2, a.nt - a.m2, [&](int r, int ii) { return tot[r][ii]; });
+        emit_side<RI, RJ>(a, i0, jl, bi, lane, 2, a.m2, a.nt - a.m2, [&](int r, int ii) { return static_cast<int>(unpack16(tot[r], ii)); });
     }
 }
 
@@ -486,35 +386,16 @@ __global__ __launch_bounds__(256, LDSFEED ? ((TIES && RJ > 1) ? 2 : ((TIES || MU
 // (it, q, j, e) = pair (32 it + 8 q + e, j): one 16-byte load or store per lane, coalesced over j.
 __device__ __forceinline__ size_t gc_index(int it, int q, int j, int Gp) { return (static_cast<size_t>(it * 4 + q) * Gp + j) * 8; }
 
-// block -> tile mapping shared by k1_pairs, k1_group_counts and k1_classify
-template <int RI, int RJ>
-__device__ __forceinline__ bool tile_of_block(const K1Args &a, int &i0, int &jc)
+template <int NB, bool TIES>
+__global__ __launch_bounds__(256, 2) void k1_group_counts(K1Args a, uint16_t *__restrict__ planes, size_t plane_elems)
 {
-    const int slot = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int bu = kUnitH * a.Q;
-    const int u = (q / bu) * 8 + slot;
-    if (u >= a.n_units) return false;
-    const uint32_t um = a.unit_map[u];
-    const int wq = q % bu;
-    const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + wq / a.Q;
-    jc = static_cast<int>(um >> 16) * a.Q + wq % a.Q;
-    i0 = it * RI;
-    constexpr int CJ = kTileJ * RJ;
-    if (i0 >= a.Gp || jc * CJ >= a.Gp) return false;
-    return ((jc * CJ + CJ - 1) >> 6) >= (i0 >> 6);  // whole workgroups only: barriers inside
-}
-
-template <int RI, int RJ, bool TIES, bool LDSFEED>
-__global__ __launch_bounds__(256, (TIES && RJ > 1) ? 2 : 3) void k1_group_counts(K1Args a, uint16_t *__restrict__ planes, size_t plane_elems)
-{
-    static_assert(RI == 32, "four quarters of 8 rows per tile");
-    int i0, jc;
-    if (!tile_of_block<RI, RJ>(a, i0, jc)) return;
-    const int j0 = jc * (kTileJ * RJ) + threadIdx.x;
-    __shared__ float4v sm_lo[LDSFEED ? 2 * kStage * 8 : 1];
-    __shared__ float4v sm_hi[(LDSFEED && TIES) ? 2 * kStage * 8 : 1];
-    const bool idle = wave_idle<RJ>(j0 & ~63, i0, a.G);
-    float2v gt[RJ][RI / 2], ge[RJ][RI / 2];
+    constexpr int RI = kTileI, RJ = TIES ? kRJTies : kRJ;
+    int i0, jl;
+    if (!tile_of_block<RI, RJ>(a, i0, jl)) return;
+    __shared__ uint4 sm_lo[2 * kStageB * RI * 4];
+    __shared__ uint4 sm_hi[TIES ? 2 * kStageB * RI * 4 : 1];
+    const bool idle = wave_idle<RJ>(jl & ~63, i0, a.G);
+    uint32_t gt[RJ][RI / 2], ge[TIES ? RJ : 1][RI / 2];
     uint32_t tot[RJ][RI / 2];  // two u16 sums per register (sums are at most S < 65536)
 #pragma unroll
     for (int r = 0; r < RJ; ++r)
@@ -522,22 +403,19 @@ __global__ __launch_bounds__(256, (TIES && RJ > 1) ? 2 : 3) void k1_group_counts
         for (int h = 0; h < RI / 2; ++h) tot[r][h] = 0;
     const int it = i0 / RI;
     for (int g = 0; g < a.ngroups; ++g) {
-        if (LDSFEED) count_pass_lds<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi, idle);
-        else count_pass<RI, RJ, TIES>(a.pos8, a.lo, a.hi, a.Gp, i0, j0, a.goff[g], a.goff[g + 1], gt, ge);
+        count_pass<RJ, NB, TIES>(a.P, a.AL, a.AH, a.Gp, i0, jl, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi, idle);
         uint16_t *plane = planes + static_cast<size_t>(g) * plane_elems;
 #pragma unroll
         for (int r = 0; r < RJ; ++r) {
-            const int j = j0 + 256 * r;
+            const int j = jl + 64 * r;
             uint32_t pk[RI / 2];
 #pragma unroll
             for (int h = 0; h < RI / 2; ++h) {
-                uint32_t n0 = static_cast<uint32_t>(gt[r][h].x), n1 = static_cast<uint32_t>(gt[r][h].y);
                 if (TIES) {
-                    const uint32_t e0 = static_cast<uint32_t>(ge[r][h].x - gt[r][h].x), e1 = static_cast<uint32_t>(ge[r][h].y - gt[r][h].y);
-                    if (e0) n0 += tie_wins(a.seed, i0 + 2 * h, j, g, e0);
-                    if (e1) n1 += tie_wins(a.seed, i0 + 2 * h + 1, j, g, e1);
-                }
-                pk[h] = n0 | (n1 << 16);
+                    const uint32_t n0 = count_with_coins<RJ, TIES>(gt, ge, a.seed, i0, jl, r, 2 * h, g);
+                    const uint32_t n1 = count_with_coins<RJ, TIES>(gt, ge, a.seed, i0, jl, r, 2 * h + 1, g);
+                    pk[h] = n0 | (n1 << 16);
+                } else pk[h] = gt[r][h];
                 tot[r][h] += pk[h];  // no carry between the halves: each half-sum stays below 2^16
             }
             if (j < a.Gp) {
@@ -550,7 +428,7 @@ __global__ __launch_bounds__(256, (TIES && RJ > 1) ? 2 : 3) void k1_group_counts
     uint16_t *plane = planes + static_cast<size_t>(a.ngroups) * plane_elems;
 #pragma unroll
     for (int r = 0; r < RJ; ++r) {
-        const int j = j0 + 256 * r;
+        const int j = jl + 64 * r;
         if (j < a.Gp) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -561,20 +439,20 @@ __global__ __launch_bounds__(256, (TIES && RJ > 1) ? 2 : 3) void k1_group_counts
 
 // Classify comparison k from the stored counts.  HBM-bound: 2 x 64 B read per (tile, gene j),
 // the class-table words written as in k1_pairs.
-template <int RI, int RJ>
+template <int RJ>
 __global__ __launch_bounds__(256) void k1_classify(K1Args a, const uint16_t *__restrict__ planes, size_t plane_elems)
 {
-    int i0, jc;
-    if (!tile_of_block<RI, RJ>(a, i0, jc)) return;
+    constexpr int RI = kTileI;
+    int i0, jl;
+    if (!tile_of_block<RI, RJ>(a, i0, jl)) return;
     const int lane = threadIdx.x & 63;
-    const int j0 = jc * (kTileJ * RJ) + threadIdx.x;
     const int it = i0 / RI;
     const uint16_t *pk = planes + static_cast<size_t>(a.gc) * plane_elems;
     const uint16_t *pt = planes + static_cast<size_t>(a.ngroups) * plane_elems;
     uint32_t wk[RJ][RI / 2], wt[RJ][RI / 2];  // two u16 counts per register
 #pragma unroll
     for (int r = 0; r < RJ; ++r) {
-        const int j = j0 + 256 * r;
+        const int j = jl + 64 * r;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint4 vk = {0, 0, 0, 0}, vt = {0, 0, 0, 0};
@@ -586,39 +464,45 @@ __global__ __launch_bounds__(256) void k1_classify(K1Args a, const uint16_t *__r
             wt[r][4 * q] = vt.x; wt[r][4 * q + 1] = vt.y; wt[r][4 * q + 2] = vt.z; wt[r][4 * q + 3] = vt.w;
         }
     }
-    auto nk_of = [&](int r, int ii) -> int { return static_cast<int>((wk[r][ii >> 1] >> (16 * (ii & 1))) & 0xFFFFu); };
-    auto nt_of = [&](int r, int ii) -> int { return static_cast<int>((wt[r][ii >> 1] >> (16 * (ii & 1))) & 0xFFFFu) - nk_of(r, ii); };
-    emit_side<RI, RJ, int>(a, i0, j0, i0 >> 6, lane, 0, a.m1, a.nc - a.m1, nk_of);
-    emit_side<RI, RJ, int>(a, i0, j0, i0 >> 6, lane, 2, a.m2, a.nt - a.m2, nt_of);
+    auto nk_of = [&](int r, int ii) -> int { return static_cast<int>(unpack16(wk[r], ii)); };
+    auto nt_of = [&](int r, int ii) -> int { return static_cast<int>(unpack16(wt[r], ii)) - nk_of(r, ii); };
+    emit_side<RI, RJ>(a, i0, jl, i0 >> 6, lane, 0, a.m1, a.nc - a.m1, nk_of);
+    emit_side<RI, RJ>(a, i0, jl, i0 >> 6, lane, 2, a.m2, a.nt - a.m2, nt_of);
 }
 
-// Parity hook: same inner loop, writes the raw counts of a block of ordered pairs.
-template <int RI>
-__global__ __launch_bounds__(256) void k1_counts(const uint4 *__restrict__ pos, const float *__restrict__ lo,
-                                                 const float *__restrict__ hi, int Gp,
-                                                 const int32_t *__restrict__ goff, int ngroups, int ibase,
-                                                 int jbase, int ci0, int ci1, int cj0, int cj1,
+// Parity hook: the raw counts of a block of ordered pairs, one thread per pair, the same borrow chain over the
+// same planes as count_pass (plain loads, no staging: blocks of a few hundred genes).
+__global__ __launch_bounds__(256) void k1_counts(const uint4 *__restrict__ P, const uint4 *__restrict__ AL,
+                                                 const uint4 *__restrict__ AH, int Gp, int nbits,
+                                                 const int32_t *__restrict__ goff, int ngroups, int ci0, int ci1, int cj0, int cj1,
                                                  uint16_t *__restrict__ out_gt, uint16_t *__restrict__ out_eq)
 {
-    const int i0 = ibase + blockIdx.y * RI;
-    const int j = jbase + blockIdx.x * kTileJ + threadIdx.x;
-    float2v gt[1][RI / 2], ge[1][RI / 2];
+    const int j = cj0 + blockIdx.x * 256 + threadIdx.x, i = ci0 + blockIdx.y;
+    if (j >= cj1 || i >= ci1) return;
     const int nj = cj1 - cj0;
     for (int g = 0; g < ngroups; ++g) {
-        count_pass<RI, 1, true>(pos, lo, hi, Gp, i0, j, goff[g], goff[g + 1], gt, ge);
-        if (j >= cj0 && j < cj1) {
+        uint32_t n_gt = 0, n_ge = 0;
+        for (int b = goff[g]; b < goff[g + 1]; ++b) {
+            Planes16 p, lo, hi;
 #pragma unroll
-            for (int ii = 0; ii < RI; ++ii) {
-                const int i = i0 + ii;
-                if (i >= ci0 && i < ci1) {
-                    const size_t o = (static_cast<size_t>(i - ci0) * nj + (j - cj0)) * ngroups + g;
-                    const float fgt = (ii & 1) ? gt[0][ii >> 1].y : gt[0][ii >> 1].x;
-                    const float fge = (ii & 1) ? ge[0][ii >> 1].y : ge[0][ii >> 1].x;
-                    out_gt[o] = static_cast<uint16_t>(fgt);
-                    out_eq[o] = static_cast<uint16_t>(fge - fgt);
-                }
+            for (int q = 0; q < 4; ++q) {
+                p.set(q, P[(static_cast<size_t>(b) * 4 + q) * Gp + j]);
+                lo.set(q, AL[(static_cast<size_t>(b) * Gp + i) * 4 + q]);
+                hi.set(q, AH[(static_cast<size_t>(b) * Gp + i) * 4 + q]);
             }
+            uint32_t lt = 0, le = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k >= nbits) break;
+                lt = __builtin_amdgcn_bitop3_b32(p.w[k], lo.w[a_word(k)], lt, 0x8e);
+                le = __builtin_amdgcn_bitop3_b32(p.w[k], hi.w[a_word(k)], le, 0x8e);
+            }
+            n_gt += __builtin_popcount(lt);
+            n_ge += __builtin_popcount(le);
         }
+        const size_t o = (static_cast<size_t>(i - ci0) * nj + (j - cj0)) * ngroups + g;
+        out_gt[o] = static_cast<uint16_t>(n_gt);
+        out_eq[o] = static_cast<uint16_t>(n_ge - n_gt);
     }
 }
 
@@ -652,9 +536,8 @@ __global__ __launch_bounds__(256) void k_pack_ref(const uint8_t *__restrict__ by
 // ---------------------------------------------------------------------------
 // K2: one wave per gene row.  Streams the row's four planes (16 B per lane per
 // load, fully coalesced), ANDs with the reference mask and popcounts.  Raw
-// counters: 0 cL, 1 cH, 2 tL, 3 tH (marginals), 4 LL, 5 LH, 6 HL, 7 HH.  They
-// are linear in the table, so shards can be summed before the 9 tallies are
-// derived (k3_derive).  HBM-bound: 16 VALU ops per 32 pairs.
+// counters: 0 cL, 1 cH, 2 tL, 3 tH (marginals), 4 LL, 5 LH, 6 HL, 7 HH.  The 9 tallies
+// follow from them in k3_derive.  HBM-bound: 16 VALU ops per 32 pairs.
 __device__ __forceinline__ void tally_word(uint32_t cl, uint32_t ch, uint32_t tl, uint32_t th, uint32_t m,
                                            uint32_t (&c)[kRaw])
 {
@@ -663,21 +546,15 @@ __device__ __forceinline__ void tally_word(uint32_t cl, uint32_t ch, uint32_t tl
     c[4] += __popc(cl & tl); c[5] += __popc(cl & th); c[6] += __popc(ch & tl); c[7] += __popc(ch & th);
 }
 
-// own: with G-sharding, one bit per 16-byte chunk of a row and per 32-row block: set iff this shard
-// wrote anything there (the rest of its table is zero and need not be read); nullptr = everything.
-// raw2 (sharded runs): a second copy of the counters, the one the all-reduce then sums in place
 __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, const uint4 *__restrict__ refbits, int G, int Wq,
-                                           const uint32_t *__restrict__ own, int own_words, int32_t *__restrict__ raw,
-                                           int32_t *__restrict__ raw2)
+                                           int32_t *__restrict__ raw)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= G) return;
     const uint4 *r = table + static_cast<size_t>(row) * kPlanes * Wq;
-    const uint32_t *ow = own ? own + static_cast<size_t>(row >> 5) * own_words : nullptr;
     uint32_t c[kRaw] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = lane; q < Wq; q += 64) {
-        if (ow && !((ow[q >> 5] >> (q & 31)) & 1u)) continue;
         const uint4 m = refbits[q];
         const uint4 cl = r[q], ch = r[Wq + q], tl = r[2 * Wq + q], th = r[3 * Wq + q];
         tally_word(cl.x, ch.x, tl.x, th.x, m.x, c);
@@ -696,10 +573,6 @@ __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, cons
         int4 *o = reinterpret_cast<int4 *>(raw + static_cast<size_t>(row) * kRaw);
         o[0] = make_int4(c[0], c[1], c[2], c[3]);
         o[1] = make_int4(c[4], c[5], c[6], c[7]);
-        if (raw2) {
-            int4 *o2 = reinterpret_cast<int4 *>(raw2 + static_cast<size_t>(row) * kRaw);
-            o2[0] = o[0]; o2[1] = o[1];
-        }
     }
 }
 
@@ -709,7 +582,7 @@ __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, cons
 // (leaving) the reference set adds (removes), for every gene i, the class bits found at bit i of ROW j:
 // one contiguous row per changed gene instead of the whole table.  Exact (integer sums).
 __device__ __forceinline__ void delta_genes(const uint32_t *__restrict__ table, int G, int Wp, const uint32_t *__restrict__ list,
-                                            int n, int32_t *__restrict__ raw, int32_t *__restrict__ raw2)
+                                            int n, int32_t *__restrict__ raw)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= G) return;
@@ -730,25 +603,20 @@ __device__ __forceinline__ void delta_genes(const uint32_t *__restrict__ table, 
     a.x += d[0]; a.y += d[1]; a.z += d[2]; a.w += d[3];
     b.x += d[4]; b.y += d[5]; b.z += d[6]; b.w += d[7];
     o[0] = a; o[1] = b;
-    if (raw2) {
-        int4 *o2 = reinterpret_cast<int4 *>(raw2 + static_cast<size_t>(i) * kRaw);
-        o2[0] = a; o2[1] = b;
-    }
 }
 
 // The K2 stage of one pass: one launch, the device picks the form.  slot < 0: always a full scan.
 __global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st, const uint32_t *__restrict__ table,
                                                 const uint4 *__restrict__ refbits, int G, int Wp,
-                                                const uint32_t *__restrict__ own, int own_words,
-                                                int32_t *__restrict__ raw, int32_t *__restrict__ raw2, int slot,
+                                                int32_t *__restrict__ raw, int slot,
                                                 const uint32_t *__restrict__ list, int32_t *__restrict__ modes)
 {
     if (st->done) return;
     const int n = slot >= 0 ? st->delta_cnt[slot] : kDeltaMax + 1;
     const bool full = n > kDeltaMax;
     if (modes && blockIdx.x == 0 && threadIdx.x == 0) modes[st->passes] = full ? 1 : 0;  // for the stage timers
-    if (full) tally_rows(reinterpret_cast<const uint4 *>(table), refbits, G, Wp / 4, own, own_words, raw, raw2);
-    else if (static_cast<int>(blockIdx.x) * 256 < G) delta_genes(table, G, Wp, list, n, raw, raw2);
+    if (full) tally_rows(reinterpret_cast<const uint4 *>(table), refbits, G, Wp / 4, raw);
+    else if (static_cast<int>(blockIdx.x) * 256 < G) delta_genes(table, G, Wp, list, n, raw);
 }
 
 // ---------------------------------------------------------------------------
@@ -1215,15 +1083,38 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
 
 // ------------------------------------------------------------------ launchers
 
+// bits needed for every number the pair kernel compares: positions 0..G-1 and band ends up to G
+static int plane_bits(int64_t G) { return G <= 4095 ? 12 : (G <= 32767 ? 15 : 16); }
+
+template <int NB>
+static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool shared, bool multi, size_t plane_elems)
+{
+    if (shared) {
+        if (!c->gc_valid) {
+            if (c->has_ties) k1_group_counts<NB, true><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+            else k1_group_counts<NB, false><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+            c->gc_valid = true;
+        }
+        if (c->has_ties) k1_classify<kRJTies><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+        else k1_classify<kRJ><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+    } else if (multi) {
+        if (c->has_ties) k1_pairs<NB, true, true><<<grid, 256, 0, c->stream>>>(a);
+        else k1_pairs<NB, false, true><<<grid, 256, 0, c->stream>>>(a);
+    } else {
+        if (c->has_ties) k1_pairs<NB, true, false><<<grid, 256, 0, c->stream>>>(a);
+        else k1_pairs<NB, false, false><<<grid, 256, 0, c->stream>>>(a);
+    }
+}
+
 int32_t launch_k1(reo_ctx *c, int k)
 {
     K1Args a;
-    a.pos8 = reinterpret_cast<const uint4 *>(c->pos.p); a.lo = c->lo.p; a.hi = c->hi.p; a.table = c->table.p;
+    a.P = c->pos.p; a.AL = c->lo.p; a.AH = c->hi.p; a.table = c->table.p;
     a.G = static_cast<int>(c->G); a.Gp = c->Gp; a.Wp = c->Wp;
     const bool multi = c->ngroups > 2;
     const int other = multi ? k : 1 - k;  // two groups: the treat side is the other group
-    a.cb = c->goff8[k] / 8; a.ce = c->goff8[k + 1] / 8;
-    a.tb = c->goff8[other] / 8; a.te = c->goff8[other + 1] / 8;
+    a.cb = c->goff32[k] / 32; a.ce = c->goff32[k + 1] / 32;
+    a.tb = c->goff32[other] / 32; a.te = c->goff32[other + 1] / 32;
     a.gc = k; a.gt = other;
     a.nc = c->goff[k + 1] - c->goff[k]; a.nt = static_cast<int>(c->S) - a.nc;  // gsi1, gsi2 (:358-359)
     a.goff = c->goff_dev.p; a.ngroups = c->ngroups;
@@ -1231,20 +1122,16 @@ int32_t launch_k1(reo_ctx *c, int k)
     a.seed = c->seed;
 
     // work units: panel p = Q consecutive j-chunks, cut into i-ranges of kUnitH tiles.  Q keeps the
-    // panel's pos slice (Q x 256 genes x S8 slots x 2 B) within about 2 MiB of the 4 MiB L2 of an XCD.
+    // panel's pos planes (Q x 256 RJ genes x nblk blocks x 64 B) within about 2 MiB of the 4 MiB L2 of an XCD.
     const int RJ = c->has_ties ? kRJTies : kRJ;  // genes j per lane
     const int CJ = kTileJ * RJ;
     const int NJ = (c->Gp + CJ - 1) / CJ, NIT = c->Gp / kTileI;
-    const size_t chunk_bytes = static_cast<size_t>(CJ) * c->goff8[c->ngroups] * 2;
+    const size_t chunk_bytes = static_cast<size_t>(CJ) * (c->goff32[c->ngroups] / 32) * 64;
     const int Q = chunk_bytes * 4 <= (2u << 20) ? 4 : (chunk_bytes * 2 <= (2u << 20) ? 2 : 1);
     const int NP = (NJ + Q - 1) / Q;
     std::vector<uint32_t> units;
     int64_t owned = 0, total = 0;
     uint32_t gu = 0;
-    // chunk-ownership mask for K2 (16-byte chunks = 128 columns; one row of bits per 32-row block)
-    const int Wq = c->Wp / 4, own_words = (Wq + 31) / 32, nblk32 = c->Gp / 32;
-    std::vector<uint32_t> ownm(c->world > 1 ? static_cast<size_t>(nblk32) * own_words : 0, 0u);
-    auto mark = [&](int rowblk, int chunk) { ownm[static_cast<size_t>(rowblk) * own_words + (chunk >> 5)] |= 1u << (chunk & 31); };
     for (int p = 0; p < NP; ++p) {
         const int ni = std::min(NIT, (CJ / kTileI) * Q * (p + 1));  // i-tiles that reach this panel's columns
         for (int r = 0; r * kUnitH < ni; ++r, ++gu) {
@@ -1255,28 +1142,18 @@ int32_t launch_k1(reo_ctx *c, int k)
                     if ((jc * CJ + CJ - 1) / 64 < (t * kTileI) / 64) continue;
                     ++total;
                     if (mine) ++owned;
-                    if (mine && c->world > 1) {
-                        // forward bits: rows of tile t, columns of chunk jc; mirror bits: rows of chunk jc, columns of tile t
-                        for (int q = jc * CJ / 128; q < std::min(Wq, (jc + 1) * CJ / 128); ++q) mark(t, q);
-                        for (int rb = jc * CJ / 32; rb < std::min(nblk32, (jc + 1) * CJ / 32); ++rb) mark(rb, (t * kTileI) / 128);
-                    }
                 }
         }
     }
     c->tiles_owned = owned; c->tiles_total = total;
     c->k1_cj = CJ; c->k1_q = Q;
-    c->own_words = own_words;
-    if (c->world > 1) {
-        int32_t rc0;
-        if ((rc0 = c->own_mask.ensure(ownm.size()))) return rc0;
-        REO_HIP_CHECK(hipMemcpyAsync(c->own_mask.p, ownm.data(), ownm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    }
     a.n_units = static_cast<int>(units.size()); a.Q = Q;
     int32_t rc;
     if ((rc = c->unit_map.ensure(std::max<size_t>(units.size(), 1)))) return rc;
-    if (!units.empty())
+    if (!units.empty()) {
         REO_HIP_CHECK(hipMemcpyAsync(c->unit_map.p, units.data(), units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `units` is a local: the copy must have read it before any return below
+    }
     a.unit_map = c->unit_map.p;
     REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
     if (units.empty()) return REO_OK;
@@ -1290,39 +1167,25 @@ int32_t launch_k1(reo_ctx *c, int k)
         const size_t need = plane_elems * (c->ngroups + 1) * sizeof(uint16_t);
         const size_t have = c->gcounts.n * sizeof(uint16_t);
         if (need > have && need - have + (size_t(4) << 30) > free_b) shared = false;  // keep 4 GiB for everything else
+        if (shared && (rc = c->gcounts.ensure(plane_elems * (c->ngroups + 1)))) return rc;
     }
     c->last_k1_shared = shared ? 1 : 0;
     tic(c, 1);
-    if (shared) {
-        if (!c->gc_valid) {
-            if ((rc = c->gcounts.ensure(plane_elems * (c->ngroups + 1)))) { toc(c); return rc; }
-            if (c->has_ties) k1_group_counts<kTileI, kRJTies, true, kLdsTies><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
-            else k1_group_counts<kTileI, kRJ, false, true><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
-            c->gc_valid = true;
-        }
-        if (c->has_ties) k1_classify<kTileI, kRJTies><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
-        else k1_classify<kTileI, kRJ><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
-    } else if (multi) {
-        if (c->has_ties) k1_pairs<kTileI, kRJTies, true, true, kLdsTies><<<grid, 256, 0, c->stream>>>(a);
-        else k1_pairs<kTileI, kRJ, false, true, true><<<grid, 256, 0, c->stream>>>(a);
-    } else {
-        if (c->has_ties) k1_pairs<kTileI, kRJTies, true, false, kLdsTies><<<grid, 256, 0, c->stream>>>(a);
-        else k1_pairs<kTileI, kRJ, false, false, true><<<grid, 256, 0, c->stream>>>(a);
+    switch (plane_bits(c->G)) {
+    case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems); break;
+    case 15: launch_pair_kernels<15>(c, a, grid, shared, multi, plane_elems); break;
+    default: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems); break;
     }
     toc(c);
     REO_HIP_CHECK(hipGetLastError());
-    REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `units` is read by the async copy above
     return REO_OK;
 }
 
 int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq)
 {
-    const int ibase = static_cast<int>(i0 / kTileI) * kTileI, jbase = static_cast<int>(j0 / kTileJ) * kTileJ;
-    dim3 grid(static_cast<unsigned>((j1 - jbase + kTileJ - 1) / kTileJ),
-              static_cast<unsigned>((i1 - ibase + kTileI - 1) / kTileI));
-    k1_counts<kTileI><<<grid, 256, 0, c->stream>>>(reinterpret_cast<const uint4 *>(c->pos.p), c->lo.p, c->hi.p, c->Gp, c->goff_dev.p, c->ngroups,
-                                                   ibase, jbase, static_cast<int>(i0), static_cast<int>(i1),
-                                                   static_cast<int>(j0), static_cast<int>(j1), d_gt, d_eq);
+    dim3 grid(static_cast<unsigned>((j1 - j0 + 255) / 256), static_cast<unsigned>(i1 - i0));
+    k1_counts<<<grid, 256, 0, c->stream>>>(c->pos.p, c->lo.p, c->hi.p, c->Gp, plane_bits(c->G), c->goff_dev.p, c->ngroups,
+                                           static_cast<int>(i0), static_cast<int>(i1), static_cast<int>(j0), static_cast<int>(j1), d_gt, d_eq);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -1346,12 +1209,9 @@ int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits)
 int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits, int slot, bool allow_delta)
 {
     const int G = static_cast<int>(c->G);
-    int32_t *raw = c->world > 1 ? c->raw_local.p : c->raw.p;  // shards keep their own counters, the sum goes to raw
     tic(c, 2);
     k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(c->state.p, c->table.p, reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp,
-                                                 c->world > 1 ? c->own_mask.p : nullptr, c->own_words, raw,
-                                                 c->world > 1 ? c->raw.p : nullptr,  // the copy the all-reduce sums in place
-                                                 allow_delta ? slot : -1,
+                                                 c->raw.p, allow_delta ? slot : -1,
                                                  allow_delta ? c->delta_list.p + static_cast<size_t>(slot) * c->Gp : nullptr,
                                                  allow_delta ? c->modes.p : nullptr);
     toc(c);

@@ -12,13 +12,13 @@
 
 namespace reo {
 
-constexpr int kTileJ = 256;   // genes per workgroup along j (4 waves x 64 lanes)
+constexpr int kTileJ = 256;   // lanes per workgroup along j (4 waves x 64 lanes)
 constexpr int kTileI = 32;    // gene rows per pair tile (one mirror word)
 constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kUnitH = 32;    // i-tiles per K1 work unit
-constexpr int kRJ = 2;        // genes j per lane in the tie-free pair kernel
-constexpr int kRJTies = 1;    // genes j per lane in the tie-rich pair kernel
-constexpr bool kLdsTies = true;  // tie-rich kernel: band edges through LDS (true) or the scalar cache (false)
+constexpr int kRJ = 4;        // genes j per lane in the tie-free pair kernel
+constexpr int kRJTies = 2;    // genes j per lane in the tie-rich pair kernel (two band edges per pair)
+constexpr int kGenePad = 1024;  // Gp is a multiple of this (= kTileJ * kRJ: every lane's genes exist)
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
 constexpr int kDeltaMax = 128;   // at most this many changed reference genes: update the tallies incrementally
 constexpr int kSortChunk = 1024; // genes per bitonic sort in the ranking stage
@@ -97,20 +97,20 @@ struct reo_ctx {
 
     // rank/band transform output (samples re-ordered so groups are contiguous)
     int Gp = 0, Wp = 0;  // padded gene count, 32-bit words per bit row
-    std::vector<int32_t> goff;  // ngroups+1 offsets into the sorted sample order
-    std::vector<int32_t> goff8; // the same with every group padded to a multiple of 8 sample slots
-    reo::DevBuf<uint16_t> pos;  // [S8/8][Gp][8] position of gene in its sample's sorted order, 8 slots per 16 B
-    reo::DevBuf<float> lo;      // [S8][Gp] first position of the tie band (exact integer in fp32)
-    reo::DevBuf<float> hi;      // [S8][Gp] one past the last position of the tie band
-    reo::DevBuf<int32_t> goff_dev;
+    std::vector<int32_t> goff;   // ngroups+1 offsets into the sorted sample order
+    std::vector<int32_t> goff32; // the same with every group padded to whole blocks of 32 sample slots
+    // bit planes over 32-sample blocks (transform.hip, t_slice); nblk = goff32.back() / 32
+    reo::DevBuf<uint4> pos;     // [nblk][4][Gp]  planes 4q..4q+3 of the position of gene g in its sample's sorted order
+    reo::DevBuf<uint4> lo;      // [nblk][Gp][4]  16 plane words of the first position of the tie band (plane k in word (k+15)%16)
+    reo::DevBuf<uint4> hi;      // [nblk][Gp][4]  the same for one past the last position of the tie band
+    reo::DevBuf<uint16_t> t_pos16, t_lo16, t_hi16;  // [S32][Gp] the three numbers before slicing (scratch)
+    reo::DevBuf<int32_t> goff_dev;  // group offsets in blocks
     // transform scratch (grow-only, freed with the context)
     reo::DevBuf<uint64_t> t_kin, t_kout;
     reo::DevBuf<uint16_t> t_vin, t_vout;
     reo::DevBuf<unsigned char> t_temp;
     reo::DevBuf<int32_t> t_order, t_flags, t_slots;
     reo::DevBuf<uint32_t> unit_map;  // K1 work units: panel << 16 | i-range
-    reo::DevBuf<uint32_t> own_mask;  // [Gp/32][own_words] chunks of the class table this shard wrote (world > 1)
-    int own_words = 0;
     bool transformed = false;
     int has_ties = 0;
     int transform_in_lds = 0;  // the last transform sorted each sample inside one workgroup's LDS (transform.hip)
@@ -118,6 +118,9 @@ struct reo_ctx {
     // class table: [G][4 planes][Wp] 32-bit words
     reo::DevBuf<uint32_t> table;
     int built_k = -1;
+    bool table_complete = false;        // world > 1: the shards' parts have been summed (api.hip, exchange_table)
+    void *comm = nullptr;               // ncclComm_t of the in-library RCCL path (comm.hip), or null
+    std::vector<reo_ctx *> peers;       // reo_create_multi: the contexts of devices 1.. owned by this (leader) context
     // one-vs-rest with > 2 groups: per-group pair counts shared by the comparisons (kernels.hip, k1_group_counts)
     reo::DevBuf<uint16_t> gcounts;      // [ngroups + 1][Gp/32][4][Gp][8]
     bool gc_valid = false;
@@ -129,8 +132,7 @@ struct reo_ctx {
     // iteration state
     reo::DevBuf<uint32_t> refbits[2];   // [Wp]
     reo::DevBuf<uint8_t> refbytes[2];   // [Gp]
-    reo::DevBuf<int32_t> raw;           // [G][8] (summed over shards when world > 1)
-    reo::DevBuf<int32_t> raw_local;     // [G][8] this shard's own counters (world > 1 only)
+    reo::DevBuf<int32_t> raw;           // [G][8]
     reo::DevBuf<uint32_t> delta_list;   // [2][Gp] changed genes (gene << 1 | added) per pass parity
     reo::DevBuf<int32_t> cont;          // [G][9]
     reo::DevBuf<double> result;         // [15][G]
@@ -171,6 +173,11 @@ int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits, int slot, bool allow_de
 int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int with_stats);
 int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int n_conv, int64_t a, int64_t b);
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
+
+// comm.hip: in-library RCCL.  Returns REO_OK after enqueueing the sum on c->stream, 1 when no communicator is attached
+int32_t comm_allreduce_table(reo_ctx *c, int64_t count);
+void comm_release(reo_ctx *c);
+int32_t multi_build_pairs(reo_ctx *lead, int32_t k, int32_t (*build_local)(reo_ctx *, int32_t));
 
 // timing helpers (api.hip)
 void tic(reo_ctx *c, int slot);

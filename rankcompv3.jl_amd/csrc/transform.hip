@@ -12,6 +12,11 @@
 // into the same two 16-bit integer compares for the pair kernel.  The band
 // edges are found with the reference's own predicate evaluated in the input's
 // arithmetic, so the result is exact, not approximate.
+//
+// Output for the pair kernel (kernels.hip): the three 16-bit numbers of every (gene, sample) leave as BIT
+// PLANES over blocks of 32 samples (t_slice), because [pos_j < lo_i] for 32 samples at once is a borrow chain
+// of one v_bitop3_b32 per bit.  Every group is padded to whole 32-sample blocks; padding samples have
+// lo = hi = 0, which no position is below.
 #include <cstdlib>
 #include <cstring>
 
@@ -84,8 +89,8 @@ template <class T>
 __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys,
                                                const uint16_t *__restrict__ idx, int G, int Gp, int cb0,
                                                const int32_t *__restrict__ slots,
-                                               uint16_t *__restrict__ pos, float *__restrict__ lo,
-                                               float *__restrict__ hi, int32_t *__restrict__ anytie)
+                                               uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
+                                               uint16_t *__restrict__ hi, int32_t *__restrict__ anytie)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
     int c = blockIdx.y;
@@ -116,17 +121,18 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
     }
     int g = idx[static_cast<size_t>(c) * G + p];
     const int slot = slots[cb0 + c];  // sample slot in the group-padded order
-    pos[(static_cast<size_t>(slot >> 3) * Gp + g) * 8 + (slot & 7)] = static_cast<uint16_t>(p);
     const size_t o = static_cast<size_t>(slot) * Gp + g;
-    lo[o] = static_cast<float>(l);
-    hi[o] = static_cast<float>(h + 1);
+    pos[o] = static_cast<uint16_t>(p);
+    lo[o] = static_cast<uint16_t>(l);
+    hi[o] = static_cast<uint16_t>(h + 1);
 }
 
 // One workgroup per sample, everything in LDS: when the varying key bits fit 31 bits and the genes fit
 // 1024 x IPT items, the sample's column is read once, sorted with a block radix sort (rocprim block
 // primitive, keys in registers, exchange through LDS), the tie bands are searched in the LDS copy of the
-// sorted keys, and lo / hi leave as whole coalesced rows.  HBM traffic: the matrix once in, pos / lo / hi
-// once out, instead of keys out, two sort passes in and out, keys in again.
+// sorted keys, and pos / lo / hi leave in gene order as whole coalesced rows of 16-bit numbers.  HBM
+// traffic: the matrix once in, three u16 rows once out, instead of keys out, two sort passes in and out,
+// keys in again.
 // Key = the varying bits (begin_bit .. begin_bit + nbits - 1) of the order-preserving code; bit `nbits`
 // marks padding items, which sort behind every gene.
 // flags: 0 non-finite input, 1 some tie, 4 some sample needs more than 31 key bits (the caller then
@@ -134,18 +140,14 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
 template <class T, int IPT>
 __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
                                                  const int32_t *__restrict__ slots, int G, int Gp, int S,
-                                                 uint16_t *__restrict__ pos, float *__restrict__ lo,
-                                                 float *__restrict__ hi, int32_t *__restrict__ flags)
+                                                 uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
+                                                 uint16_t *__restrict__ hi, int32_t *__restrict__ flags)
 {
     using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typename sorter::storage_type &storage = *reinterpret_cast<typename sorter::storage_type *>(smem);
     const int t = threadIdx.x;
-    // Workgroups are dealt round-robin over the 8 XCDs.  The 8 samples of one 16-byte pos group are written
-    // as 2-byte pieces by 8 different workgroups; only when those run on the SAME XCD do the pieces meet in
-    // one L2 and leave as whole lines.  Measured WRITE_SIZE with c = blockIdx.x: 896 MB for 200 MB of output.
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int c = (((q >> 3) << 3) + xcd) * 8 + (q & 7);  // 8 consecutive workgroups of an XCD = 8 consecutive samples
+    const int c = blockIdx.x;  // one sample per workgroup; its three output rows are whole lines of its own
     if (c >= S) return;
     const T *col = X + static_cast<int64_t>(colmap[c]) * ld;
     const int slot = slots[c];
@@ -230,10 +232,10 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     }
     if (tied && *anytie == 0) atomicOr(anytie, 1);
     __syncthreads();  // every search in skey is done: the space becomes lo16 / hi16 indexed by gene
-    constexpr bool kStagePos = IPT <= 24;  // 6 bytes of LDS per gene fit beside nothing else up to 24 576 genes
+    constexpr bool kStagePos = IPT <= 24;  // 6 bytes of LDS per gene fit beside nothing else up to 25 600 genes
     uint16_t *lo16 = reinterpret_cast<uint16_t *>(smem), *hi16 = lo16 + Gp, *pos16 = hi16 + Gp;
-    for (int g = G + t; g < Gp; g += 1024) { lo16[g] = 0; hi16[g] = 0; }  // padded genes are below no band edge
-    uint16_t *prow = pos + static_cast<size_t>(slot >> 3) * Gp * 8 + (slot & 7);
+    for (int g = G + t; g < Gp; g += 1024) { lo16[g] = 0; hi16[g] = 0; if (kStagePos) pos16[g] = 0; }  // padded genes are below no band edge
+    uint16_t *prow = pos + static_cast<size_t>(slot) * Gp;
 #pragma unroll
     for (int e = 0; e < IPT; ++e) {
         const int p = t * IPT + e;
@@ -242,18 +244,57 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         lo16[g] = static_cast<uint16_t>(band[e] & 0xFFFFu);
         hi16[g] = static_cast<uint16_t>(band[e] >> 16);
         if (kStagePos) pos16[g] = static_cast<uint16_t>(p);
-        else prow[static_cast<size_t>(g) * 8] = static_cast<uint16_t>(p);
+        else prow[g] = static_cast<uint16_t>(p);
     }
     __syncthreads();
-    if (kStagePos)  // genes in order: a wave's 64 two-byte pieces fall into 16 consecutive lines, not 64 random ones
-        for (int g = t; g < G; g += 1024) prow[static_cast<size_t>(g) * 8] = pos16[g];
-    float4 *lrow = reinterpret_cast<float4 *>(lo + static_cast<size_t>(slot) * Gp);
-    float4 *hrow = reinterpret_cast<float4 *>(hi + static_cast<size_t>(slot) * Gp);
-    for (int q = t; q < Gp / 4; q += 1024) {
-        const uint2 a = reinterpret_cast<const uint2 *>(lo16)[q], b = reinterpret_cast<const uint2 *>(hi16)[q];
-        lrow[q] = make_float4(static_cast<float>(a.x & 0xFFFFu), static_cast<float>(a.x >> 16), static_cast<float>(a.y & 0xFFFFu), static_cast<float>(a.y >> 16));
-        hrow[q] = make_float4(static_cast<float>(b.x & 0xFFFFu), static_cast<float>(b.x >> 16), static_cast<float>(b.y & 0xFFFFu), static_cast<float>(b.y >> 16));
+    uint4 *lrow = reinterpret_cast<uint4 *>(lo + static_cast<size_t>(slot) * Gp);
+    uint4 *hrow = reinterpret_cast<uint4 *>(hi + static_cast<size_t>(slot) * Gp);
+    for (int q = t; q < Gp / 8; q += 1024) {
+        lrow[q] = reinterpret_cast<const uint4 *>(lo16)[q];
+        hrow[q] = reinterpret_cast<const uint4 *>(hi16)[q];
+        if (kStagePos) reinterpret_cast<uint4 *>(prow)[q] = reinterpret_cast<const uint4 *>(pos16)[q];
     }
+}
+
+// 16-bit rows -> bit planes over 32-sample blocks.  One thread per (gene, block): reads the gene's 32 numbers of
+// each of the three rows (coalesced over genes) and writes
+//   P  [nblk][4][Gp] uint4 : planes 4q..4q+3 of pos of gene g in block b at (b * 4 + q) * Gp + g   (lane operand)
+//   AL [nblk][Gp][4] uint4 : the 16 plane words of lo of gene g in block b at (b * Gp + g) * 4 ..   (tile operand)
+//   AH likewise for hi.
+// In AL / AH plane k sits in word (k + 15) % 16, one word off its place in P: register tuples are even-aligned, so
+// the P word and the A word that meet in one v_bitop3_b32 then never share a VGPR bank (measured: a bit op whose
+// three sources share a bank issues at half rate).
+__global__ __launch_bounds__(256) void t_slice(const uint16_t *__restrict__ pos, const uint16_t *__restrict__ lo,
+                                               const uint16_t *__restrict__ hi, int Gp, uint4 *__restrict__ P,
+                                               uint4 *__restrict__ AL, uint4 *__restrict__ AH)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    const size_t row0 = static_cast<size_t>(b) * 32 * Gp + g;
+    uint32_t w[16];
+    auto planes = [&](const uint16_t *__restrict__ src) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = 0;
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const uint32_t v = src[row0 + static_cast<size_t>(s) * Gp];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[k] |= ((v >> k) & 1u) << s;
+        }
+    };
+    planes(pos);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) P[(static_cast<size_t>(b) * 4 + q) * Gp + g] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+    auto skewed = [&](uint4 *__restrict__ dst) {
+        uint4 *o = dst + (static_cast<size_t>(b) * Gp + g) * 4;
+        o[0] = uint4{w[1], w[2], w[3], w[4]};
+        o[1] = uint4{w[5], w[6], w[7], w[8]};
+        o[2] = uint4{w[9], w[10], w[11], w[12]};
+        o[3] = uint4{w[13], w[14], w[15], w[0]};
+    };
+    planes(lo);
+    skewed(AL);
+    planes(hi);
+    skewed(AH);
 }
 
 template <class T, int IPT>
@@ -263,9 +304,8 @@ int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d
     const size_t lds = std::max(sizeof(typename sorter::storage_type), static_cast<size_t>(IPT <= 24 ? 6 : 4) * c->Gp);
     // every time: the attribute belongs to the (function, device) pair and a process may use several devices
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const unsigned grid = static_cast<unsigned>((c->S + 63) / 64 * 64);  // whole 8 x 8 (XCD, sample) groups
-    t_sample<T, IPT><<<grid, 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp, static_cast<int>(c->S),
-                                                     c->pos.p, c->lo.p, c->hi.p, d_flags);
+    t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
+                                                                            static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -289,18 +329,17 @@ int32_t transform_impl(reo_ctx *c)
     c->goff.assign(c->ngroups + 1, 0);
     for (int s = 0; s < S; ++s) c->goff[c->group_id[s] + 1]++;
     for (int g = 0; g < c->ngroups; ++g) c->goff[g + 1] += c->goff[g];
-    // every group is padded to a multiple of 8 sample slots: the pair kernel reads 8 samples
-    // of a gene with one 16-byte load.  Padding slots hold pos = 0xFFFF, which is below no band
-    // edge (edges are <= G <= 65535), so they add nothing to any count.
-    c->goff8.assign(c->ngroups + 1, 0);
-    for (int g = 0; g < c->ngroups; ++g) c->goff8[g + 1] = c->goff8[g] + (c->goff[g + 1] - c->goff[g] + 7) / 8 * 8;
-    const int S8 = c->goff8[c->ngroups];
-    std::vector<int32_t> slots(S), goff8_units(c->ngroups + 1);
+    // every group is padded to whole blocks of 32 sample slots: the pair kernel compares 32 samples of a pair
+    // per instruction.  Padding slots hold lo = hi = 0, which no position is below, so they add nothing to any count.
+    c->goff32.assign(c->ngroups + 1, 0);
+    for (int g = 0; g < c->ngroups; ++g) c->goff32[g + 1] = c->goff32[g] + (c->goff[g + 1] - c->goff[g] + 31) / 32 * 32;
+    const int S32 = c->goff32[c->ngroups], nblk = S32 / 32;
+    std::vector<int32_t> slots(S), goff_blocks(c->ngroups + 1);
     for (int t = 0; t < S; ++t) {
         const int g = c->group_id[order[t]];
-        slots[t] = c->goff8[g] + (t - c->goff[g]);
+        slots[t] = c->goff32[g] + (t - c->goff[g]);
     }
-    for (int g = 0; g <= c->ngroups; ++g) goff8_units[g] = c->goff8[g] / 8;
+    for (int g = 0; g <= c->ngroups; ++g) goff_blocks[g] = c->goff32[g] / 32;
 
     // scratch lives in the context (grow-only): hipMalloc/hipFree per call cost milliseconds
     DevBuf<int32_t> &d_order = c->t_order, &d_flags = c->t_flags;
@@ -311,26 +350,31 @@ int32_t transform_impl(reo_ctx *c)
     REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
     unsigned long long *d_varbits = reinterpret_cast<unsigned long long *>(d_flags.p + 2);
     if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
-    REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff8_units.data(), sizeof(int32_t) * (c->ngroups + 1),
+    REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff_blocks.data(), sizeof(int32_t) * (c->ngroups + 1),
                                  hipMemcpyHostToDevice, st));
 
-    const size_t n = static_cast<size_t>(S8) * Gp;
-    if ((rc = c->pos.ensure(n)) || (rc = c->lo.ensure(n)) || (rc = c->hi.ensure(n))) return rc;
-    REO_HIP_CHECK(hipMemsetAsync(c->pos.p, 0xFF, n * sizeof(uint16_t), st));
+    const size_t n = static_cast<size_t>(S32) * Gp;            // 16-bit numbers per intermediate row set
+    const size_t nq = static_cast<size_t>(nblk) * Gp * 4;      // uint4 per plane set
+    if ((rc = c->t_pos16.ensure(n)) || (rc = c->t_lo16.ensure(n)) || (rc = c->t_hi16.ensure(n)) ||
+        (rc = c->pos.ensure(nq)) || (rc = c->lo.ensure(nq)) || (rc = c->hi.ensure(nq)))
+        return rc;
+    // rows of padding slots and (segmented path) padded genes: below no band edge
+    REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));
+    REO_HIP_CHECK(hipMemsetAsync(c->t_lo16.p, 0, n * sizeof(uint16_t), st));
+    REO_HIP_CHECK(hipMemsetAsync(c->t_hi16.p, 0, n * sizeof(uint16_t), st));
     const T *X = static_cast<const T *>(c->dX);
+    auto finish = [&](int has_ties) -> int32_t {
+        t_slice<<<dim3(Gp / 256, nblk), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p);
+        REO_HIP_CHECK(hipGetLastError());
+        c->has_ties = has_ties;
+        c->transformed = true;
+        return REO_OK;
+    };
 
     // first choice: every sample sorted inside one workgroup's LDS (t_sample)
     const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort (A/B tests)
     c->transform_in_lds = 0;
     if (G <= 32 * 1024 && !(env && env[0] == 's')) {
-        // rows of the padding slots of every group (at most 7 each): below no band edge
-        for (int g = 0; g < c->ngroups; ++g) {
-            const int first = c->goff8[g] + (c->goff[g + 1] - c->goff[g]), cnt = c->goff8[g + 1] - first;
-            if (cnt > 0) {
-                REO_HIP_CHECK(hipMemsetAsync(c->lo.p + static_cast<size_t>(first) * Gp, 0, static_cast<size_t>(cnt) * Gp * sizeof(float), st));
-                REO_HIP_CHECK(hipMemsetAsync(c->hi.p + static_cast<size_t>(first) * Gp, 0, static_cast<size_t>(cnt) * Gp * sizeof(float), st));
-            }
-        }
         if (G <= 8 * 1024) rc = launch_sample<T, 8>(c, X, d_order.p, d_flags.p);
         else if (G <= 20 * 1024) rc = launch_sample<T, 20>(c, X, d_order.p, d_flags.p);
         else if (G <= 24 * 1024) rc = launch_sample<T, 24>(c, X, d_order.p, d_flags.p);
@@ -345,16 +389,15 @@ int32_t transform_impl(reo_ctx *c)
             return REO_EINVAL;
         }
         if (!fl[4]) {
-            c->has_ties = fl[1];
             c->transform_in_lds = 1;
-            c->transformed = true;
-            return REO_OK;
+            return finish(fl[1]);
         }
         // some sample has keys wider than 31 bits: start over with the segmented sort
         REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_lo16.p, 0, n * sizeof(uint16_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_hi16.p, 0, n * sizeof(uint16_t), st));
     }
-    REO_HIP_CHECK(hipMemsetAsync(c->lo.p, 0, n * sizeof(float), st));
-    REO_HIP_CHECK(hipMemsetAsync(c->hi.p, 0, n * sizeof(float), st));
 
     // column batches: rocprim takes a 32-bit element count
     const int CB = std::max(1, std::min(S, static_cast<int>((1u << 27) / static_cast<unsigned>(G))));
@@ -390,7 +433,7 @@ int32_t transform_impl(reo_ctx *c)
                                                           static_cast<unsigned>(static_cast<size_t>(nc) * G),
                                                           static_cast<unsigned>(nc), seg_begin, seg_begin + 1,
                                                           begin_bit, end_bit, st));
-        t_bands<T><<<grid, 256, 0, st>>>(k_out.p, v_out.p, G, Gp, cb0, c->t_slots.p, c->pos.p, c->lo.p, c->hi.p,
+        t_bands<T><<<grid, 256, 0, st>>>(k_out.p, v_out.p, G, Gp, cb0, c->t_slots.p, c->t_pos16.p, c->t_lo16.p, c->t_hi16.p,
                                          d_flags.p + 1);
     }
     REO_HIP_CHECK(hipGetLastError());
@@ -402,9 +445,7 @@ int32_t transform_impl(reo_ctx *c)
                   "src/RankCompV3.jl:601)");
         return REO_EINVAL;
     }
-    c->has_ties = flags[1];
-    c->transformed = true;
-    return REO_OK;
+    return finish(flags[1]);
 }
 
 }  // namespace

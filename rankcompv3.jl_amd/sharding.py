@@ -5,10 +5,11 @@ multi-GPU protocol can be exercised without a GPU.
 G is sharded by work unit: the upper triangle of the gene x gene pair matrix is
 cut into tiles of TILE_I rows x CHUNK_J columns; a unit = UNIT_H consecutive
 row tiles x Q column chunks of one panel; units are numbered panel-major and
-unit u belongs to shard u % world.  Every shard tallies its own tiles; the raw
-per-gene counters are linear in the table, so an integer all-reduce (sum) over
-the shards followed by `derive_tallies` reproduces the unsharded tallies bit
-for bit (src/RankCompV3.jl:403).
+unit u belongs to shard u % world.  Every shard builds the class-table bits of
+its own tiles (forward and mirror) into a zeroed table; the shards' bits are
+disjoint, so ONE integer all-reduce (sum) of the table gives every shard the
+whole table, and tallies / iteration passes then run unsharded
+(src/RankCompV3.jl:403).
 """
 from __future__ import annotations
 
@@ -16,15 +17,16 @@ import numpy as np
 
 TILE_I = 32     # kTileI
 TILE_J = 256    # kTileJ
-RJ = 2          # kRJ (genes per lane in the tie-free kernel)
-RJ_TIES = 1     # kRJTies (genes per lane in the tie-rich kernel)
+RJ = 4          # kRJ (genes per lane in the tie-free kernel)
+RJ_TIES = 2     # kRJTies (genes per lane in the tie-rich kernel)
 UNIT_H = 32     # kUnitH
+GENE_PAD = 1024 # kGenePad
+SLOT_PAD = 32   # sample slots per block of the bit planes
 
 
 def geometry(G: int, sample_slots: int, has_ties: bool):
     """(Gp, CJ, Q) exactly as launch_k1 derives them."""
-    cj_pad = TILE_J * max(RJ, RJ_TIES)
-    Gp = (G + cj_pad - 1) // cj_pad * cj_pad
+    Gp = (G + GENE_PAD - 1) // GENE_PAD * GENE_PAD
     CJ = TILE_J * (RJ_TIES if has_ties else RJ)
     chunk_bytes = CJ * sample_slots * 2
     Q = 4 if chunk_bytes * 4 <= (2 << 20) else (2 if chunk_bytes * 2 <= (2 << 20) else 1)
@@ -32,8 +34,8 @@ def geometry(G: int, sample_slots: int, has_ties: bool):
 
 
 def sample_slots(group_sizes) -> int:
-    """Every group is padded to a multiple of 8 sample slots (transform.hip)."""
-    return int(sum((int(n) + 7) // 8 * 8 for n in group_sizes))
+    """Every group is padded to whole blocks of 32 sample slots (transform.hip)."""
+    return int(sum((int(n) + SLOT_PAD - 1) // SLOT_PAD * SLOT_PAD for n in group_sizes))
 
 
 def tile_owner(G: int, slots: int, has_ties: bool, world: int) -> np.ndarray:
@@ -100,3 +102,24 @@ def derive_tallies(raw: np.ndarray, ref: np.ndarray) -> np.ndarray:
     c[:, 5] = tHt - LH - HH
     c[:, 4] = total - (cLt + cHt + c[:, 3] + c[:, 5])
     return c.astype(np.int32)
+
+
+def class_planes(code: np.ndarray, mask: np.ndarray | None = None) -> np.ndarray:
+    """The four bit planes cL cH tL tH of the class table ([G, 4, G], one int32 per bit, unpacked), restricted to the
+    pairs in `mask` (a shard's share; everything else stays zero, like the shard's zeroed table)."""
+    code = np.asarray(code)
+    sel = code < 9
+    if mask is not None:
+        sel = sel & mask
+    ic, it = code // 3, code % 3
+    return np.stack([(ic == 0) & sel, (ic == 2) & sel, (it == 0) & sel, (it == 2) & sel], axis=1).astype(np.int32)
+
+
+def codes_from_planes(planes: np.ndarray) -> np.ndarray:
+    """Inverse of class_planes on a complete table: class codes 0..8, 255 on the diagonal (k_decode)."""
+    cl, ch, tl, th = (planes[:, k, :] for k in range(4))
+    ic = np.where(cl > 0, 0, np.where(ch > 0, 2, 1))
+    it = np.where(tl > 0, 0, np.where(th > 0, 2, 1))
+    code = (3 * ic + it).astype(np.uint8)
+    np.fill_diagonal(code, 255)
+    return code

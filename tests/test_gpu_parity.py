@@ -311,8 +311,9 @@ def test_full_size_one_vs_rest_codes_on_sampled_blocks(pkg, oracle):
 
 def test_two_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle):
     """G-sharding: two contexts (shards 0/2 and 1/2) on one GPU, their all-reduce hooks joined by a
-    thread barrier.  Owned pairs carry the oracle's codes, the others are empty, and the summed
-    tallies / the whole iteration equal the unsharded result bit for bit."""
+    thread barrier.  Before the exchange owned pairs carry the oracle's codes and the others are empty; after
+    the one sum of the class table both shards hold the whole table, and tallies / the whole iteration equal
+    the unsharded result bit for bit."""
     import threading
     import torch
     G, S, seed = 1500, 24, 0x5EED0005
@@ -347,14 +348,19 @@ def test_two_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle):
                 ctx.set_groups(gid, 2)
                 ctx.compute_thresholds(0.01)
                 ctx.set_shard(rank, world)
-                ctx.set_allreduce(hook)
-                ctx.build_pairs(0)
+                ctx.build_pairs(0)          # no exchange configured yet: the shard's own part of the table
                 info = ctx.info()
                 got = ctx.get_codes(0, G, 0, G)
                 mask = pkg.sharding.owned_pair_mask(G, info["sample_slots"], True, rank, world)
                 off = ~np.eye(G, dtype=bool)
                 assert np.array_equal(got[mask], code[mask])
                 assert (got[off & ~mask] == 4).all()
+                with pytest.raises(pkg.ReoError):
+                    ctx.tally(ref0)         # REO_ECOMM: the table has not been exchanged
+                ctx.set_allreduce(hook)
+                ctx.build_pairs(0)          # one sum of the class table over the shards
+                got = ctx.get_codes(0, G, 0, G)
+                assert np.array_equal(got[off], code[off])
                 cont = ctx.tally(ref0)
                 res = ctx.identify_degs(ref0, 1.0, 0.05, 8, 1)
                 results[rank] = (info, cont, res)

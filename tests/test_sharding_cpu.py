@@ -1,5 +1,5 @@
-"""Multi-GPU protocol without a GPU: ownership rule, linearity of the raw
-counters, and the all-reduce hook over gloo with world_size = 2."""
+"""Multi-GPU protocol without a GPU: ownership rule, disjointness of the shards' class-table bits, and the
+all-reduce hook summing the table over gloo with world_size = 2."""
 import os
 import re
 import socket
@@ -26,9 +26,11 @@ def test_tiles_are_partitioned(pkg, G, slots, world):
     below = (jc * CJ + CJ - 1) // 64 < (it * sh.TILE_I) // 64
     assert ((owner == -1) == below).all()          # every tile on or above the diagonal has exactly one owner
     assert owner.max() == min(world, owner.max() + 1) - 1 or owner.max() < world
-    if G >= 5000:
-        counts = np.bincount(owner[owner >= 0], minlength=world)
-        assert counts.min() > 0 and counts.max() <= 1.6 * counts.mean()   # units are dealt round-robin
+    counts = np.bincount(owner[owner >= 0], minlength=world)
+    if G >= 5000 and world == 2:
+        assert counts.min() > 0
+    if G >= 20000:
+        assert counts.min() > 0 and counts.max() <= 1.3 * counts.mean()   # units are dealt round-robin
 
 
 def test_pair_masks_cover_every_pair_once(pkg):
@@ -65,24 +67,18 @@ def _worker(rank, world, port, G, S, seed, out):
         mask = sh.owned_pair_mask(G, slots, True, rank, world)
         hook = pkg.dist.allreduce_hook(None)
         assert pkg.dist.shard_of_process() == (rank, world)
-        # the loop of src/RankCompV3.jl:396-425 with sharded tallies: K2 partial -> all-reduce -> K3
-        ref = pkg.synth.ref_mask(G, 200, seed)
-        res = np.zeros((G, 15), order="F")
-        trace, i_iter = [], 0
-        while i_iter < 6:
-            raw = np.ascontiguousarray(sh.raw_counters(code, ref, mask))
-            hook(raw.ctypes.data, raw.size, 0)                    # sum over shards, in place
-            cont = sh.derive_tallies(raw, ref)
-            assert np.array_equal(cont, oracle.tally(code, ref))  # == unsharded tallies, bit for bit
-            inds = np.zeros(G, dtype=np.uint8)
-            nn = oracle.lib().oracle_iter_stats(cont.ctypes.data_as(oracle._i32p), G, 1.0, 0.05,
-                                                res.ctypes.data_as(oracle._f64p), inds.ctypes.data_as(oracle._u8p))
-            trace.append((int(G - nn), int(nn)))
-            if abs(int(ref.sum()) - nn) < 1:
-                break
-            i_iter += 1
-            ref = inds.astype(bool)
-        exp, iters, etrace = oracle.iterate(code, pkg.synth.ref_mask(G, 200, seed), 1.0, 0.05, 6, 1)
+        # what reo_build_pairs does with world > 1: own bits into a zeroed table, one sum over the shards
+        planes = np.ascontiguousarray(sh.class_planes(code, mask))
+        assert planes.sum() < sh.class_planes(code).sum()         # a proper part
+        hook(planes.ctypes.data, planes.size, 0)                  # in place
+        assert planes.max() == 1                                  # the shards' bits were disjoint
+        whole = sh.codes_from_planes(planes)
+        assert np.array_equal(whole, code)
+        # ... after which tallies and the loop of src/RankCompV3.jl:396-425 run unsharded on every rank
+        ref0 = pkg.synth.ref_mask(G, 200, seed)
+        assert np.array_equal(sh.derive_tallies(sh.raw_counters(whole, ref0), ref0), oracle.tally(code, ref0))
+        res, iters, trace = oracle.iterate(whole, ref0, 1.0, 0.05, 6, 1)
+        exp, eiters, etrace = oracle.iterate(code, ref0, 1.0, 0.05, 6, 1)
         assert trace == etrace and np.array_equal(res, exp)
         out.put((rank, "ok", len(trace)))
     except Exception as e:  # pragma: no cover
