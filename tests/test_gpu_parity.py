@@ -5,6 +5,7 @@ bit-exact; floating-point statistics within the tolerances written below
 (north star: p-values within 1e-6).
 """
 import os
+import zlib
 
 import numpy as np
 import pytest
