@@ -160,7 +160,8 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(64)) ||
         (rc = c->state.ensure(1)) ||
         (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * (kSortChunk + kSortChunk / 32))) ||
-        (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))))
+        (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))) ||
+        (rc = c->cand.ensure(2 * 1024)) || (rc = c->hist.ensure((G + 32767) / 32768 * 32768)) || (rc = c->mrank.ensure(G)) || (rc = c->scal.ensure(64)))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
@@ -181,7 +182,10 @@ static int32_t init_state(reo_ctx *c, int32_t nref)
     IterState st;
     memset(&st, 0, sizeof st);
     st.nref = nref;
+    st.nref_prev = nref;
     st.delta_cnt[0] = st.delta_cnt[1] = 0x7FFFFFFF;  // the first pass counts from scratch
+    st.need_full = 1;
+    st.raw_pass = -1;
     *c->host_state = st;
     REO_HIP_CHECK(hipMemcpyAsync(c->state.p, c->host_state, sizeof st, hipMemcpyHostToDevice, c->stream));
     return REO_OK;
@@ -277,7 +281,7 @@ void reo_destroy(reo_ctx *c)
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release(); c->modes.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
+    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -480,8 +484,7 @@ int32_t reo_tally(reo_ctx *c, const uint8_t *ref_mask, int32_t *cont)
     int32_t nref = 0;
     if ((rc = upload_ref(c, ref_mask, 0, &nref))) return rc;
     if ((rc = init_state(c, nref))) return rc;
-    if ((rc = launch_k2(c, c->refbits[0].p, 0, false))) return rc;
-    if ((rc = launch_derive(c, c->refbytes[0].p, 0))) return rc;
+    if ((rc = launch_tally(c, nref))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(cont, c->cont.p, sizeof(int32_t) * 9 * c->G, hipMemcpyDeviceToHost, c->stream));
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));
     collect_timings(c);
@@ -509,35 +512,64 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     if ((rc = upload_ref(c, ref0, 0, &nref))) return rc;
     if ((rc = init_state(c, nref))) return rc;
     if ((rc = c->trace.ensure(2 * static_cast<size_t>(n_iter > 0 ? n_iter : 1)))) return rc;
-    if ((rc = c->modes.ensure(static_cast<size_t>(n_iter > 0 ? n_iter : 1)))) return rc;
-    collect_timings(c);  // flush timers of earlier calls: the K2 timers below are matched to passes by order
+    if ((rc = c->modes.ensure(static_cast<size_t>(n_iter > 0 ? n_iter : 1) + 64))) return rc;
+    collect_timings(c);  // flush timers of earlier calls: the K2 timers below are matched to launches by order
     REO_HIP_CHECK(hipMemsetAsync(c->result.p, 0, sizeof(double) * 15 * G, c->stream));  // zeros(r,15), :398
-    // The loop control of :400,418-424 lives in device memory (IterState): passes are
-    // enqueued in batches and every kernel of a pass returns at once after convergence,
-    // so the host only looks at the state once per batch.  (Shards of a multi-GPU run hold the whole
-    // class table after reo_build_pairs and run these passes independently and identically.)
-    const int batch = 8;
-    int enq = 0, passes = 0;
-    while (enq < n_iter) {  // :400
-        const int nb = std::min(batch, n_iter - enq);
+    c->it_pval_deg = pval_deg; c->it_padj_deg = padj_deg; c->it_n_iter = n_iter; c->it_n_conv = n_conv;
+    c->it_a0 = static_cast<int>(a - 1); c->it_b0 = static_cast<int>(b - 1);
+    c->k2_idx = 0;
+    REO_HIP_CHECK(hipMemsetAsync(c->modes.p, 0, c->modes.n * sizeof(int32_t), c->stream));
+    REO_HIP_CHECK(hipMemsetAsync(c->hist.p, 0, c->hist.n * sizeof(int32_t), c->stream));
+    // The loop control of :400,418-424 lives in device memory (IterState): passes are enqueued in batches, every
+    // kernel looks at the state and returns at once when its pass is not wanted (convergence, n_iter reached, the
+    // other kind of pass is due), and the host reads the state once per batch.  Two kinds of pass (kernels.hip):
+    // the sorting path -- needed for the first pass, whenever the reference set changed by more genes than a tally
+    // update takes, and when a quantile window lost its order statistic -- and the light path.  A batch = two
+    // sorting passes (mostly idle launches) + as many light passes as may follow; small problems sort every pass.
+    const bool small = G < light_min_genes();
+    int passes = 0, seen_need_full = 1;
+    while (n_iter > 0) {  // :400
+        const int remaining = n_iter - passes;
+        const int nfull = small ? std::min(8, remaining) : std::min(2, remaining);
+        const int nlight = (small || seen_need_full) ? 0 : std::min(32, remaining);
         tic(c, 3);
-        for (int t = enq; t < enq + nb; ++t) {
-            const int cur = t & 1;  // pass t reads mask buffer t&1 and writes the other (ref_gene_vec = inds, :424)
-            if ((rc = launch_k2(c, c->refbits[cur].p, cur, true))) return rc;
-            if ((rc = launch_stats(c, cur, pval_deg, padj_deg, n_conv, a, b))) return rc;
-        }
+        for (int t = 0; t < nfull; ++t)
+            if ((rc = launch_full_pass(c, false))) return rc;
+        for (int t = 0; t < nlight; ++t)
+            if ((rc = launch_light_pass(c))) return rc;
         toc(c);
         REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));
-        enq += nb;
+        if (getenv("REO_DEBUG_PASSES"))
+            fprintf(stderr, "batch: %d sorting + %d light launches, passes %d -> %d, need_full %d, done %d, last_full %d\n", nfull, nlight,
+                    passes, c->host_state->passes, c->host_state->need_full, c->host_state->done, c->host_state->last_full);
         passes = c->host_state->passes;
-        if (c->host_state->done) break;  // :419-422
+        seen_need_full = c->host_state->need_full;
+        if (c->host_state->done || passes >= n_iter) break;  // :419-422
+    }
+    if (passes > 0 && !c->host_state->last_full) {
+        // the loop ended on a light pass: delta2, se, z1, the tallies and padj of that pass come from the sorting path
+        tic(c, 3);
+        if ((rc = launch_full_pass(c, true))) return rc;
+        toc(c);
     }
     if (trace && passes > 0)
         REO_HIP_CHECK(hipMemcpyAsync(trace, c->trace.p, sizeof(int32_t) * 2 * passes, hipMemcpyDeviceToHost, c->stream));
-    if (c->profiling && passes > 0) {
-        c->k2_modes.assign(passes, 0);
-        REO_HIP_CHECK(hipMemcpyAsync(c->k2_modes.data(), c->modes.p, sizeof(int32_t) * passes, hipMemcpyDeviceToHost, c->stream));
+    const int nk2 = std::min<int>(c->k2_idx, static_cast<int>(c->modes.n));
+    if (c->profiling && nk2 > 0) {
+        c->k2_modes.assign(c->k2_idx, 0);
+        REO_HIP_CHECK(hipMemcpyAsync(c->k2_modes.data(), c->modes.p, sizeof(int32_t) * nk2, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (getenv("REO_DEBUG_STAMPS")) {  // diagnostic builds (-DREO_STAMPS): marks of the last light pass, 10 ns units
+        unsigned long long st[24];
+        REO_HIP_CHECK(hipMemcpy(st, c->scal.p + 32, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "stamps kl_pvalues:");
+        for (int k = 1; k <= 6; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[0]));
+        fprintf(stderr, "  kl_mask:");
+        for (int k = 9; k <= 11; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[8]));
+        fprintf(stderr, "  kl_derive:");
+        for (int k = 14; k <= 17; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[13]));
+        fprintf(stderr, "  (x 10 ns)\n");
     }
     if (iters_run) *iters_run = passes;
     REO_HIP_CHECK(hipMemcpyAsync(result, c->result.p, sizeof(double) * 15 * G, hipMemcpyDeviceToHost, c->stream));

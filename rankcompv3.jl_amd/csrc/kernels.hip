@@ -7,7 +7,8 @@
 //                   classification per comparison
 //   K2  k2_tally    class table x reference mask -> per-gene tallies   (:403)
 //       (delta form: the same launch updates the counters from the rows of the genes whose mask bit changed)
-//   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask, loop control (:404-425,225-259)
+//   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask, loop control (:404-425,225-259): the
+//                   sorting path; kl_* the light passes (no sort: quantile windows + BH cut by histogram)
 //
 // All file:line citations are relative to /root/reference.
 //
@@ -581,22 +582,30 @@ __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, cons
 // by the mirror rule (:386) column j of the table is row j with L and H swapped, so gene j entering
 // (leaving) the reference set adds (removes), for every gene i, the class bits found at bit i of ROW j:
 // one contiguous row per changed gene instead of the whole table.  Exact (integer sums).
-__device__ __forceinline__ void delta_genes(const uint32_t *__restrict__ table, int G, int Wp, const uint32_t *__restrict__ list,
-                                            int n, int32_t *__restrict__ raw)
+__device__ __forceinline__ void delta_gene(const uint32_t *__restrict__ table, int Wp, const uint32_t *__restrict__ list,
+                                           int n, int32_t *__restrict__ raw, int i)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= G) return;
     const int w = i >> 5, sh = i & 31;
     int d[kRaw] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int e = 0; e < n; ++e) {
-        const uint32_t ent = list[e];  // wave-uniform
-        const uint32_t *row = table + static_cast<size_t>(ent >> 1) * kPlanes * Wp + w;
-        const int sgn = (ent & 1u) ? 1 : -1;
-        // pair (i, j) seen from gene i: cL(i,j) = cH(j,i), cH(i,j) = cL(j,i), likewise for the treat side
-        const int cl = (row[Wp] >> sh) & 1, ch = (row[0] >> sh) & 1;
-        const int tl = (row[3 * Wp] >> sh) & 1, th = (row[2 * Wp] >> sh) & 1;
-        d[0] += sgn * cl; d[1] += sgn * ch; d[2] += sgn * tl; d[3] += sgn * th;
-        d[4] += sgn * (cl & tl); d[5] += sgn * (cl & th); d[6] += sgn * (ch & tl); d[7] += sgn * (ch & th);
+    for (int e0 = 0; e0 < n; e0 += 4) {  // four list entries per step: sixteen independent loads in flight
+        uint32_t ent[4], w0[4], w1[4], w2[4], w3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ent[u] = list[min(e0 + u, n - 1)];  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t *row = table + static_cast<size_t>(ent[u] >> 1) * kPlanes * Wp + w;
+            w0[u] = row[0]; w1[u] = row[Wp]; w2[u] = row[2 * Wp]; w3[u] = row[3 * Wp];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e0 + u >= n) continue;
+            const int sgn = (ent[u] & 1u) ? 1 : -1;
+            // pair (i, j) seen from gene i: cL(i,j) = cH(j,i), cH(i,j) = cL(j,i), likewise for the treat side
+            const int cl = (w1[u] >> sh) & 1, ch = (w0[u] >> sh) & 1;
+            const int tl = (w3[u] >> sh) & 1, th = (w2[u] >> sh) & 1;
+            d[0] += sgn * cl; d[1] += sgn * ch; d[2] += sgn * tl; d[3] += sgn * th;
+            d[4] += sgn * (cl & tl); d[5] += sgn * (cl & th); d[6] += sgn * (ch & tl); d[7] += sgn * (ch & th);
+        }
     }
     int4 *o = reinterpret_cast<int4 *>(raw + static_cast<size_t>(i) * kRaw);
     int4 a = o[0], b = o[1];
@@ -605,25 +614,99 @@ __device__ __forceinline__ void delta_genes(const uint32_t *__restrict__ table, 
     o[0] = a; o[1] = b;
 }
 
-// The K2 stage of one pass: one launch, the device picks the form.  slot < 0: always a full scan.
-__global__ __launch_bounds__(256) void k2_tally(const IterState *__restrict__ st, const uint32_t *__restrict__ table,
-                                                const uint4 *__restrict__ refbits, int G, int Wp,
-                                                int32_t *__restrict__ raw, int slot,
-                                                const uint32_t *__restrict__ list, int32_t *__restrict__ modes)
+__device__ __forceinline__ void delta_genes(const uint32_t *__restrict__ table, int G, int Wp, const uint32_t *__restrict__ list,
+                                            int n, int32_t *__restrict__ raw)
 {
-    if (st->done) return;
-    const int n = slot >= 0 ? st->delta_cnt[slot] : kDeltaMax + 1;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < G) delta_gene(table, Wp, list, n, raw, i);
+}
+
+// ---------------------------------------------------------------------------
+// Arguments shared by every kernel of the iteration passes (:396-425).  The pass index, and with it the parity of
+// the double-buffered reference mask and change list, lives in device memory (IterState), so the host can enqueue
+// passes without knowing which of them will run.
+struct IterArgs {
+    IterState *st;
+    const uint32_t *table;
+    int G, Gp, Wp;
+    int n_iter, n_conv;
+    int a0, b0;                  // 0-based bounds of the slice of :411
+    double pval_deg, padj_deg;
+    uint32_t *refbits[2];        // [Wp] mask of the pass of that parity, as bits ...
+    uint8_t *refbytes[2];        // [Gp] ... and as bytes
+    int32_t *raw;                // [G][8]
+    uint32_t *delta_list;        // [2][Gp] genes whose mask bit changes for the pass of that parity
+    double *result;              // [15][G]
+    double *chunk_v; uint16_t *chunk_i; double *chunk_spl;
+    double *sorted_d; double *sorted_spl; double *sorted_p;
+    uint32_t *rank_s; uint32_t *rank_a;
+    double *part; double *blockmin; double *scal;
+    int32_t *trace; int32_t *modes;
+    double *cand;                // [2][kCandMax] light passes: values inside the two quantile windows
+    int32_t *hist;               // [G + 2]     light passes: histogram of the BH ranks m_i
+    int32_t *mrank;              // [G]         light passes: m_i
+    int replay;                  // 1: recompute the outputs of the last executed pass from its tallies, change no state
+    int k2_idx;                  // index of this k2_tally launch (for the stage timers)
+    unsigned long long *stamps;  // diagnostic builds (-DREO_STAMPS): s_memrealtime marks of workgroup 0, else unused
+};
+
+#ifdef REO_STAMPS
+#define STAMP(a, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) (a).stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(a, k) do { } while (0)
+#endif
+
+// scal[]: 0 se of the last pass; 1..4 quantile windows wa_lo wa_hi wb_lo wb_hi for the next light pass;
+// 5..8 their half widths (value units) around the exact quantiles
+constexpr int kCandMax = 64;     // candidates per quantile window (one per lane of the wave that sorts them)
+constexpr int kWindow = 24;      // ranks on either side of the quantile that the window is made to hold
+constexpr int kLightMinG = 4096; // below this the sorting passes are cheap and the windows would overlap
+
+// the pass the kernels of the sorting path work on: the next one, or (replay) the last executed one
+__device__ __forceinline__ bool full_pass_active(const IterArgs &a, int &t, int &nref)
+{
+    const IterState *st = a.st;
+    if (a.replay) { t = st->passes - 1; nref = st->nref_prev; return t >= 0; }
+    t = st->passes; nref = st->nref;
+    return !st->done && st->passes < a.n_iter && st->need_full;
+}
+
+__device__ __forceinline__ bool light_pass_active(const IterArgs &a, int &t)
+{
+    const IterState *st = a.st;
+    t = st->passes;
+    return !st->done && st->passes < a.n_iter && !st->need_full;
+}
+
+// The K2 stage of a sorting pass: one launch, the device picks the form (whole-table scan, or update from the rows
+// of the genes whose mask bit changed).  Skipped when a light pass has already brought the counters up to date.
+__global__ __launch_bounds__(256) void k2_tally(IterArgs a)
+{
+    int t, nref;
+    if (!full_pass_active(a, t, nref) || a.st->raw_pass == t) return;
+    const int cur = t & 1;
+    const int n = a.st->delta_cnt[cur];
     const bool full = n > kDeltaMax;
-    if (modes && blockIdx.x == 0 && threadIdx.x == 0) modes[st->passes] = full ? 1 : 0;  // for the stage timers
-    if (full) tally_rows(reinterpret_cast<const uint4 *>(table), refbits, G, Wp / 4, raw);
-    else if (static_cast<int>(blockIdx.x) * 256 < G) delta_genes(table, G, Wp, list, n, raw);
+    if (a.modes && blockIdx.x == 0 && threadIdx.x == 0) a.modes[a.k2_idx] = full ? 1 : 0;  // for the stage timers
+    if (full) tally_rows(reinterpret_cast<const uint4 *>(a.table), reinterpret_cast<const uint4 *>(a.refbits[cur]), a.G, a.Wp / 4, a.raw);
+    else if (static_cast<int>(blockIdx.x) * 256 < a.G) delta_genes(a.table, a.G, a.Wp, a.delta_list + static_cast<size_t>(cur) * a.Gp, n, a.raw);
+}
+
+// stand-alone form for reo_tally: always a whole-table scan with the mask of parity 0
+__global__ __launch_bounds__(256) void k2_scan(const uint32_t *__restrict__ table, const uint4 *__restrict__ refbits, int G, int Wp,
+                                               int32_t *__restrict__ raw)
+{
+    tally_rows(reinterpret_cast<const uint4 *>(table), refbits, G, Wp / 4, raw);
 }
 
 // ---------------------------------------------------------------------------
 // K3.  McCullagh's test for a 3x3 table, closed form of :225-259.
 //   N = [[a b][b d]], n = (a, d), R = (R1, R2); singular iff a*d == b*b (exact
 //   integer test, equivalent to abs(det(N)) <= eps() for integer N, :242).
-__device__ void mccullagh3(const int32_t *n, double *out)
+// FULL = false: delta1 only (the passes in between need nothing else: delta2, se, z1 and the test's own p-value
+// never reach the next pass -- :412 overwrites the p-value -- and are recomputed for the pass that ends the loop).
+template <bool FULL>
+__device__ __forceinline__ void mccullagh3(const int32_t *n, double *out)
 {
     const long long n12 = n[1], n13 = n[2], n21 = n[3], n23 = n[5], n31 = n[6], n32 = n[7];
     const long long a = n12 + n13 + n21 + n31;  // N11  (:232)
@@ -639,6 +722,8 @@ __device__ void mccullagh3(const int32_t *n, double *out)
     const double r1 = static_cast<double>(R1), r2 = static_cast<double>(R2);
     const double d1 = (fa * w1 * nu) * log((r1 + 0.5) / (fa - r1 + 0.5)) +
                       (fd * w2 * nu) * log((r2 + 0.5) / (fd - r2 + 0.5));  // :248-249
+    out[1] = d1;
+    if (!FULL) return;
     const double A = w1 * r1 + w2 * r2, B = w1 * (fa - r1) + w2 * (fd - r2);
     const double d2 = log((0.5 + A) / (0.5 + B));               // :250
     const double v1 = 4.0 * (1.0 + 0.25 * d1 * d1) * nu;        // :251
@@ -647,7 +732,7 @@ __device__ void mccullagh3(const int32_t *n, double *out)
     const double z1 = d1 / se;                                  // :254
     double p = erfc(fabs(z1) * 0.70710678118654752440);         // 2*min(cdf, ccdf), :255
     out[0] = p > 1.0 ? 1.0 : p;
-    out[1] = d1; out[2] = d2; out[3] = se; out[4] = z1;
+    out[2] = d2; out[3] = se; out[4] = z1;
 }
 
 __global__ void k_mccullagh(const int32_t *__restrict__ cont, int64_t n, double *__restrict__ out)
@@ -657,56 +742,60 @@ __global__ void k_mccullagh(const int32_t *__restrict__ cont, int64_t n, double 
     int32_t c[9];
     for (int t = 0; t < 9; ++t) c[t] = cont[i * 9 + t];
     double o[5];
-    mccullagh3(c, o);
+    mccullagh3<true>(c, o);
     for (int t = 0; t < 5; ++t) out[i * 5 + t] = o[t];
 }
 
-// raw counters -> 9 tallies (:403) [-> McCullagh -> result columns 3..15 (:404-405)]
-// nref comes from the
-// device-side iteration state so that passes can be enqueued back to back.
-// one gene: raw counters -> 9 tallies (:403) [-> McCullagh -> result columns 3..15 (:404-405)]; returns delta1
-__device__ __forceinline__ double derive_gene(const int32_t *__restrict__ raw, const uint8_t *__restrict__ refbytes,
-                                              int nref, int G, int i, int32_t *__restrict__ cont,
-                                              double *__restrict__ result, bool with_stats)
+// one gene: raw counters -> 9 tallies (:403)
+__device__ __forceinline__ void tallies_of(const int32_t *__restrict__ raw, bool in_ref, int nref, int i, int32_t (&c)[9])
 {
     const int4 r0 = reinterpret_cast<const int4 *>(raw)[2 * i], r1 = reinterpret_cast<const int4 *>(raw)[2 * i + 1];
     const int cLt = r0.x, cHt = r0.y, tLt = r0.z, tHt = r0.w, LL = r1.x, LH = r1.y, HL = r1.z, HH = r1.w;
-    const int total = nref - (refbytes[i] ? 1 : 0);  // the diagonal is never set (:363,385)
-    int32_t c[9];
+    const int total = nref - (in_ref ? 1 : 0);  // the diagonal is never set (:363,385)
     c[0] = LL; c[2] = LH; c[6] = HL; c[8] = HH;
     c[1] = cLt - LL - LH;
     c[7] = cHt - HL - HH;
     c[3] = tLt - LL - HL;
     c[5] = tHt - LH - HH;
     c[4] = total - (cLt + cHt + c[3] + c[5]);
-    if (cont) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) cont[static_cast<size_t>(i) * 9 + t] = c[t];
-    }
-    if (!with_stats) return 0.0;
-    double o[5];
-    mccullagh3(c, o);
-    const size_t Gs = G;
-    result[i] = o[0];
-    result[Gs + i] = 1.0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) result[(2 + t) * Gs + i] = static_cast<double>(c[t]);
-    result[11 * Gs + i] = o[1]; result[12 * Gs + i] = o[2];
-    result[13 * Gs + i] = o[3]; result[14 * Gs + i] = o[4];
-    return o[1];
 }
 
 // stand-alone form for reo_tally (tallies only)
-__global__ __launch_bounds__(256) void k3_derive(const IterState *__restrict__ st, const int32_t *__restrict__ raw,
-                                                 const uint8_t *__restrict__ refbytes, int G,
-                                                 int32_t *__restrict__ cont, double *__restrict__ result,
-                                                 int with_stats, IterState *__restrict__ stw, int slot_next)
+__global__ __launch_bounds__(256) void k3_tallies(const int32_t *__restrict__ raw, const uint8_t *__restrict__ refbytes, int nref, int G,
+                                                  int32_t *__restrict__ cont)
 {
-    if (st->done) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && stw) stw->delta_cnt[slot_next] = 0;  // k3_finalize of this pass fills that list
     if (i >= G) return;
-    derive_gene(raw, refbytes, st->nref, G, i, cont, result, with_stats != 0);
+    int32_t c[9];
+    tallies_of(raw, refbytes[i] != 0, nref, i, c);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) cont[static_cast<size_t>(i) * 9 + t] = c[t];
+}
+
+// sorting pass: tallies -> McCullagh -> result columns 3..15 (:404-405)
+__global__ __launch_bounds__(256) void k3_derive(IterArgs a)
+{
+    int t, nref;
+    if (!full_pass_active(a, t, nref)) return;
+    const int cur = t & 1;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && !a.replay) {
+        a.st->delta_cnt[1 - cur] = 0;  // k3_finalize of this pass fills that list
+        a.st->raw_pass = t;
+    }
+    if (i >= a.G) return;
+    int32_t c[9];
+    tallies_of(a.raw, a.refbytes[cur][i] != 0, nref, i, c);
+    double o[5];
+    mccullagh3<true>(c, o);
+    const size_t Gs = a.G;
+    double *result = a.result;
+    result[i] = o[0];
+    result[Gs + i] = 1.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) result[(2 + q) * Gs + i] = static_cast<double>(c[q]);
+    result[11 * Gs + i] = o[1]; result[12 * Gs + i] = o[2];
+    result[13 * Gs + i] = o[3]; result[14 * Gs + i] = o[4];
 }
 
 // Sum over the 256 threads of a workgroup, the same bits in every thread and every workgroup: an
@@ -724,7 +813,7 @@ __device__ __forceinline__ double block_sum_256(double v, double *red)
 }
 
 // ---- ranking: the sort of :409 and the order BH needs (:413) ---------------
-// (1) k3_sort_chunks: bitonic sort of 2048-gene chunks in LDS by (delta1, gene);
+// (1) k3_sort_chunks: bitonic sort of 1024-gene chunks by delta1;
 // (2) k3_merge_rank: rank of a gene = its position in its own chunk + the
 //     number of smaller elements of every other chunk (binary searches; chunks
 //     hold contiguous gene ranges, so "smaller gene index" is "earlier chunk");
@@ -743,73 +832,35 @@ __device__ __forceinline__ void cmpx(double &v, uint32_t &i, double pv, uint32_t
     if (take) { v = pv; i = pi; }
 }
 
-// Bitonic sort of one kSortChunk-gene chunk, four consecutive elements per thread in registers
-// (kSortChunk / 4 threads).  Exchange distances 1 and 2 stay inside the thread, distances 4..128 go
-// through wave shuffles, and only the stages with distance >= 256 (partner in another wave) use
-// LDS + a barrier.
-constexpr int kSortE = 1;  // elements per thread (K3 per 128 passes at 20 000 genes: 4 -> 6.58 ms, 2 -> 6.56, 1 -> 6.49)
-constexpr int kSortThreads = kSortChunk / kSortE;
-
-__global__ __launch_bounds__(kSortThreads) void k3_sort_chunks(const IterState *__restrict__ st,
-                                                               const double *__restrict__ d1, int G,
-                                                               double *__restrict__ cv, uint16_t *__restrict__ ci,
-                                                               double *__restrict__ splitters)
+// Bitonic sort of one kSortChunk-gene chunk, one element per thread: exchange distances 1..32 go through wave
+// shuffles, and only the stages with distance >= 64 (partner in another wave) use LDS + a barrier.
+__global__ __launch_bounds__(kSortChunk) void k3_sort_chunks(IterArgs a)
 {
-    if (st->done) return;
-    constexpr int E = kSortE;
+    int tp, nref;
+    if (!full_pass_active(a, tp, nref)) return;
     __shared__ double sv[kSortChunk];
     __shared__ uint16_t si[kSortChunk];
+    const double *d1 = a.result + 11 * static_cast<size_t>(a.G);
     const int t = threadIdx.x, base = blockIdx.x * kSortChunk;
-    const int x0 = E * t;  // element index of this thread's first slot
-    double v[E];
-    uint32_t id[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        v[e] = base + x0 + e < G ? d1[base + x0 + e] : INFINITY;  // padding sorts to the end of the last chunk
-        id[e] = x0 + e;
-    }
+    double v = base + t < a.G ? d1[base + t] : INFINITY;  // padding sorts to the end of the last chunk
+    uint32_t id = t;
     for (int k = 2; k <= kSortChunk; k <<= 1) {
-        const bool up = (x0 & k) == 0;  // for k >= E all slots of a thread share the direction
-        for (int j = k >> 1; j >= 64 * E; j >>= 1) {
-            const int m = j / E;  // partner thread distance (>= 64: another wave)
+        const bool up = (t & k) == 0;
+        for (int j = k >> 1; j >= 64; j >>= 1) {  // partner in another wave
             __syncthreads();
-#pragma unroll
-            for (int e = 0; e < E; ++e) { sv[x0 + e] = v[e]; si[x0 + e] = static_cast<uint16_t>(id[e]); }
+            sv[t] = v; si[t] = static_cast<uint16_t>(id);
             __syncthreads();
-            const int px = E * (t ^ m);
-            const bool keep_min = ((t & m) == 0) == up;
-#pragma unroll
-            for (int e = 0; e < E; ++e) cmpx(v[e], id[e], sv[px + e], si[px + e], keep_min);
+            cmpx(v, id, sv[t ^ j], si[t ^ j], ((t & j) == 0) == up);
         }
-        for (int j = (k >> 1) < 32 * E ? (k >> 1) : 32 * E; j >= E; j >>= 1) {
-            const int m = j / E;  // 1..32: inside the wave
-            const bool keep_min = ((t & m) == 0) == up;
-            double pv[E];
-            uint32_t pi[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) { pv[e] = __shfl_xor(v[e], m, 64); pi[e] = __shfl_xor(id[e], m, 64); }
-#pragma unroll
-            for (int e = 0; e < E; ++e) cmpx(v[e], id[e], pv[e], pi[e], keep_min);
-        }
-#pragma unroll
-        for (int j = E >> 1; j >= 1; j >>= 1) {  // partners inside the thread
-            if (j >= k) continue;
-#pragma unroll
-            for (int a = 0; a < E; ++a) {
-                if (a & j) continue;
-                const int b = a + j;
-                const bool up_ = ((x0 + a) & k) == 0;
-                if ((v[a] > v[b]) == up_) {
-                    const double tv = v[a]; v[a] = v[b]; v[b] = tv;
-                    const uint32_t ti = id[a]; id[a] = id[b]; id[b] = ti;
-                }
-            }
+        for (int j = (k >> 1) < 32 ? (k >> 1) : 32; j >= 1; j >>= 1) {  // inside the wave
+            const double pv = __shfl_xor(v, j, 64);
+            const uint32_t pi = __shfl_xor(id, j, 64);
+            cmpx(v, id, pv, pi, ((t & j) == 0) == up);
         }
     }
-#pragma unroll
-    for (int e = 0; e < E; ++e) { cv[base + x0 + e] = v[e]; ci[base + x0 + e] = static_cast<uint16_t>(id[e]); }
+    a.chunk_v[base + t] = v; a.chunk_i[base + t] = static_cast<uint16_t>(id);
     // every 32nd element once more, packed: k3_merge_rank stages these into LDS with contiguous loads
-    if ((x0 & 31) == 0) splitters[blockIdx.x * (kSortChunk / 32) + (x0 >> 5)] = v[0];
+    if ((t & 31) == 0) a.chunk_spl[blockIdx.x * (kSortChunk / 32) + (t >> 5)] = v;
 }
 
 // A search in a sorted array a[0..n) for the count of elements that sort before v (`<` when strict, `<=`
@@ -817,6 +868,8 @@ __global__ __launch_bounds__(kSortThreads) void k3_sort_chunks(const IterState *
 // half-open index range [l, h) of fewer than 2^LOG elements, then LOG halving steps in global memory finish.
 // The two levels are separate calls so that a thread with several searches can run their global steps in
 // lockstep: the loads of one step are independent, so k searches cost one round trip per step, not k.
+// EVERY load of a lockstep step is issued unconditionally; a search that is switched off or already finished
+// must therefore be given an in-bounds dummy (see the callers: this is where round 1's memory fault came from).
 struct Range { int l, h; };
 
 template <int LOG>
@@ -843,22 +896,21 @@ constexpr int kMergeLanes = 16;
 constexpr int kMergeThreads = 256;   // 16 elements per workgroup share one copy of the splitters
 constexpr int kSplit = kSortChunk / 32;  // splitters per chunk
 
-__global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *__restrict__ st, const double *__restrict__ cv,
-                                                     const uint16_t *__restrict__ ci, int G, int nchunk,
-                                                     int a0, int b0, uint32_t *__restrict__ rs,
-                                                     double *__restrict__ sorted_d, double *__restrict__ part,
-                                                     const double *__restrict__ splitters, double *__restrict__ sorted_spl)
+__global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(IterArgs a, int nchunk)
 {
-    if (st->done) return;
+    int tp, nref;
+    if (!full_pass_active(a, tp, nref)) return;
+    const int G = a.G;
+    const double *cv = a.chunk_v;
     __shared__ double slice[kMergeThreads / kMergeLanes];
     __shared__ double spl[(65536 / kSortChunk) * kSplit];  // [chunk][kSplit]: 2048 splitters at most (G <= 65535)
-    for (int t = threadIdx.x; t < nchunk * kSplit; t += kMergeThreads) spl[t] = splitters[t];  // = cv[chunk][32 m], packed
+    for (int t = threadIdx.x; t < nchunk * kSplit; t += kMergeThreads) spl[t] = a.chunk_spl[t];  // = cv[chunk][32 m], packed
     __syncthreads();
     const int e = blockIdx.x * (kMergeThreads / kMergeLanes) + threadIdx.x / kMergeLanes;  // element (position in the chunked array)
     const int sub = threadIdx.x % kMergeLanes;
     const int c = e / kSortChunk, p = e % kSortChunk;
     const bool live = e < nchunk * kSortChunk;
-    const int gene = live ? c * kSortChunk + ci[e] : G;
+    const int gene = live ? c * kSortChunk + a.chunk_i[e] : G;
     const double v = live ? cv[e] : 0.0;
     int count = 0;
     if (gene < G) {
@@ -870,6 +922,7 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *
             const bool s1 = cc > c, s2 = c2 > c;  // equal values of earlier chunks sort first
             Range r1 = on1 ? coarse_range<5>(spl + cc * kSplit, (n1 + 31) >> 5, n1, v, s1) : Range{0, 0};
             Range r2 = on2 ? coarse_range<5>(spl + c2 * kSplit, (n2 + 31) >> 5, n2, v, s2) : Range{0, 0};
+            // c2 may lie past the last chunk: the switched-off search reads chunk cc instead (in bounds)
             const double *ch1 = cv + cc * kSortChunk, *ch2 = cv + (on2 ? c2 : cc) * kSortChunk;
 #pragma unroll
             for (int step = 0; step < 5; ++step) {
@@ -884,10 +937,10 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *
     bool in = false;
     if (sub == 0 && gene < G) {
         const int rank = p + count;
-        rs[gene] = rank;
-        sorted_d[rank] = v;
-        if ((rank & 63) == 0) sorted_spl[rank >> 6] = v;  // packed splitters for k3_abs_rank
-        in = rank >= a0 && rank <= b0;  // inside the 5 %-95 % slice of :411
+        a.rank_s[gene] = rank;
+        a.sorted_d[rank] = v;
+        if ((rank & 63) == 0) a.sorted_spl[rank >> 6] = v;  // packed splitters for k3_abs_rank
+        in = rank >= a.a0 && rank <= a.b0;  // inside the 5 %-95 % slice of :411
     }
     // moments (count, mean, M2) of this block's elements that fall into the slice; combined in k3_abs_rank
     if (sub == 0) slice[threadIdx.x / kMergeLanes] = in ? v : NAN;
@@ -904,43 +957,55 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(const IterState *
         double m2 = has ? (x - mean) * (x - mean) : 0.0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
-        if (threadIdx.x == 0) { part[3 * blockIdx.x] = n; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = m2; }
+        if (threadIdx.x == 0) { a.part[3 * blockIdx.x] = n; a.part[3 * blockIdx.x + 1] = mean; a.part[3 * blockIdx.x + 2] = m2; }
     }
 }
 
-// |delta1| ranks (= rank of pval ascending), then se = std of the 5 %-95 % slice of the sorted delta1
-// (n-1 estimator, :409-411) from the per-block moments of k3_merge_rank (every workgroup combines them
-// the same way: n = sum n_b, mean = sum n_b mean_b / n, M2 = sum [M2_b + n_b (mean_b - mean)^2], fixed-
-// order tree sums), then pval = pvalue(Normal(0,se), delta1, tail=:both) (:412) -> column 1, and into
-// rank order for the BH step.
-__global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__ st, const double *__restrict__ d1,
-                                                   const uint32_t *__restrict__ rs,
-                                                   const double *__restrict__ sorted_d,
-                                                   const double *__restrict__ sorted_spl, int G,
-                                                   const double *__restrict__ part, int npart,
-                                                   uint32_t *__restrict__ ra, double *__restrict__ pval,
-                                                   double *__restrict__ sorted_p, double *__restrict__ scal)
+// Chan's combination of per-block moments (n_b, mean_b, M2_b), the same bits in every thread of every workgroup:
+// n = sum n_b, mean = sum n_b mean_b / n, M2 = sum [M2_b + n_b (mean_b - mean)^2], fixed-order tree sums.
+__device__ __forceinline__ void combine_moments(const double *__restrict__ part, int npart, double *red, double &n, double &mean, double &m2)
 {
-    if (st->done) return;
-    __shared__ double red[256];
-    __shared__ double spl[1024];  // every 64th element of the sorted vector (G <= 65535)
-    const int nspl = (G + 63) >> 6;
-    for (int t = threadIdx.x; t < nspl; t += 256) spl[t] = sorted_spl[t];  // = sorted_d[64 t], packed
     double nb = 0.0, sb = 0.0;
     for (int t = threadIdx.x; t < npart; t += 256) { const double n_ = part[3 * t]; nb += n_; sb += n_ * part[3 * t + 1]; }
-    const double n = block_sum_256(nb, red);  // (also the barrier that publishes spl)
-    const double mean = block_sum_256(sb, red) / n;
+    n = block_sum_256(nb, red);
+    mean = block_sum_256(sb, red) / n;
     double qb = 0.0;
     for (int t = threadIdx.x; t < npart; t += 256) {
         const double n_ = part[3 * t], d_ = part[3 * t + 1] - mean;
         qb += part[3 * t + 2] + n_ * d_ * d_;
     }
-    const double se = sqrt(block_sum_256(qb, red) / (n - 1.0));
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = se;
+    m2 = block_sum_256(qb, red);
+}
+
+// pvalue(Normal(0, se), delta1, tail = :both), :412
+__device__ __forceinline__ double normal_p(double v, double se)
+{
+    if (se == 0.0) return 0.0;  // Normal(0,0): cdf/ccdf degenerate to a step, the smaller tail is 0
+    const double p = erfc(fabs(v) / se * 0.70710678118654752440);
+    return p > 1.0 ? 1.0 : p;
+}
+
+// |delta1| ranks (= rank of pval ascending), then se = std of the 5 %-95 % slice of the sorted delta1
+// (n-1 estimator, :409-411) from the per-block moments of k3_merge_rank (every workgroup combines them
+// the same way), then pval (:412) -> column 1, and into rank order for the BH step.
+__global__ __launch_bounds__(256) void k3_abs_rank(IterArgs a, int npart)
+{
+    int tp, nref;
+    if (!full_pass_active(a, tp, nref)) return;
+    const int G = a.G;
+    const double *sorted_d = a.sorted_d;
+    __shared__ double red[256];
+    __shared__ double spl[1024];  // every 64th element of the sorted vector (G <= 65535)
+    const int nspl = (G + 63) >> 6;
+    for (int t = threadIdx.x; t < nspl; t += 256) spl[t] = a.sorted_spl[t];  // = sorted_d[64 t], packed
+    double n, mean, m2;
+    combine_moments(a.part, npart, red, n, mean, m2);  // (its first barrier also publishes spl)
+    const double se = sqrt(m2 / (n - 1.0));
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[0] = se;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= G) return;
-    const double v = d1[i];
-    const int r = rs[i];
+    const double v = a.result[11 * static_cast<size_t>(G) + i];
+    const int r = a.rank_s[i];
     // three counts in the sorted vector: < v, <= -v, <= v; their six global steps run in lockstep
     Range r1 = coarse_range<6>(spl, nspl, G, v, true), r2 = coarse_range<6>(spl, nspl, G, -v, false),
           r3 = coarse_range<6>(spl, nspl, G, v, false);
@@ -957,29 +1022,23 @@ __global__ __launch_bounds__(256) void k3_abs_rank(const IterState *__restrict__
     } else {        // larger |w|: w < v or w > -v
         rank = lbv + (G - ubn) + (r - lbv);
     }
-    ra[i] = rank;
-    double p;
-    if (se == 0.0) {
-        p = 0.0;  // Normal(0,0): cdf/ccdf degenerate to a step, the smaller tail is 0
-    } else {
-        const double z = fabs(v) / se;
-        p = erfc(z * 0.70710678118654752440);
-        p = p > 1.0 ? 1.0 : p;
-    }
-    pval[i] = p;
-    sorted_p[rank] = p;
+    a.rank_a[i] = rank;
+    const double p = normal_p(v, se);
+    a.result[i] = p;
+    a.sorted_p[rank] = p;
 }
 
 // Benjamini-Hochberg step-up (:413), part 1: p_(r) * (n/r) and the reverse
 // cumulative minimum inside blocks of 1024 ranks (in place) + the block minima.
-__global__ __launch_bounds__(1024) void k3_bh_local(const IterState *__restrict__ st, double *__restrict__ sorted_p,
-                                                    int G, double *__restrict__ blockmin)
+__global__ __launch_bounds__(1024) void k3_bh_local(IterArgs a)
 {
-    if (st->done) return;
+    int tp, nref;
+    if (!full_pass_active(a, tp, nref)) return;
+    const int G = a.G;
     __shared__ double wmin[16];
     const int r = blockIdx.x * 1024 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double v = r < G ? sorted_p[r] * (static_cast<double>(G) / static_cast<double>(r + 1)) : INFINITY;
+    double v = r < G ? a.sorted_p[r] * (static_cast<double>(G) / static_cast<double>(r + 1)) : INFINITY;
     // reverse cumulative minimum inside the wave (min is exact: any order gives the same bits) ...
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -992,28 +1051,78 @@ __global__ __launch_bounds__(1024) void k3_bh_local(const IterState *__restrict_
     double t = INFINITY;
     for (int k = wave + 1; k < 16; ++k) { const double w = wmin[k]; t = w < t ? w : t; }
     v = t < v ? t : v;
-    if (r < G) sorted_p[r] = v;
-    if (threadIdx.x == 0) blockmin[blockIdx.x] = v;
+    if (r < G) a.sorted_p[r] = v;
+    if (threadIdx.x == 0) a.blockmin[blockIdx.x] = v;
 }
 
-// BH part 2 + mask update.  padj -> column 2 (:416); non-DEG mask inds (:417)
-// as bytes and bits for the next pass; the last workgroup to finish applies
-// the loop control of :418-424 to the device-side iteration state.
-__global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, const double *__restrict__ pval,
-                                                   const double *__restrict__ sufmin,
-                                                   const double *__restrict__ blockmin,
-                                                   const uint32_t *__restrict__ ra, int G, int Gp,
-                                                   double pval_deg, double padj_deg, int n_conv,
-                                                   double *__restrict__ padj, uint8_t *__restrict__ nbytes,
-                                                   uint32_t *__restrict__ nbits, int32_t *__restrict__ trace,
-                                                   const uint8_t *__restrict__ obytes, uint32_t *__restrict__ dlist,
-                                                   int slot_next)
+// The end of a pass, shared by the sorting path (k3_finalize) and the light path (kl_mask): the non-DEG mask
+// inds (:417) of gene i as bytes and bits for the next pass, the list of genes whose mask bit changes (the next
+// pass updates its tallies from their rows alone, delta_genes), and -- by the last workgroup to finish -- the loop
+// control of :418-424 on the device-side iteration state.  Every thread of the grid (Gp threads) must call it.
+// Returns -1 except in thread 0 of the last workgroup, where it returns 1 when more genes changed than a tally
+// update can take (the next pass must scan the table) and 0 otherwise; that thread then sets st->need_full.
+__device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, bool ind, bool light)
 {
-    if (st->done) return;
+    IterState *st = a.st;
+    const int cur = t & 1, nxt = 1 - cur;
+    if (i < a.Gp) a.refbytes[nxt][i] = ind ? 1 : 0;
+    const bool changed = i < a.G && ind != (a.refbytes[cur][i] != 0);
+    const unsigned long long cm = __ballot(changed);
+    if (cm) {
+        int basepos = 0;
+        if ((threadIdx.x & 63) == 0) basepos = atomicAdd(&st->delta_cnt[nxt], __popcll(cm));
+        basepos = __shfl(basepos, 0, 64);
+        const int at = basepos + __popcll(cm & ((1ULL << (threadIdx.x & 63)) - 1ULL));
+        if (changed && at < kDeltaMax) a.delta_list[static_cast<size_t>(nxt) * a.Gp + at] = (static_cast<uint32_t>(i) << 1) | (ind ? 1u : 0u);
+    }
+    const unsigned long long m = __ballot(ind);
+    __shared__ int wave_nn[4];
+    if ((threadIdx.x & 63) == 0) {
+        if (i < a.Gp) {
+            a.refbits[nxt][i >> 5] = static_cast<uint32_t>(m);
+            a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+        }
+        wave_nn[threadIdx.x >> 6] = __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return -1;
+    // one atomic per workgroup, not per wave: serialised updates of one word were a third of this kernel
+    const int nn_blk = wave_nn[0] + wave_nn[1] + wave_nn[2] + wave_nn[3];
+    if (nn_blk) atomicAdd(&st->nn_acc, nn_blk);
+    __threadfence();
+    const int tk = atomicAdd(&st->ticket, 1);
+    if (tk != static_cast<int>(gridDim.x) - 1) return -1;
+    __threadfence();
+    const int nn = atomicAdd(&st->nn_acc, 0);  // sum(inds), :417-418
+    a.trace[2 * t] = a.G - nn;
+    a.trace[2 * t + 1] = nn;
+    st->passes = t + 1;
+    st->nref_prev = st->nref;
+    const int diff = st->nref - nn;
+    if ((diff < 0 ? -diff : diff) < a.n_conv) {
+        st->done = 1;       // :419-422
+    } else {
+        st->i_iter += 1;    // :423
+        st->nref = nn;      // ref_gene_vec = inds, :424
+    }
+    st->last_full = light ? 0 : 1;
+    st->nn_acc = 0;
+    st->ticket = 0;
+    return atomicAdd(&st->delta_cnt[nxt], 0) > kDeltaMax ? 1 : 0;
+}
+
+// BH part 2 + mask update of a sorting pass.  padj -> column 2 (:416), inds (:417), loop control (:418-424); the last
+// workgroup also lays the quantile windows for a following light pass around ranks a0 and b0 of the sorted delta1.
+// replay: padj only.
+__global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
+{
+    int t, nref;
+    if (!full_pass_active(a, t, nref)) return;
+    const int G = a.G;
     __shared__ double tail[65];
     const int nb = (G + 1023) / 1024;
     __shared__ double bm[64];
-    if (static_cast<int>(threadIdx.x) < nb) bm[threadIdx.x] = blockmin[threadIdx.x];
+    if (static_cast<int>(threadIdx.x) < nb) bm[threadIdx.x] = a.blockmin[threadIdx.x];
     __syncthreads();
     if (static_cast<int>(threadIdx.x) <= nb) {  // tail[b] = minimum over the blocks after b (one thread per b)
         double run = INFINITY;
@@ -1024,59 +1133,285 @@ __global__ __launch_bounds__(256) void k3_finalize(IterState *__restrict__ st, c
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool ind = false;
     if (i < G) {
-        const uint32_t r = ra[i];
-        double q = sufmin[r];
-        const double t = tail[r >> 10];
-        q = t < q ? t : q;
+        const uint32_t r = a.rank_a[i];
+        double q = a.sorted_p[r];
+        const double tl = tail[r >> 10];
+        q = tl < q ? tl : q;
         q = q < 1.0 ? q : 1.0;
-        padj[i] = q;
-        ind = !(pval[i] <= pval_deg && q <= padj_deg);
+        a.result[static_cast<size_t>(G) + i] = q;
+        ind = !(a.result[i] <= a.pval_deg && q <= a.padj_deg);
     }
-    if (i < Gp) nbytes[i] = ind ? 1 : 0;
-    // genes whose mask bit changes: the next pass can update its tallies from their rows alone (delta_genes)
-    const bool changed = i < G && ind != (obytes[i] != 0);
-    const unsigned long long cm = __ballot(changed);
-    if (cm) {
-        int basepos = 0;
-        if ((threadIdx.x & 63) == 0) basepos = atomicAdd(&st->delta_cnt[slot_next], __popcll(cm));
-        basepos = __shfl(basepos, 0, 64);
-        const int at = basepos + __popcll(cm & ((1ULL << (threadIdx.x & 63)) - 1ULL));
-        if (changed && at < kDeltaMax) dlist[at] = (static_cast<uint32_t>(i) << 1) | (ind ? 1u : 0u);
+    if (a.replay) return;
+    const int over = publish_mask(a, t, i, ind, false);
+    if (over < 0) return;
+    // quantile windows: the values kWindow ranks on either side of the slice bounds, kept as widths around the
+    // exact quantiles so that a light pass can re-centre them on its own quantiles
+    bool ok = G >= kLightMinG && a.a0 - kWindow >= 0 && a.b0 + kWindow < G;
+    if (ok) {
+        const double va = a.sorted_d[a.a0], vb = a.sorted_d[a.b0];
+        const double wa_lo = a.sorted_d[a.a0 - kWindow], wa_hi = a.sorted_d[a.a0 + kWindow];
+        const double wb_lo = a.sorted_d[a.b0 - kWindow], wb_hi = a.sorted_d[a.b0 + kWindow];
+        ok = wa_hi < wb_lo;
+        a.scal[1] = wa_lo; a.scal[2] = wa_hi; a.scal[3] = wb_lo; a.scal[4] = wb_hi;
+        a.scal[5] = va - wa_lo; a.scal[6] = wa_hi - va; a.scal[7] = vb - wb_lo; a.scal[8] = wb_hi - vb;
     }
-    const unsigned long long m = __ballot(ind);
-    __shared__ int wave_nn[4];
-    if ((threadIdx.x & 63) == 0) {
-        if (i < Gp) {
-            nbits[i >> 5] = static_cast<uint32_t>(m);
-            nbits[(i >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+    a.st->need_full = (over || !ok) ? 1 : 0;
+    a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0;  // a light pass may have failed half-way
+}
+
+// ---------------------------------------------------------------------------
+// Light passes.  A pass needs three things of the G values delta1: the trimmed standard deviation (:409-411), the
+// BH decision padj <= padj_deg (:413,417) and the counts of :418 -- none of which needs the sorted vector:
+//  * the slice bounds are two order statistics.  From one pass to the next delta1 moves little, so the values that
+//    can hold rank a0 (b0) are those inside a narrow window around the previous pass's quantile: kl_derive counts
+//    the values below each window, collects the few hundred inside, and its last workgroup sorts just those, reads
+//    the exact order statistics off them and combines the slice's moments (block partials of the values strictly
+//    between the windows + the window values inside the slice).  A window that fails to hold its order statistic
+//    makes the pass fall back to the sorting path (st->need_full);
+//  * BH: with m_i = min{r : p_i (n/r) <= padj_deg} (the same floating-point expression as the step-up rule) and
+//    H(r) = #{i : m_i <= r}, the rule's cut is k* = max{r : H(r) >= r} and padj_i <= padj_deg <=> m_i <= k*:
+//    a histogram and one scan instead of a sort (proof in DESIGN.md).
+// Only the pass that ends the loop needs padj values and the other output columns: they are recomputed from its
+// tallies by the sorting path (replay).  Three kernels per pass instead of seven, none of them searching or sorting
+// G values.
+
+// Bitonic sort of the 64 doubles a wave holds (one per lane), ascending by lane: 21 shuffle stages, no LDS, no barrier.
+__device__ __forceinline__ double sort64(double x)
+{
+    const int t = threadIdx.x & 63;
+    for (int k = 2; k <= 64; k <<= 1) {
+        const bool up = (t & k) == 0 || k == 64;
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const bool keep_min = ((t & j) == 0) == up;
+            const double px = __shfl_xor(x, j, 64);
+            if (keep_min ? (px < x) : (px > x)) x = px;
         }
-        wave_nn[threadIdx.x >> 6] = __popcll(m);
     }
+    return x;
+}
+
+// sum over the 64 lanes of a wave, the same bits in every lane (xor butterfly)
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// light pass, kernel 1: tallies from the changed rows, delta1, window bookkeeping
+__global__ __launch_bounds__(256) void kl_derive(IterArgs a)
+{
+    int t;
+    if (!light_pass_active(a, t)) return;
+    IterState *st = a.st;
+    const int G = a.G, cur = t & 1;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        st->delta_cnt[1 - cur] = 0;  // kl_mask of this pass fills that list
+        st->raw_pass = t;
+    }
+    STAMP(a, 13);
+    __shared__ double red[256];
+    __shared__ int wcnt[4][2];
+    const double wa_lo = a.scal[1], wa_hi = a.scal[2], wb_lo = a.scal[3], wb_hi = a.scal[4];
+    double v = 0.0;
+    bool inner = false, inA = false, inB = false, belowA = false, belowB = false;
+    if (i < G) {
+        delta_gene(a.table, a.Wp, a.delta_list + static_cast<size_t>(cur) * a.Gp, st->delta_cnt[cur], a.raw, i);
+        STAMP(a, 14);
+        int32_t c[9];
+        tallies_of(a.raw, a.refbytes[cur][i] != 0, st->nref, i, c);
+        double o[5];
+        mccullagh3<false>(c, o);
+        v = o[1];
+        STAMP(a, 15);
+        a.result[11 * static_cast<size_t>(G) + i] = v;
+        a.hist[i] = 0;  // bins G .. of the padded histogram are never touched (zeroed once per call)
+        belowA = v < wa_lo; inA = !belowA && v <= wa_hi;
+        belowB = v < wb_lo; inB = !belowB && v <= wb_hi;
+        inner = v > wa_hi && v < wb_lo;
+    }
+    // block partial moments of the values strictly between the windows (always inside the slice)
+    {
+        const double nb = block_sum_256(inner ? 1.0 : 0.0, red);
+        const double sum = block_sum_256(inner ? v : 0.0, red);
+        const double mean = nb > 0.0 ? sum / nb : 0.0;
+        const double m2 = block_sum_256(inner ? (v - mean) * (v - mean) : 0.0, red);
+        if (threadIdx.x == 0) { a.part[3 * blockIdx.x] = nb; a.part[3 * blockIdx.x + 1] = mean; a.part[3 * blockIdx.x + 2] = m2; }
+    }
+    STAMP(a, 16);
+    // counts below the windows and the window members (one atomic per wave each)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long mA = __ballot(inA), mB = __ballot(inB), bA = __ballot(belowA), bB = __ballot(belowB);
+    int baseA = 0, baseB = 0;
+    if (lane == 0) {
+        if (mA) baseA = atomicAdd(&st->cnt_a, __popcll(mA));
+        if (mB) baseB = atomicAdd(&st->cnt_b, __popcll(mB));
+        wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
+    }
+    baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) a.cand[at] = v; }
+    if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) a.cand[kCandMax + at] = v; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        // one atomic per workgroup, not per wave: 313 serialised updates of one word were a third of this kernel
-        const int nn_blk = wave_nn[0] + wave_nn[1] + wave_nn[2] + wave_nn[3];
-        if (nn_blk) atomicAdd(&st->nn_acc, nn_blk);
-        __threadfence();
-        const int t = atomicAdd(&st->ticket, 1);
-        if (t == static_cast<int>(gridDim.x) - 1) {
-            __threadfence();
-            const int nn = atomicAdd(&st->nn_acc, 0);  // sum(inds), :417-418
-            const int pass = st->passes;
-            trace[2 * pass] = G - nn;
-            trace[2 * pass + 1] = nn;
-            st->passes = pass + 1;
-            const int diff = st->nref - nn;
-            if ((diff < 0 ? -diff : diff) < n_conv) {
-                st->done = 1;       // :419-422
-            } else {
-                st->i_iter += 1;    // :423
-                st->nref = nn;      // ref_gene_vec = inds, :424
-            }
-            st->nn_acc = 0;
-            st->ticket = 0;
+        const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
+        if (ba) atomicAdd(&st->below_a, ba);
+        if (bb) atomicAdd(&st->below_b, bb);
+    }
+    STAMP(a, 17);
+}
+
+// light pass, kernel 2: every workgroup finishes the selection for itself (the two order statistics and the slice
+// moments from the window members and the block partials: a few hundred values), then p-values (:412), BH ranks
+// m_i and their histogram for its genes.  Workgroup 0 also publishes se, the next windows, or the failure.
+__global__ __launch_bounds__(256) void kl_pvalues(IterArgs a)
+{
+    int t;
+    if (!light_pass_active(a, t)) return;
+    IterState *st = a.st;
+    const int G = a.G;
+    __shared__ double red[256];
+    __shared__ double sel[2][4];  // per window: order statistic, count, mean, M2 of its members inside the slice
+    STAMP(a, 0);
+    const int below_a = st->below_a, below_b = st->below_b, cnt_a = st->cnt_a, cnt_b = st->cnt_b;
+    const int ia = a.a0 - below_a, ib = a.b0 - below_b;  // positions of the order statistics inside the sorted windows
+    bool ok = cnt_a <= kCandMax && cnt_b <= kCandMax && ia >= 0 && ia < cnt_a && ib >= 0 && ib < cnt_b;
+    double se = 0.0, va = 0.0, vb = 0.0;
+    if (ok) {  // workgroup-uniform
+        // wave 0 sorts window A, wave 1 window B (<= 64 values each, one per lane); the slice takes window A from its
+        // order statistic on and window B up to its order statistic
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (wave < 2) {
+            const int cnt = wave ? cnt_b : cnt_a, pos = wave ? ib : ia;
+            const double x = sort64(lane < cnt ? a.cand[wave * kCandMax + lane] : INFINITY);
+            const bool in = wave ? lane <= pos : (lane >= pos && lane < cnt);
+            const double n = static_cast<double>(wave ? pos + 1 : cnt - pos);
+            const double mean = wave_sum(in ? x : 0.0) / n;
+            const double q = wave_sum(in ? (x - mean) * (x - mean) : 0.0);
+            const double stat = __shfl(x, pos, 64);
+            if (lane == 0) { sel[wave][0] = stat; sel[wave][1] = n; sel[wave][2] = mean; sel[wave][3] = q; }
+        }
+        STAMP(a, 1);
+        double n0, mean0, q0;
+        combine_moments(a.part, (G + 255) / 256, red, n0, mean0, q0);  // (its barriers also publish sel)
+        STAMP(a, 2);
+        va = sel[0][0]; vb = sel[1][0];
+        const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
+        STAMP(a, 3);
+        if (!(n0 > 0.0)) { mean0 = 0.0; q0 = 0.0; }  // no value between the windows: combine_moments divided by zero
+        const double n = n0 + n1 + n2;
+        const double mean = (n0 * mean0 + n1 * mean1 + n2 * mean2) / n;
+        const double m2 = (q0 + n0 * (mean0 - mean) * (mean0 - mean)) + (q1 + n1 * (mean1 - mean) * (mean1 - mean)) +
+                          (q2 + n2 * (mean2 - mean) * (mean2 - mean));
+        se = sqrt(m2 / (n - 1.0));
+        ok = static_cast<int>(n) == a.b0 - a.a0 + 1 && (va + a.scal[6] < vb - a.scal[7]);  // (holds for G >= kLightMinG)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (ok) {
+            a.scal[0] = se;
+            // windows for the next light pass: the same widths around this pass's quantiles (9..12: read by no kernel
+            // of this pass; kl_mask's last workgroup moves them to 1..4)
+            a.scal[9] = va - a.scal[5]; a.scal[10] = va + a.scal[6]; a.scal[11] = vb - a.scal[7]; a.scal[12] = vb + a.scal[8];
+        } else {
+            st->need_full = 1;  // a window lost its order statistic: this pass runs on the sorting path (tallies are up to date)
         }
     }
+    if (!ok) return;
+    STAMP(a, 4);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < G;
+    const double p = live ? normal_p(a.result[11 * static_cast<size_t>(G) + i], se) : 1.0;
+    if (live) a.result[i] = p;
+    // m = the smallest rank r at which the step-up rule's p (n/r) is within padj_deg (n + 1: none)
+    const double Gd = static_cast<double>(G), al = a.padj_deg;
+    auto within = [&](int r) { return p * (Gd / static_cast<double>(r)) <= al; };
+    int m;
+    if (!live || !within(G)) m = G + 1;
+    else {
+        const double est = ceil(p * Gd / al);
+        m = est < 1.0 ? 1 : (est > Gd ? G : static_cast<int>(est));
+        while (m > 1 && within(m - 1)) --m;
+        while (!within(m)) ++m;  // within(G) holds
+    }
+    STAMP(a, 5);
+    if (live) a.mrank[i] = m;
+    // bin m - 1.  Strongly significant genes all have m = 1: one atomic per wave for that bin, not one per gene
+    // (thousands of adds to one word serialise at about 12 ns each)
+    const unsigned long long first = __ballot(m == 1);
+    if (m == 1) { if ((threadIdx.x & 63) == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&a.hist[0], __popcll(first)); }
+    else if (m <= G) atomicAdd(&a.hist[m - 1], 1);
+    STAMP(a, 6);
+}
+
+// light pass, kernel 3: every workgroup finds the BH cut k* = max{r in 1..G : H(r) >= r} (H = running sum of the
+// histogram: 4 G bytes, read coalesced) for itself, then inds (:417) from p and the cut, mask, change list, loop
+// control (:418-424).
+__global__ __launch_bounds__(256) void kl_mask(IterArgs a)
+{
+    int t;
+    if (!light_pass_active(a, t)) return;
+    const int G = a.G;
+    // bin b = rank b + 1.  Tiles of 2048 bins (eight consecutive bins = two int4 per thread), sixteen tiles per round so
+    // that their loads are in flight together and their wave scans interleave; two barriers per round.
+    STAMP(a, 8);
+    __shared__ __attribute__((aligned(16))) int wsum[16][4];
+    __shared__ int wbest[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int4 *hist4 = reinterpret_cast<const int4 *>(a.hist);
+    const int ntile = (G + 2047) / 2048;
+    int best = 0, carry = 0;
+    for (int q0 = 0; q0 < ntile; q0 += 16) {
+        int4 h[16][2];
+        int s[16], inc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {  // unconditional: the histogram is padded with zero bins to whole rounds of 16 tiles
+            h[e][0] = hist4[(q0 + e) * 512 + 2 * threadIdx.x];
+            h[e][1] = hist4[(q0 + e) * 512 + 2 * threadIdx.x + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = (h[e][0].x + h[e][0].y + h[e][0].z + h[e][0].w) + (h[e][1].x + h[e][1].y + h[e][1].z + h[e][1].w);
+            inc[e] = s[e];
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const int u = __shfl_up(inc[e], o, 64); if (lane >= o) inc[e] += u; }
+        if (lane == 63)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wsum[e][wave] = inc[e];
+        __syncthreads();
+        int4 ws[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ws[e] = *reinterpret_cast<const int4 *>(wsum[e]);  // sixteen independent 16-byte reads
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int run = carry + inc[e] - s[e] + (wave > 0 ? ws[e].x : 0) + (wave > 1 ? ws[e].y : 0) + (wave > 2 ? ws[e].z : 0);
+            const int r0 = ((q0 + e) * 256 + threadIdx.x) * 8 + 1;  // rank of the first of this thread's eight bins
+            const int hv[8] = {h[e][0].x, h[e][0].y, h[e][0].z, h[e][0].w, h[e][1].x, h[e][1].y, h[e][1].z, h[e][1].w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { run += hv[u]; if (r0 + u <= G && run >= r0 + u) best = max(best, r0 + u); }
+            carry += ws[e].x + ws[e].y + ws[e].z + ws[e].w;
+        }
+        __syncthreads();  // wsum is read by everyone before the next round overwrites it
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(best, o, 64); best = u > best ? u : best; }
+    if (lane == 0) wbest[wave] = best;
+    __syncthreads();
+    const int kstar = max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
+    STAMP(a, 9);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool ind = false;
+    if (i < G) ind = !(a.result[i] <= a.pval_deg && a.mrank[i] <= kstar);
+    STAMP(a, 10);
+    const int over = publish_mask(a, t, i, ind, true);
+    STAMP(a, 11);
+    if (over < 0) return;
+    a.st->need_full = over;
+    a.scal[1] = a.scal[9]; a.scal[2] = a.scal[10]; a.scal[3] = a.scal[11]; a.scal[4] = a.scal[12];
+    a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0;
 }
 
 }  // namespace
@@ -1206,55 +1541,80 @@ int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits)
     return REO_OK;
 }
 
-int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits, int slot, bool allow_delta)
+// reo_tally: whole-table scan with the mask of parity 0, then the nine tallies per gene
+int32_t launch_tally(reo_ctx *c, int nref)
 {
     const int G = static_cast<int>(c->G);
     tic(c, 2);
-    k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(c->state.p, c->table.p, reinterpret_cast<const uint4 *>(d_refbits), G, c->Wp,
-                                                 c->raw.p, allow_delta ? slot : -1,
-                                                 allow_delta ? c->delta_list.p + static_cast<size_t>(slot) * c->Gp : nullptr,
-                                                 allow_delta ? c->modes.p : nullptr);
+    k2_scan<<<(G + 3) / 4, 256, 0, c->stream>>>(c->table.p, reinterpret_cast<const uint4 *>(c->refbits[0].p), G, c->Wp, c->raw.p);
     toc(c);
     c->t_ms[4] += 1.0;
+    k3_tallies<<<(G + 255) / 256, 256, 0, c->stream>>>(c->raw.p, c->refbytes[0].p, nref, G, c->cont.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
 
-int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int with_stats)
+static IterArgs iter_args(reo_ctx *c, int replay)
 {
-    const int G = static_cast<int>(c->G);
-    k3_derive<<<(G + 255) / 256, 256, 0, c->stream>>>(c->state.p, c->raw.p, d_refbytes, G, c->cont.p, c->result.p,
-                                                      with_stats, nullptr, 0);
-    REO_HIP_CHECK(hipGetLastError());
-    return REO_OK;
+    IterArgs a;
+    a.st = c->state.p; a.table = c->table.p;
+    a.G = static_cast<int>(c->G); a.Gp = c->Gp; a.Wp = c->Wp;
+    a.n_iter = c->it_n_iter; a.n_conv = c->it_n_conv; a.a0 = c->it_a0; a.b0 = c->it_b0;
+    a.pval_deg = c->it_pval_deg; a.padj_deg = c->it_padj_deg;
+    for (int t = 0; t < 2; ++t) { a.refbits[t] = c->refbits[t].p; a.refbytes[t] = c->refbytes[t].p; }
+    a.raw = c->raw.p; a.delta_list = c->delta_list.p; a.result = c->result.p;
+    const int nchunk = (a.G + kSortChunk - 1) / kSortChunk;
+    a.chunk_v = c->chunk_v.p; a.chunk_i = c->chunk_i.p;
+    a.chunk_spl = c->chunk_v.p + static_cast<size_t>(nchunk) * kSortChunk;  // [nchunk][kSortChunk / 32]
+    a.sorted_d = c->sorted_d.p; a.sorted_spl = c->sorted_d.p + ((c->G + 63) / 64) * 64;  // [ceil(G / 64)]
+    a.sorted_p = c->sorted_p.p; a.rank_s = c->rank_s.p; a.rank_a = c->rank_a.p;
+    a.part = c->part.p; a.blockmin = c->blockmin.p; a.scal = c->scal.p;
+    a.trace = c->trace.p; a.modes = nullptr;
+    a.cand = c->cand.p; a.hist = c->hist.p; a.mrank = c->mrank.p;
+    a.replay = replay; a.k2_idx = 0;
+    a.stamps = reinterpret_cast<unsigned long long *>(c->scal.p + 32);
+    return a;
 }
 
-int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int n_conv, int64_t a, int64_t b)
+// One pass on the sorting path (K2 + six K3 kernels); every kernel returns at once unless the device-side state
+// asks for such a pass.  replay: recompute the output columns of the last executed pass from its tallies.
+int32_t launch_full_pass(reo_ctx *c, bool replay)
 {
-    const int G = static_cast<int>(c->G);
-    const int nb = (G + 255) / 256;
-    double *res = c->result.p;
-    const double *d1 = res + 11 * c->G;
+    IterArgs a = iter_args(c, replay ? 1 : 0);
+    const int G = a.G, nb = (G + 255) / 256;
     const int nchunk = (G + kSortChunk - 1) / kSortChunk;
     const int nmerge = (nchunk * kSortChunk + kMergeThreads / kMergeLanes - 1) / (kMergeThreads / kMergeLanes);
-    k3_derive<<<nb, 256, 0, c->stream>>>(c->state.p, c->raw.p, c->refbytes[cur].p, G, nullptr, res, 1, c->state.p, 1 - cur);
-    double *chunk_spl = c->chunk_v.p + static_cast<size_t>(nchunk) * kSortChunk;  // [nchunk][kSortChunk / 32]
-    double *sorted_spl = c->sorted_d.p + ((c->G + 63) / 64) * 64;               // [ceil(G / 64)]
-    k3_sort_chunks<<<nchunk, kSortThreads, 0, c->stream>>>(c->state.p, d1, G, c->chunk_v.p, c->chunk_i.p, chunk_spl);
-    k3_merge_rank<<<nmerge, kMergeThreads, 0, c->stream>>>(c->state.p, c->chunk_v.p, c->chunk_i.p, G, nchunk,
-                                                           static_cast<int>(a - 1), static_cast<int>(b - 1),
-                                                           c->rank_s.p, c->sorted_d.p, c->part.p, chunk_spl, sorted_spl);
-    k3_abs_rank<<<nb, 256, 0, c->stream>>>(c->state.p, d1, c->rank_s.p, c->sorted_d.p, sorted_spl, G, c->part.p, nmerge,
-                                           c->rank_a.p, res, c->sorted_p.p, c->scal.p);
-    k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(c->state.p, c->sorted_p.p, G, c->blockmin.p);
-    k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(c->state.p, res, c->sorted_p.p, c->blockmin.p, c->rank_a.p, G,
-                                                    c->Gp, pval_deg, padj_deg, n_conv, res + c->G,
-                                                    c->refbytes[1 - cur].p, c->refbits[1 - cur].p, c->trace.p,
-                                                    c->refbytes[cur].p,
-                                                    c->delta_list.p + static_cast<size_t>(1 - cur) * c->Gp, 1 - cur);
+    if (!replay) {
+        if (c->k2_idx < static_cast<int>(c->modes.n)) { a.modes = c->modes.p; a.k2_idx = c->k2_idx; }
+        ++c->k2_idx;
+        tic(c, 2);
+        k2_tally<<<(G + 3) / 4, 256, 0, c->stream>>>(a);
+        toc(c);
+        c->t_ms[4] += 1.0;
+    }
+    k3_derive<<<nb, 256, 0, c->stream>>>(a);
+    k3_sort_chunks<<<nchunk, kSortChunk, 0, c->stream>>>(a);
+    k3_merge_rank<<<nmerge, kMergeThreads, 0, c->stream>>>(a, nchunk);
+    k3_abs_rank<<<nb, 256, 0, c->stream>>>(a, nmerge);
+    k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(a);
+    k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(a);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
+
+// One light pass (three kernels, no sort); returns at once on the device unless the state allows one.
+int32_t launch_light_pass(reo_ctx *c)
+{
+    const IterArgs a = iter_args(c, 0);
+    const int nb = (a.G + 255) / 256;
+    kl_derive<<<nb, 256, 0, c->stream>>>(a);
+    kl_pvalues<<<nb, 256, 0, c->stream>>>(a);
+    kl_mask<<<c->Gp / 256, 256, 0, c->stream>>>(a);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t light_min_genes() { return kLightMinG; }
 
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out)
 {

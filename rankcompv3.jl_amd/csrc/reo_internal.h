@@ -26,13 +26,21 @@ constexpr int kSortChunk = 1024; // genes per bitonic sort in the ranking stage
 // Device-resident loop state of the iteration driver (src/RankCompV3.jl:396-425),
 // so that passes can be enqueued back to back without a host round trip.
 struct IterState {
-    int32_t done;     // convergence reached (:419-422): later launches return at once
-    int32_t passes;   // executed passes of the while loop
-    int32_t nref;     // sum(ref_gene_vec) of the current pass
-    int32_t i_iter;   // :397,423
-    int32_t ticket;   // finished workgroups of k3_finalize
-    int32_t nn_acc;   // running sum(inds)
+    int32_t done;      // convergence reached (:419-422): later launches return at once
+    int32_t passes;    // executed passes of the while loop
+    int32_t nref;      // sum(ref_gene_vec) of the current pass
+    int32_t i_iter;    // :397,423
+    int32_t ticket;    // finished workgroups of the kernel that ends a pass
+    int32_t nn_acc;    // running sum(inds)
     int32_t delta_cnt[2];  // genes whose mask bit changes for the pass of that parity (see delta_genes in kernels.hip)
+    int32_t need_full; // the next pass must run on the sorting path (tallies need a table scan, or no quantile windows)
+    int32_t raw_pass;  // the tally counters hold the tallies of this pass (-1: none)
+    int32_t nref_prev; // nref of the last executed pass (for recomputing its outputs)
+    int32_t last_full; // the last executed pass ran on the sorting path: every output column is in place
+    int32_t tick_a, tick_b;                     // finished workgroups of kl_derive / kl_pvalues
+    int32_t below_a, below_b, cnt_a, cnt_b;     // light pass: values below / inside the two quantile windows
+    int32_t kstar;     // light pass: the Benjamini-Hochberg cut
+    int32_t pad[3];
 };
 
 void set_error(const char *fmt, ...);
@@ -146,7 +154,13 @@ struct reo_ctx {
     reo::DevBuf<double> part;           // [<= 256][3] slice moments per block
     reo::DevBuf<reo::IterState> state;  // [1]
     reo::DevBuf<int32_t> trace;         // [n_iter][2]
-    reo::DevBuf<int32_t> modes;         // [n_iter] 1 = the pass scanned the whole table in K2, 0 = incremental update
+    reo::DevBuf<int32_t> modes;         // [K2 launches] 1 = the launch scanned the whole table, 0 = incremental update or skipped
+    reo::DevBuf<double> cand;           // [2][1024] light passes: values inside the quantile windows
+    reo::DevBuf<int32_t> hist, mrank;   // [G padded to whole 1024-bin tiles], [G] light passes: histogram of the BH ranks, the ranks
+    // parameters of the running reo_identify_degs call (kernels.hip, iter_args)
+    double it_pval_deg = 1.0, it_padj_deg = 0.05;
+    int it_n_iter = 0, it_n_conv = 0, it_a0 = 0, it_b0 = 0;
+    int k2_idx = 0;                     // K2 launches of the running call
     reo::IterState *host_state = nullptr;  // pinned
 
     // timing
@@ -169,9 +183,10 @@ int32_t launch_k1(reo_ctx *c, int k);
 int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq);
 int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
-int32_t launch_k2(reo_ctx *c, const uint32_t *d_refbits, int slot, bool allow_delta);
-int32_t launch_derive(reo_ctx *c, const uint8_t *d_refbytes, int with_stats);
-int32_t launch_stats(reo_ctx *c, int cur, double pval_deg, double padj_deg, int n_conv, int64_t a, int64_t b);
+int32_t launch_tally(reo_ctx *c, int nref);
+int32_t launch_full_pass(reo_ctx *c, bool replay);
+int32_t launch_light_pass(reo_ctx *c);
+int32_t light_min_genes();
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
 
 // comm.hip: in-library RCCL.  Returns REO_OK after enqueueing the sum on c->stream, 1 when no communicator is attached
