@@ -1,29 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: gene-pair·sample comparisons/s of the REO hot path.
 
-`dtype` is "f32": the pair kernel compares 16-bit sorted positions held as exact integers in fp32
-(v_pk_add_f32 with clamp); the tallies are integer popcounts and the per-gene statistics fp64.
-`scaling` is "strong": with N GPUs the same 20k x 1k problem is split over the ranks.
+One "step" = one full pass of the hot path over the BASELINE.json config-3 workload (synthetic 20,000 genes x 1,000
+samples, tie-free T0 family, 2 groups, 3,000 initial reference genes, n_iter = 128): rank/band transform + pair kernel
+K1 + 128 iteration passes (tallies + statistics), with the expression matrix already resident in HBM when the timed
+region starts and the G x 15 result copied back to the host inside it.  The primary `value` uses n_conv = 0, which
+makes the convergence test of src/RankCompV3.jl:419 never true, i.e. exactly 128 passes (deterministic, worst case);
+the run with the reference's default n_conv = 5 is reported beside it as `converged`, and the tie-rich family (count
+data: two comparisons per pair and sample) as `tie_rich`.
 
-One "step" = one full pass of the hot path over the BASELINE.json config-3
-workload (synthetic 20,000 genes x 1,000 samples, tie-free T0 family, 2 groups,
-3,000 initial reference genes, n_iter = 128): rank/band transform + pair kernel
-K1 + 128 iterations of (tally K2 + statistics K3), with the expression matrix
-already resident in HBM when the timed region starts and the G x 15 result
-copied back to the host inside it.  The primary `value` uses n_conv = 0, which
-makes the convergence test of src/RankCompV3.jl:419 never true, i.e. exactly
-128 iterations (deterministic, worst case); the run with the default
-n_conv = 5 is reported beside it as `converged`.
+`dtype` is "u16": the pair kernel compares 16-bit sorted positions, bit-sliced over 32-sample blocks (v_bitop3_b32
+borrow chains + v_bcnt_u32_b32); the tallies are integer popcounts and the per-gene statistics fp64.
+`scaling` is "strong": with N GPUs the same 20k x 1k problem is split over the ranks (pair tiles; one RCCL all-reduce
+of the class table inside reo_build_pairs, in-library: reo_comm_init_rank).
 
-python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with
-torch.distributed.run (one rank per GPU; the G dimension is sharded by pair
-tile and the per-gene tallies are all-reduced over RCCL every iteration).
+python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with torch.distributed.run (one rank per GPU).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -34,9 +33,30 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s measured copy)
-VALU_CMP_PEAK = 3.93e13    # comparisons/s: 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4 cycles per comparison (one v_pk_add_f32
-                           # clamp + one v_pk_add_f32, 4 cycles each, per TWO comparisons; tools/microbench_cmp3.hip measures
-                           # 36.5e12/s for that pair at the clock the chip holds)
+CLOCK = 2.4e9              # Hz, the nominal shader clock the issue peak is priced at (the chip holds about 2.0 GHz under this load)
+SIMDS = 256 * 4
+
+
+def valu_peak(nbits: int, ties: bool) -> float:
+    """Issue floor of the bit-sliced pair loop: per 32 samples of one pair and lane, `nbits` v_bitop3_b32 at 2 cycles
+    (full rate, three VGPR sources) + one v_bcnt_u32_b32 at 4 cycles (half rate), twice that with ties (lo and hi);
+    64 lanes per wave instruction, 4 SIMDs per CU, 256 CUs.  Measured rates: tools/microbench_bitop.hip."""
+    cycles = (2 * nbits + 4) * (2 if ties else 1)
+    return SIMDS * CLOCK * (64 * 32) / cycles
+
+
+def plane_bits(G: int) -> int:
+    return 12 if G <= 4095 else (15 if G <= 32767 else 16)
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main() -> None:
@@ -49,9 +69,10 @@ def main() -> None:
     ap.add_argument("--family", default="t0", choices=["t0", "t1"])
     ap.add_argument("--n-iter", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-genes", type=int, default=6000)
+    ap.add_argument("--no-tie-rich", action="store_true")
+    ap.add_argument("--cpu-genes", type=int, default=8000)
     ap.add_argument("--debug-gloo-one-gpu", action="store_true",
-                    help="debug only: every rank uses cuda:0 and the all-reduce goes through gloo via the host")
+                    help="debug only: every rank uses cuda:0 and the table exchange goes through gloo via the host")
     args = ap.parse_args()
 
     import torch
@@ -66,128 +87,185 @@ def main() -> None:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # RCCL and gloo print banners to stdout when a communicator comes up; stdout carries the one JSON line only
+    class _StdoutToStderr:
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        def __exit__(self, *exc):
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+
     if world > 1:
-        if args.debug_gloo_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        with _StdoutToStderr():
+            if args.debug_gloo_one_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
 
     pkg = ge.load_pkg()
     G, S, seed = args.genes, args.samples, 0x5EED0003
-    gen = pkg.synth.t0_ranks if args.family == "t0" else pkg.synth.t1_counts
-    X = gen(G, S, seed)                                   # Int64, like Matrix(df_expr) of count data
     group = pkg.synth.groups(S)
     gid, lev = pkg.encode_groups(group)
     ref0 = pkg.synth.ref_mask(G, 3000, seed)              # ref_gene_max = 3000
-    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)  # (S, G) row-major == G x S column-major, ld = G
-    torch.cuda.synchronize()
-
-    ctx = pkg.Context(device=local, seed=seed)
-    ctx.set_profiling(True)
-    if world > 1:
-        ctx.set_shard(rank, world)
-
-        ctx.set_allreduce(pkg.dist.allreduce_hook(dev, via_host=args.debug_gloo_one_gpu))
-
-    verbose = bool(os.environ.get("REO_BENCH_VERBOSE"))
-
-    def step(n_conv: int):
-        t = [time.perf_counter()]
-        ctx.set_matrix_device(Xd.data_ptr(), G, S, G, "i64")
-        ctx.set_groups(gid, len(lev))
-        ctx.compute_thresholds(0.01)
-        t.append(time.perf_counter())
-        ctx.build_pairs(0)
-        t.append(time.perf_counter())
-        out = ctx.identify_degs(ref0, 1.0, 0.05, args.n_iter, n_conv)
-        t.append(time.perf_counter())
-        if verbose and rank == 0:
-            print("step wall ms: setup %.2f build_pairs %.2f identify_degs %.2f" %
-                  tuple((b - a) * 1e3 for a, b in zip(t, t[1:])), file=sys.stderr)
-        return out
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_conv: int, steps: int):
-        ctx.reset_timings()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            res, iters, trace = step(n_conv)
-        barrier()
-        dt = time.perf_counter() - t0
+    def make_ctx():
+        ctx = pkg.Context(device=local, seed=seed)
+        ctx.set_profiling(True)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.debug_gloo_one_gpu else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, iters, trace, ctx.timings(), res
+            if args.debug_gloo_one_gpu:
+                ctx.set_shard(rank, world)
+                ctx.set_allreduce(pkg.dist.allreduce_hook(dev, via_host=True))
+            else:  # in-library RCCL: rank 0 makes the id, torch.distributed only carries its 128 bytes
+                with _StdoutToStderr():
+                    box = [pkg._ffi.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    ctx.comm_init_rank(box[0], rank, world)
+        return ctx
 
-    for _ in range(args.warmup):
-        step(0)
-    dt, iters, trace, tm, res = timed(0, args.steps)
-    dtc, iters_c, trace_c, tmc, _ = timed(5, max(1, args.steps))
-    info = ctx.info()
+    def run_family(family: str, steps: int, warmup: int, n_conv_list):
+        gen = pkg.synth.t0_ranks if family == "t0" else pkg.synth.t1_counts
+        X = gen(G, S, seed)                                   # Int64, like Matrix(df_expr) of count data
+        Xd = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)  # (S, G) row-major == G x S column-major, ld = G
+        torch.cuda.synchronize()
+        ctx = make_ctx()
+
+        def step(n_conv: int):
+            ctx.set_matrix_device(Xd.data_ptr(), G, S, G, "i64")
+            ctx.set_groups(gid, len(lev))
+            ctx.compute_thresholds(0.01)
+            ctx.build_pairs(0)
+            return ctx.identify_degs(ref0, 1.0, 0.05, args.n_iter, n_conv)
+
+        def timed(n_conv: int, steps: int):
+            ctx.reset_timings()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                res, iters, trace = step(n_conv)
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.debug_gloo_one_gpu else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt, iters, trace, ctx.timings(), res
+
+        for _ in range(warmup):
+            step(n_conv_list[0])
+        out = [timed(nc, steps) for nc in n_conv_list]
+        info = ctx.info()
+        ctx.close()
+        return X, out, info
+
+    X, (forced, conv), info = run_family(args.family, args.steps, args.warmup, [0, 5])
+    dt, iters, trace, tm, res = forced
+    dtc, iters_c, trace_c, tmc, _ = conv
 
     P = G * (G - 1) // 2
     units = P * S                                          # comparisons per step (whole job, all ranks together)
     value = units * args.steps / dt
-    k1_ms = tm["k1_ms"] / max(tm["k1_launches"], 1)
-    k2_ms = tm["k2_full_ms"] / max(tm["k2_full_launches"], 1)   # full-scan launches only
     share = info["tiles_owned"] / max(info["tiles_total"], 1)
-    # algorithmic bytes: K1 reads G*S*2 B of u16 ranks and writes the 4-bit class table,
-    # K2 streams the class table + mask and writes int32[9] per gene
-    k1_bytes = (G * S * 2 + G * G / 2) * share
+
+    def k1_roofline(tm_, info_, ties: bool):
+        k1_ms = tm_["k1_ms"] / max(tm_["k1_launches"], 1)
+        share_ = info_["tiles_owned"] / max(info_["tiles_total"], 1)
+        # algorithmic bytes: K1 reads G*S*2 B of 16-bit positions and writes the 4-bit class table
+        k1_bytes = (G * S * 2 + G * G / 2) * share_
+        peak = valu_peak(plane_bits(G), ties)
+        rate = units * share_ / (k1_ms * 1e-3)
+        return {"bound": "valu", "achieved": rate / 1e12, "peak": peak / 1e12, "unit": "Tcmp/s", "frac": rate / peak,
+                "peak_definition": "256 CU x 4 SIMD x 2.4 GHz x 2048 comparisons per (2*bits+4)%s cycles, bits=%d" % (" x 2" if ties else "", plane_bits(G)),
+                "hbm_achieved_GBps": k1_bytes / (k1_ms * 1e-3) / 1e9, "hbm_frac": k1_bytes / (k1_ms * 1e-3) / HBM_PEAK,
+                "ms_per_launch": k1_ms, "traffic": None, "kernel": "k1_pairs<%d,%s,false>" % (plane_bits(G), "true" if ties else "false")}
+
+    k1 = k1_roofline(tm, info, bool(info["has_ties"]))
+    k2_ms = tm["k2_full_ms"] / max(tm["k2_full_launches"], 1)   # whole-table scans only
+    # K2 streams the class table + mask and writes int32[8] per gene
     k2_bytes = G * G / 2 + G / 8 + 36 * G
-    k1_cmp_rate = units * share / (k1_ms * 1e-3)
-    k1 = {"bound": "valu", "achieved": k1_cmp_rate / 1e12, "peak": VALU_CMP_PEAK / 1e12, "unit": "Tcmp/s",
-          "frac": k1_cmp_rate / VALU_CMP_PEAK, "hbm_achieved_GBps": k1_bytes / (k1_ms * 1e-3) / 1e9,
-          "hbm_frac": k1_bytes / (k1_ms * 1e-3) / HBM_PEAK, "ms_per_launch": k1_ms, "traffic": None,
-          "kernel": "k1_pairs"}
-    k2 = {"bound": "hbm", "achieved": k2_bytes / (k2_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-          "frac": k2_bytes / (k2_ms * 1e-3) / HBM_PEAK, "ms_per_launch": k2_ms, "launches": tm["k2_full_launches"],
-          "incremental_passes": tm["k2_launches"] - tm["k2_full_launches"],
+    k2 = {"bound": "hbm", "achieved": k2_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+          "frac": k2_bytes / (k2_ms * 1e-3) / HBM_PEAK if k2_ms else None, "ms_per_launch": k2_ms, "launches": tm["k2_full_launches"],
           "traffic": None, "kernel": "k2_tally"}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         with open(pmc) as f:
             tr = json.load(f)
         k1["traffic"], k2["traffic"] = tr.get("k1_pairs"), tr.get("k2_tally")
-    dominant = k1 if tm["k1_ms"] >= tm["k2_full_ms"] else k2
 
     out = {
         "metric": "gene-pair·sample comparisons/sec at 20k genes × 1k samples",
         "value": value, "unit": "comparisons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "scaling": "strong", "vs_baseline": None, "dtype": "u16",
+        "dtype_note": "pair kernel: 16-bit sorted positions as bit planes (exact); tallies: integer popcounts; statistics: fp64",
         "data": "synthetic",
         "config": {"workload": f"BASELINE config 3: synthetic {G} genes x {S} samples ({args.family.upper()} family, Int64 input), "
                                f"2 groups, ref_gene_max=3000, n_iter={args.n_iter}, n_conv=0 (exactly {iters} iterations)",
                    "genes": G, "samples": S, "iterations": iters, "sharding": f"pair tiles over {world} GPU(s)"},
-        "converged": {"value": units * max(1, args.steps) / dtc, "ms_per_step": dtc / max(1, args.steps) * 1e3,
+        "converged": {"value": units * args.steps / dtc, "ms_per_step": dtc / args.steps * 1e3,
                       "n_conv": 5, "iterations": iters_c, "final_trace": list(trace_c[-1]) if trace_c else None},
-        "stages_ms_per_step": {k: tm[k] / args.steps for k in ("transform_ms", "k1_ms", "k2_ms", "k2_full_ms", "k2_delta_ms", "k3_ms", "iter_ms", "exchange_ms")},
-        "roofline": dominant, "roofline_k1": k1, "roofline_k2": k2,
+        "stages_ms_per_step": {k: tm[k] / args.steps for k in ("transform_ms", "k1_ms", "k2_full_ms", "iter_ms", "exchange_ms")},
+        "roofline": k1, "roofline_k1": k1, "roofline_k2": k2,
         "final_trace": list(trace[-1]) if trace else None,
         "has_ties": info["has_ties"],
     }
+    out["stages_ms_per_step"]["iteration_passes_us_each"] = tm["iter_ms"] / args.steps / max(iters, 1) * 1e3
+
+    if world > 1:  # what each rank did (the driver computes the scaling efficiency from the per-N values itself)
+        mine = {"rank": rank, "k1_ms": tm["k1_ms"] / args.steps, "tiles_owned": info["tiles_owned"], "tiles_total": info["tiles_total"],
+                "exchange_ms_per_build": tm["exchange_ms"] / args.steps, "transform_ms": tm["transform_ms"] / args.steps,
+                "iter_ms": tm["iter_ms"] / args.steps}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        rep = (mine["transform_ms"] + mine["iter_ms"]) / (dt / args.steps * 1e3)
+        out["ranks"] = allr
+        out["replicated_stage_share"] = rep     # transform + iteration passes run identically on every rank
+        out["collective"] = "one ncclAllReduce(sum, uint32) of the class table (%d MB) per reo_build_pairs, in-library RCCL" % (G * info["Gp"] // 2 // 1000000)
+
+    if not args.no_tie_rich and args.family == "t0":
+        st = max(3, args.steps // 4)
+        _, (f1,), info1 = run_family("t1", st, 1, [0])
+        dt1, it1, tr1, tm1, _ = f1
+        r1 = k1_roofline(tm1, info1, True)
+        out["tie_rich"] = {"workload": "T1 family (zero-inflated counts, ~2 % tied cells): lo and hi band edges, two borrow chains per pair",
+                           "ms_per_step": dt1 / st * 1e3, "value": units * st / dt1, "k1_ms": r1["ms_per_launch"], "frac": r1["frac"],
+                           "peak": r1["peak"], "achieved": r1["achieved"], "kernel": r1["kernel"], "steps": st}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oracle = ge.load_oracle()
-        Gs = min(args.cpu_genes, G)
-        Xs = X[:Gs].astype(np.float64)
-        refs = ref0[:Gs].copy()
-        refs[:10] = True
-        t0 = time.perf_counter()
-        oracle.identify_degs(Xs, gid, len(lev), 0.01, 1.0, 0.05, refs, args.n_iter, 0, seed)
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": (Gs * (Gs - 1) // 2) * S / tc, "unit": "comparisons/s",
-                               "cores": oracle.num_threads(), "kind": "port", "seconds": tc,
-                               "sample": f"first {Gs} genes x {S} samples of the same matrix, full identify_degs "
-                                         f"(n_iter={args.n_iter}, n_conv=0), C restatement with OpenMP"}
-    ctx.close()
+        refs_all = ref0.copy()
+        samples = []
+        for Gs in (args.cpu_genes // 2, args.cpu_genes):   # two sizes: the rate per comparison must not depend on G (G^2 S scaling)
+            Gs = min(Gs, G)
+            Xs = X[:Gs].astype(np.float64)
+            refs = refs_all[:Gs].copy(); refs[:10] = True
+            t0 = time.perf_counter()
+            oracle.identify_degs(Xs, gid, len(lev), 0.01, 1.0, 0.05, refs, args.n_iter, 0, seed)
+            tc = time.perf_counter() - t0
+            samples.append({"genes": Gs, "seconds": tc, "rate": (Gs * (Gs - 1) // 2) * S / tc})
+        big = samples[-1]
+        out["cpu_baseline"] = {"value": big["rate"], "unit": "comparisons/s", "cores": oracle.num_threads(), "kind": "port",
+                               "seconds": big["seconds"], "cpu": cpu_model(), "julia": shutil.which("julia") or "not found",
+                               "sample": f"first {big['genes']} genes x {S} samples of the same matrix, full identify_degs "
+                                         f"(n_iter={args.n_iter}, n_conv=0), C restatement of the reference's loop nest with OpenMP",
+                               "scaling_check": {"sizes": samples, "rate_ratio_big_over_small": big["rate"] / samples[0]["rate"]}}
+        if hasattr(oracle, "tuned_identify_degs"):
+            Gs = min(args.cpu_genes, G)
+            Xs = X[:Gs].astype(np.float64)
+            refs = refs_all[:Gs].copy(); refs[:10] = True
+            t0 = time.perf_counter()
+            oracle.tuned_identify_degs(Xs, gid, len(lev), 0.01, 1.0, 0.05, refs, args.n_iter, 0, seed)
+            tc = time.perf_counter() - t0
+            out["cpu_baseline"]["tuned"] = {"value": (Gs * (Gs - 1) // 2) * S / tc, "seconds": tc, "genes": Gs, "kind": "port (tuned)",
+                                            "what": "R2 of SURVEY.md §8d: gene-major 16-bit ranks, SIMD compares, popcount tallies on a bit table"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -198,7 +198,7 @@ static int32_t init_state(reo_ctx *c, int32_t nref)
 static int32_t exchange_table(reo_ctx *c)
 {
     c->table_complete = c->world <= 1;
-    if (c->world <= 1) return REO_OK;
+    if (c->world <= 1 && !c->comm) return REO_OK;  // (a communicator of one rank still makes its call: the path stays testable on one GPU)
     const int64_t count = static_cast<int64_t>(c->G) * kPlanes * c->Wp;
     int32_t rc = comm_allreduce_table(c, count);  // comm.hip: REO_OK when it did the exchange, 1 when no communicator is attached
     if (rc < 0) return rc;

@@ -3,12 +3,17 @@
  * Reads a small problem from stdin (text), prints the trace and the statistics; tests/test_gpu_parity.py
  * compiles it with gcc, runs it on the GPU box and compares its output with the ctypes path and the oracle.
  *
+ * argv[1] (optional) selects how the context is made: "single" (default) reo_create; "rccl" reo_create + the
+ * in-library RCCL path as rank 0 of a world of 1 (reo_comm_unique_id, reo_comm_init_rank: reo_build_pairs then ends
+ * with an ncclAllReduce of the class table); "multi" reo_create_multi over all visible GPUs.
+ *
  * stdin:  G S ngroups seed pval_reo pval_deg padj_deg n_iter n_conv
  *         S group ids, G reference flags, then G*S Int64 values column-major
  * stdout: "passes P", P lines "trace DEG NONDEG", G lines of 15 statistics (%.17g) */
 #include <inttypes.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "reo_hip.h"
 
@@ -18,8 +23,9 @@
         if (rc_ != REO_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, reo_last_error()); return 2; } \
     } while (0)
 
-int main(void)
+int main(int argc, char **argv)
 {
+    const char *mode = argc > 1 ? argv[1] : "single";
     long long G, S, ngroups, n_iter, n_conv;
     unsigned long long seed;
     double pval_reo, pval_deg, padj_deg;
@@ -35,7 +41,16 @@ int main(void)
     for (long long e = 0; e < G * S; ++e) { long long v; if (scanf("%lld", &v) != 1) return 1; X[e] = v; }
 
     reo_ctx *ctx = NULL;
-    CHECK(reo_create(&ctx, -1, seed));
+    if (!strcmp(mode, "multi")) {
+        CHECK(reo_create_multi(&ctx, 0, seed));                 /* 0 = every visible GPU */
+    } else {
+        CHECK(reo_create(&ctx, -1, seed));
+        if (!strcmp(mode, "rccl")) {
+            unsigned char id[REO_UNIQUE_ID_BYTES];
+            CHECK(reo_comm_unique_id(id));                      /* rank 0 makes it, every rank receives it */
+            CHECK(reo_comm_init_rank(ctx, id, 0, 1));
+        }
+    }
     CHECK(reo_set_matrix_i64(ctx, X, G, S, G));                 /* Matrix(df_expr), :652 */
     CHECK(reo_set_groups(ctx, gid, S, (int32_t)ngroups));       /* unique(group), :353-357 */
     CHECK(reo_compute_thresholds(ctx, pval_reo));               /* :362 */

@@ -564,6 +564,12 @@ def test_plain_c_client_of_the_abi(pkg, oracle, tmp_path):
     text += " ".join(map(str, np.asfortranarray(X).ravel(order="F"))) + "\n"
     out = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
+    # the same through the in-library RCCL path (a communicator of one rank: reo_build_pairs ends with an ncclAllReduce of
+    # the class table) and through reo_create_multi over the GPUs of this box: identical output
+    for mode in ("rccl", "multi"):
+        alt = subprocess.run([exe, mode], input=text, capture_output=True, text=True, timeout=300)
+        assert alt.returncode == 0, (mode, alt.stderr)
+        assert alt.stdout[alt.stdout.index("passes "):] == out.stdout, mode   # (RCCL prints a version banner first)
     lines = out.stdout.strip().splitlines()
     passes = int(lines[0].split()[1])
     trace = [tuple(int(v) for v in ln.split()[1:]) for ln in lines[1:1 + passes]]
@@ -831,3 +837,32 @@ def test_rank_search_and_transform_index_edges(pkg, oracle, G, S):
     exp, eit, etr = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, 6, 1, seed)
     assert run.iters_run == eit and run.trace == etr
     _check_result(run.result, exp)
+
+
+def test_in_library_rccl_and_multi_context_from_python(pkg, oracle):
+    """reo_comm_init_rank (world of one rank) and reo_create_multi (all GPUs of this box) through ctypes: same results
+    as the plain context; the exchange stage timer shows that the RCCL call was made."""
+    G, S, seed = 2100, 40, 0x5EED0051
+    X = pkg.synth.t1_counts(G, S, seed)
+    group = pkg.synth.groups(S)
+    gid, lev = pkg.encode_groups(group)
+    ref0 = pkg.synth.ref_mask(G, 500, seed)
+
+    def run(ctx):
+        with ctx:
+            ctx.set_profiling(True)
+            ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+            ctx.build_pairs(0)
+            return ctx.get_codes(0, G, 0, G), ctx.identify_degs(ref0, 1.0, 0.05, 6, 1), ctx.timings(), ctx.info()
+
+    code0, (res0, it0, tr0), tm0, info0 = run(pkg.Context(device=0, seed=seed))
+    ctx = pkg.Context(device=0, seed=seed)
+    ctx.comm_init_rank(pkg._ffi.comm_unique_id(), 0, 1)
+    code1, (res1, it1, tr1), tm1, info1 = run(ctx)
+    code2, (res2, it2, tr2), tm2, info2 = run(pkg.Context(seed=seed, n_gpus=0))
+    for code, res, it, tr in ((code1, res1, it1, tr1), (code2, res2, it2, tr2)):
+        assert np.array_equal(code, code0) and np.array_equal(res, res0) and it == it0 and tr == tr0
+    assert info2["tiles_owned"] <= info0["tiles_owned"] == info0["tiles_total"]
+    exp, eit, etr = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, 6, 1, seed)
+    assert it0 == eit and tr0 == etr
+    _check_result(res0, exp)
