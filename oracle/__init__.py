@@ -23,8 +23,8 @@ _f64p = ctypes.POINTER(ctypes.c_double)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "reo_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "reo_oracle.c"), os.path.join(_HERE, "reo_tuned.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -163,6 +163,27 @@ def identify_degs(X, gid, ngroups, pval_reo, pval_deg, padj_deg, ref0, n_iter, n
                                     _p(trace, _i32p))
     if rc:
         raise RuntimeError(f"oracle_identify_degs rc={rc}")
+    return res, iters.value, [tuple(int(v) for v in t) for t in trace[: iters.value]]
+
+
+def tuned_identify_degs(X, gid, ngroups, pval_reo, pval_deg, padj_deg, ref0, n_iter, n_conv, seed):
+    """R2 of SURVEY.md section 8d (oracle/reo_tuned.c): the tuned CPU implementation, two groups; same results as
+    identify_degs.  For the reported CPU baseline only."""
+    X, G, S = _colmajor(X)
+    gid = np.ascontiguousarray(gid, dtype=np.int32)
+    ref0 = np.ascontiguousarray(ref0, dtype=np.uint8)
+    res = np.zeros((G, 15), order="F")
+    iters = ctypes.c_int32(0)
+    trace = np.zeros((max(n_iter, 1), 2), dtype=np.int32)
+    L = lib()
+    L.tuned_identify_degs.restype = ctypes.c_int32
+    L.tuned_identify_degs.argtypes = [_f64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _i32p, ctypes.c_int32, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double, _u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64,
+                                      _f64p, ctypes.POINTER(ctypes.c_int32), _i32p]
+    rc = L.tuned_identify_degs(_p(X, _f64p), G, S, G, _p(gid, _i32p), ngroups, pval_reo, pval_deg, padj_deg, _p(ref0, _u8p),
+                               n_iter, n_conv, seed, _p(res, _f64p), ctypes.byref(iters), _p(trace, _i32p))
+    if rc:
+        raise RuntimeError(f"tuned_identify_degs rc={rc}")
     return res, iters.value, [tuple(int(v) for v in t) for t in trace[: iters.value]]
 
 

@@ -129,3 +129,29 @@ def test_three_group_golden(oracle, golden):
         res, iters, trace = oracle.identify_degs(X, gid, 3, cm["pval_reo"], cm["pval_deg"], cm["padj_deg"],
                                                  np.array(g["ref0"]), cm["n_iter"], cm["n_conv"], cm["seed"], k=cm["k"])
         assert iters == cm["iters_run"] and np.allclose(res, cm["result"], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("kind", ["ties", "ranks", "float_band"])
+def test_tuned_cpu_variant_equals_the_reference_faithful_restatement(oracle, kind):
+    """R2 (oracle/reo_tuned.c: rank transform, SIMD compares, bit-plane table, popcount tallies) against R1
+    (oracle/reo_oracle.c: the reference's loop nest): identical trace, tallies and statistics."""
+    rng = np.random.default_rng({"ties": 1, "ranks": 2, "float_band": 3}[kind])
+    G, S = 333, 43
+    if kind == "ties":
+        X = rng.integers(0, 7, size=(G, S)).astype(np.float64)
+    elif kind == "ranks":
+        X = np.argsort(np.argsort(rng.random((G, S)), axis=0), axis=0).astype(np.float64)
+    else:
+        X = np.round(rng.normal(5, 1.0, size=(G, S)), 1) + rng.choice([0.0, 0.04, 0.099, 0.1], size=(G, S))
+    gid = (rng.permutation(S) % 2).astype(np.int32)
+    gid[0] = 0
+    if gid[1:].min() == 0 and not (gid == 1).any():
+        gid[-1] = 1
+    first1 = int(np.argmax(gid == 1))
+    assert (gid[:first1] == 0).all()          # ids in order of first appearance
+    ref0 = rng.random(G) < 0.4
+    for n_iter, n_conv in ((5, 1), (3, 0)):
+        exp, eit, etr = oracle.identify_degs(X, gid, 2, 0.05, 1.0, 0.05, ref0, n_iter, n_conv, 77)
+        got, it, tr = oracle.tuned_identify_degs(X, gid, 2, 0.05, 1.0, 0.05, ref0, n_iter, n_conv, 77)
+        assert it == eit and tr == etr
+        assert np.array_equal(got, exp, equal_nan=True)
