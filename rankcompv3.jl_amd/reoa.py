@@ -176,8 +176,10 @@ def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: 
     if use_hk_genes == "yes":  # :636-650
         hk = hk_file or os.environ.get("REO_HK_FILE")
         if hk is None:
-            log.info("WARN: no house-keeping gene table given (hk_file= / REO_HK_FILE); it is a data asset of the "
-                     "reference package and is not shipped here. Using the random reference set.")
+            log.warning("no house-keeping gene table given (hk_file= / REO_HK_FILE): the reference reads its bundled "
+                        "hk_gene_file/HK_genes_info.tsv here (src/RankCompV3.jl:546,641-649), a data asset that is not shipped with "
+                        "this build.  Using the random reference set instead (what the reference does when fewer than "
+                        "ref_gene_min house-keeping genes match); pass use_hk_genes=\"no\" to silence this.")
         else:
             if not os.path.isfile(hk):  # :638
                 raise ArgumentError(f"{hk} does not exist or is not a regular file.")
@@ -191,8 +193,15 @@ def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: 
                     log.info("WARN: only %d house-keeping genes are available, we just ignore this.", int(mask.sum()))
                 else:
                     ref = mask
+    # meta_group as the reference writes it (:680): every column of the meta table for the kept samples; after
+    # pseudo-bulking the table is rebuilt from the new profile names (:612-613) and has the two columns only
+    if n_pseudo > 0:
+        meta_out = pd.DataFrame({"Name": sample_names, "Group": sample_groups})
+    else:
+        meta_out = meta.set_index("Name", drop=False).loc[sample_names].reset_index(drop=True)
+        meta_out = meta_out[["Name", "Group"] + [c for c in meta_out.columns if c not in ("Name", "Group")]]
     return {"data": data, "sample_names": sample_names, "sample_groups": sample_groups, "gene_names": gene_names,
-            "g_name": g_name, "ref": ref}
+            "g_name": g_name, "ref": ref, "meta": meta_out}
 
 
 def write_outputs(stem: str, prep: dict, run, work_dir: str = "."):
@@ -214,10 +223,10 @@ def write_outputs(stem: str, prep: dict, run, work_dir: str = "."):
         isint = np.issubdtype(data.dtype, np.integer)
         for i, gname in enumerate(genes):
             f.write(gname + "\t" + "\t".join(str(int(v)) if isint else julia_float(float(v)) for v in data[i]) + "\n")
-    with open(os.path.join(work_dir, f"{stem}_df_meta.tsv"), "w") as f:  # :680
-        f.write("Name\tGroup\n")
-        for n, g in zip(prep["sample_names"], prep["sample_groups"]):
-            f.write(f"{n}\t{g}\n")
+    meta_out = prep.get("meta")
+    if meta_out is None:
+        meta_out = pd.DataFrame({"Name": prep["sample_names"], "Group": prep["sample_groups"]})
+    meta_out.to_csv(os.path.join(work_dir, f"{stem}_df_meta.tsv"), sep="\t", index=False)  # :680, every meta column
     cols = [f"{g_name[0]}_vs_{g_name[1]}"] if mg == 2 else [f"{g}_vs_other" for g in g_name]  # :683
     df = pd.DataFrame({"gene_name": genes})
     for cname, cm in zip(cols, run.comparisons):

@@ -108,3 +108,47 @@ def test_writers(R, pkg, tmp_path):
     assert (tmp_path / "fn_expr_df_expr.tsv").read_text().splitlines()[:2] == ["genename\ts1\ts2", "A\t1\t2"]
     assert (tmp_path / "fn_expr_df_meta.tsv").read_text() == "Name\tGroup\ns1\tx\ns2\ty\n"
     assert (tmp_path / "fn_expr_gene_up_down.tsv").read_text().splitlines()[0] == "gene_name\tx_vs_y"
+
+
+def test_julia_float_vector_table(R):
+    """Byte-level parity of the float printer with the committed vector table (tests/golden/julia_float_vectors.json:
+    Julia's shortest round-trip rule, the edge cases of the fixed / scientific switch, subnormals, signed zero, the
+    tallies written as Float64, and the five numbers the reference itself prints at src/RankCompV3.jl:207-209)."""
+    import json
+    import struct
+    table = json.load(open(os.path.join(GOLD, "julia_float_vectors.json")))
+    assert len(table) >= 35
+    for row in table:
+        v = struct.unpack("<d", struct.pack("<Q", int(row["bits"], 16)))[0]
+        assert R.julia_float(v) == row["text"], (row, R.julia_float(v))
+
+
+def test_result_tsv_bytes_for_the_golden_slice(R, pkg, tmp_path):
+    """The result file of :665-671 for the golden 64-gene slice, byte for byte against the committed fixture
+    (header genename + 15 statistics + up_down, tab-delimited, tallies as Float64)."""
+    import json
+    g = json.load(open(os.path.join(GOLD, "bundled_slice64.json")))
+    res = np.array(g["result"], dtype=np.float64)
+    labels = pkg.label_genes(res, g["pval_deg"], g["padj_deg"])
+    prep = {"g_name": ["group1", "group2"], "gene_names": ["slice%02d" % i for i in range(res.shape[0])],
+            "sample_names": ["s%d" % s for s in range(len(g["gid"]))],
+            "sample_groups": ["group%d" % (1 + v) for v in g["gid"]], "data": np.array(g["X"], dtype=np.int64)}
+
+    class Run:
+        comparisons = [{"k": 0, "result": res, "labels": labels}]
+
+    R.write_outputs("bundled_slice64", prep, Run, str(tmp_path))
+    got = (tmp_path / "bundled_slice64_group1_group2_result.tsv").read_bytes()
+    assert got == open(os.path.join(GOLD, "bundled_slice64_result.tsv"), "rb").read()
+    first = got.split(b"\n")[0].decode()
+    assert first == "genename\tpval\tpadj\tn11\tn12\tn13\tn21\tn22\tn23\tn31\tn32\tn33\tΔ1\tΔ2\tse\tz1\tup_down"
+    meta = (tmp_path / "bundled_slice64_df_meta.tsv").read_text().splitlines()
+    assert meta[0] == "Name\tGroup" and len(meta) == 1 + len(g["gid"])
+
+
+def test_df_meta_keeps_every_meta_column(R, tmp_path):
+    """CSV.write(..., meta_group) at :680 writes the whole meta table, not just Name and Group."""
+    e = _write(tmp_path, "e.tsv", "gene\ts1\ts2\ts3\ts4\nA\t1\t2\t3\t4\nB\t0\t0\t5\t6\n")
+    m = _write(tmp_path, "m.tsv", "sample\tgrp\tbatch\tage\ns1\tx\tb1\t30\ns2\tx\tb2\t41\ns3\ty\tb1\t52\ns4\ty\tb2\t63\n")
+    p = R.prepare(e, m, use_hk_genes="no")
+    assert list(p["meta"].columns) == ["Name", "Group", "batch", "age"] and p["meta"]["age"].tolist() == [30, 41, 52, 63]
