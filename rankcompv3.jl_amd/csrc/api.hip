@@ -161,7 +161,7 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         (rc = c->state.ensure(1)) ||
         (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * (kSortChunk + kSortChunk / 32))) ||
         (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))) ||
-        (rc = c->cand.ensure(2 * 1024)) || (rc = c->hist.ensure((G + 32767) / 32768 * 32768)) || (rc = c->mrank.ensure(G)) || (rc = c->scal.ensure(64)))
+        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure((G + 32767) / 32768 * 32768)) || (rc = c->mrank.ensure(G)) || (rc = c->scal.ensure(64)))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
@@ -257,6 +257,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->device = device;
     c->seed = seed;
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
+    if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return REO_EHIP; }
     *out = c;
@@ -281,7 +282,7 @@ void reo_destroy(reo_ctx *c)
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
+    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -526,7 +527,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // the sorting path -- needed for the first pass, whenever the reference set changed by more genes than a tally
     // update takes, and when a quantile window lost its order statistic -- and the light path.  A batch = two
     // sorting passes (mostly idle launches) + as many light passes as may follow; small problems sort every pass.
-    const bool small = G < light_min_genes();
+    const bool small = G < light_min_genes() || c->light_mode == 0;
     int passes = 0, seen_need_full = 1;
     while (n_iter > 0) {  // :400
         const int remaining = n_iter - passes;
@@ -535,14 +536,23 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         tic(c, 3);
         for (int t = 0; t < nfull; ++t)
             if ((rc = launch_full_pass(c, false))) return rc;
-        for (int t = 0; t < nlight; ++t)
-            if ((rc = launch_light_pass(c))) return rc;
+        if (nlight > 0 && c->light_mode == 2) {
+            if ((rc = launch_light_persistent(c))) return rc;  // runs light passes until the state stops them
+        } else {
+            for (int t = 0; t < nlight; ++t)
+                if ((rc = launch_light_pass(c))) return rc;
+        }
         toc(c);
         REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (getenv("REO_DEBUG_PASSES"))
             fprintf(stderr, "batch: %d sorting + %d light launches, passes %d -> %d, need_full %d, done %d, last_full %d\n", nfull, nlight,
                     passes, c->host_state->passes, c->host_state->need_full, c->host_state->done, c->host_state->last_full);
+        if (c->host_state->fault) {
+            set_error("the persistent iteration kernel gave up at a grid barrier (a workgroup did not arrive within its bound); "
+                      "REO_LIGHT=1 runs the same passes as separate launches");
+            return REO_EHIP;
+        }
         passes = c->host_state->passes;
         seen_need_full = c->host_state->need_full;
         if (c->host_state->done || passes >= n_iter) break;  // :419-422
@@ -563,7 +573,10 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     if (getenv("REO_DEBUG_STAMPS")) {  // diagnostic builds (-DREO_STAMPS): marks of the last light pass, 10 ns units
         unsigned long long st[24];
         REO_HIP_CHECK(hipMemcpy(st, c->scal.p + 32, sizeof st, hipMemcpyDeviceToHost));
-        fprintf(stderr, "stamps kl_pvalues:");
+        fprintf(stderr, "stamps persistent (phase1 B1 phase2 B2 [cut] phase3 B3):");
+        fprintf(stderr, " %lld %lld %lld %lld [%lld] %lld %lld |", (long long)(st[1] - st[0]), (long long)(st[2] - st[1]), (long long)(st[3] - st[2]),
+                (long long)(st[4] - st[3]), (long long)(st[7] - st[4]), (long long)(st[5] - st[4]), (long long)(st[6] - st[5]));
+        fprintf(stderr, " kl_pvalues:");
         for (int k = 1; k <= 6; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[0]));
         fprintf(stderr, "  kl_mask:");
         for (int k = 9; k <= 11; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[8]));

@@ -26,6 +26,7 @@
 //
 // Wave = 64 lanes everywhere; no warp-32 idiom is used.
 #include <algorithm>
+#include <cstddef>
 
 #include "reo_internal.h"
 
@@ -39,6 +40,23 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
+}
+
+// Loads and stores of data that travels between workgroups of ONE launch (the persistent light kernel): relaxed
+// agent-scope atomics = global_load / global_store with sc1, which bypass the CU's L1 and are served coherently
+// across the XCDs' L2s (measured hand-off form: MI355X_MICROARCH.md, "Valid forms"; tools/microbench_gridbar.hip reads
+// every workgroup's value in every round and finds none stale).  COH = false: plain accesses (separate launches).
+template <bool COH, class T>
+__device__ __forceinline__ T ldc(const T *p)
+{
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH, class T>
+__device__ __forceinline__ void stc(T *p, T v)
+{
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 
 // Binomial(n_eq, 1/2) draw standing in for n_eq calls of rand(Bool) in
@@ -582,15 +600,16 @@ __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, cons
 // by the mirror rule (:386) column j of the table is row j with L and H swapped, so gene j entering
 // (leaving) the reference set adds (removes), for every gene i, the class bits found at bit i of ROW j:
 // one contiguous row per changed gene instead of the whole table.  Exact (integer sums).
-__device__ __forceinline__ void delta_gene(const uint32_t *__restrict__ table, int Wp, const uint32_t *__restrict__ list,
-                                           int n, int32_t *__restrict__ raw, int i)
+template <bool COH>
+__device__ __forceinline__ void delta_counts(const uint32_t *__restrict__ table, int Wp, const uint32_t *list, int n, int i, int (&d)[kRaw])
 {
     const int w = i >> 5, sh = i & 31;
-    int d[kRaw] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < kRaw; ++q) d[q] = 0;
     for (int e0 = 0; e0 < n; e0 += 4) {  // four list entries per step: sixteen independent loads in flight
         uint32_t ent[4], w0[4], w1[4], w2[4], w3[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ent[u] = list[min(e0 + u, n - 1)];  // wave-uniform
+        for (int u = 0; u < 4; ++u) ent[u] = ldc<COH>(list + min(e0 + u, n - 1));  // wave-uniform
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t *row = table + static_cast<size_t>(ent[u] >> 1) * kPlanes * Wp + w;
@@ -607,6 +626,13 @@ __device__ __forceinline__ void delta_gene(const uint32_t *__restrict__ table, i
             d[4] += sgn * (cl & tl); d[5] += sgn * (cl & th); d[6] += sgn * (ch & tl); d[7] += sgn * (ch & th);
         }
     }
+}
+
+__device__ __forceinline__ void delta_gene(const uint32_t *__restrict__ table, int Wp, const uint32_t *__restrict__ list,
+                                           int n, int32_t *__restrict__ raw, int i)
+{
+    int d[kRaw];
+    delta_counts<false>(table, Wp, list, n, i, d);
     int4 *o = reinterpret_cast<int4 *>(raw + static_cast<size_t>(i) * kRaw);
     int4 a = o[0], b = o[1];
     a.x += d[0]; a.y += d[1]; a.z += d[2]; a.w += d[3];
@@ -1198,6 +1224,88 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// the BH cut k* = max{r in 1..G : H(r) >= r}, H = running sum of the histogram (bin b = rank b + 1), found by every
+// workgroup for itself.  Tiles of 2048 bins (eight consecutive bins per thread), sixteen tiles per round so that their
+// loads are in flight together and their wave scans interleave; two barriers per round.  The histogram is padded
+// with zero bins to whole rounds.
+// rmax: H never exceeds the number of genes with a finite rank, so no r above that count can qualify: only the
+// tiles that reach up to rank min(G, rmax) are read (a few thousand bins instead of G).
+template <bool COH>
+__device__ __forceinline__ int bh_cut(const int32_t *hist, int G, int rmax)
+{
+    __shared__ __attribute__((aligned(16))) int wsum[16][4];
+    __shared__ int wbest[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntile = (min(G, max(rmax, 1)) + 2047) / 2048;
+    int best = 0, carry = 0;
+    for (int q0 = 0; q0 < ntile; q0 += 16) {
+        int hv[16][8];
+        int s[16], inc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const size_t o = (static_cast<size_t>(q0 + e) * 256 + threadIdx.x) * 8;
+            if (q0 + e >= ntile) {  // workgroup-uniform
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hv[e][u] = 0;
+            } else if (COH) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(hist + o) + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hv[e][2 * u] = static_cast<int>(w & 0xFFFFFFFFull); hv[e][2 * u + 1] = static_cast<int>(w >> 32);
+                }
+            } else {
+                const int4 h0 = reinterpret_cast<const int4 *>(hist + o)[0], h1 = reinterpret_cast<const int4 *>(hist + o)[1];
+                hv[e][0] = h0.x; hv[e][1] = h0.y; hv[e][2] = h0.z; hv[e][3] = h0.w; hv[e][4] = h1.x; hv[e][5] = h1.y; hv[e][6] = h1.z; hv[e][7] = h1.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = ((hv[e][0] + hv[e][1]) + (hv[e][2] + hv[e][3])) + ((hv[e][4] + hv[e][5]) + (hv[e][6] + hv[e][7]));
+            inc[e] = s[e];
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const int u = __shfl_up(inc[e], o, 64); if (lane >= o) inc[e] += u; }
+        if (lane == 63)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wsum[e][wave] = inc[e];
+        __syncthreads();
+        int4 ws[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ws[e] = *reinterpret_cast<const int4 *>(wsum[e]);  // sixteen independent 16-byte reads
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int run = carry + inc[e] - s[e] + (wave > 0 ? ws[e].x : 0) + (wave > 1 ? ws[e].y : 0) + (wave > 2 ? ws[e].z : 0);
+            const int r0 = ((q0 + e) * 256 + threadIdx.x) * 8 + 1;  // rank of the first of this thread's eight bins
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { run += hv[e][u]; if (r0 + u <= G && run >= r0 + u) best = max(best, r0 + u); }
+            carry += ws[e].x + ws[e].y + ws[e].z + ws[e].w;
+        }
+        __syncthreads();  // wsum is read by everyone before the next round overwrites it
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(best, o, 64); best = u > best ? u : best; }
+    if (lane == 0) wbest[wave] = best;
+    __syncthreads();
+    const int k = max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
+    __syncthreads();
+    return k;
+}
+
+// m = the smallest rank r at which the step-up rule's p (n/r) is within padj_deg (n + 1: none)
+__device__ __forceinline__ int bh_rank(double p, int G, double al)
+{
+    const double Gd = static_cast<double>(G);
+    auto within = [&](int r) { return p * (Gd / static_cast<double>(r)) <= al; };
+    if (!within(G)) return G + 1;
+    const double est = ceil(p * Gd / al);
+    int m = est < 1.0 ? 1 : (est > Gd ? G : static_cast<int>(est));
+    while (m > 1 && within(m - 1)) --m;
+    while (!within(m)) ++m;  // within(G) holds
+    return m;
+}
+
 // light pass, kernel 1: tallies from the changed rows, delta1, window bookkeeping
 __global__ __launch_bounds__(256) void kl_derive(IterArgs a)
 {
@@ -1323,17 +1431,7 @@ __global__ __launch_bounds__(256) void kl_pvalues(IterArgs a)
     const bool live = i < G;
     const double p = live ? normal_p(a.result[11 * static_cast<size_t>(G) + i], se) : 1.0;
     if (live) a.result[i] = p;
-    // m = the smallest rank r at which the step-up rule's p (n/r) is within padj_deg (n + 1: none)
-    const double Gd = static_cast<double>(G), al = a.padj_deg;
-    auto within = [&](int r) { return p * (Gd / static_cast<double>(r)) <= al; };
-    int m;
-    if (!live || !within(G)) m = G + 1;
-    else {
-        const double est = ceil(p * Gd / al);
-        m = est < 1.0 ? 1 : (est > Gd ? G : static_cast<int>(est));
-        while (m > 1 && within(m - 1)) --m;
-        while (!within(m)) ++m;  // within(G) holds
-    }
+    const int m = live ? bh_rank(p, G, a.padj_deg) : G + 1;
     STAMP(a, 5);
     if (live) a.mrank[i] = m;
     // bin m - 1.  Strongly significant genes all have m = 1: one atomic per wave for that bin, not one per gene
@@ -1352,55 +1450,8 @@ __global__ __launch_bounds__(256) void kl_mask(IterArgs a)
     int t;
     if (!light_pass_active(a, t)) return;
     const int G = a.G;
-    // bin b = rank b + 1.  Tiles of 2048 bins (eight consecutive bins = two int4 per thread), sixteen tiles per round so
-    // that their loads are in flight together and their wave scans interleave; two barriers per round.
     STAMP(a, 8);
-    __shared__ __attribute__((aligned(16))) int wsum[16][4];
-    __shared__ int wbest[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int4 *hist4 = reinterpret_cast<const int4 *>(a.hist);
-    const int ntile = (G + 2047) / 2048;
-    int best = 0, carry = 0;
-    for (int q0 = 0; q0 < ntile; q0 += 16) {
-        int4 h[16][2];
-        int s[16], inc[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {  // unconditional: the histogram is padded with zero bins to whole rounds of 16 tiles
-            h[e][0] = hist4[(q0 + e) * 512 + 2 * threadIdx.x];
-            h[e][1] = hist4[(q0 + e) * 512 + 2 * threadIdx.x + 1];
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s[e] = (h[e][0].x + h[e][0].y + h[e][0].z + h[e][0].w) + (h[e][1].x + h[e][1].y + h[e][1].z + h[e][1].w);
-            inc[e] = s[e];
-        }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { const int u = __shfl_up(inc[e], o, 64); if (lane >= o) inc[e] += u; }
-        if (lane == 63)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) wsum[e][wave] = inc[e];
-        __syncthreads();
-        int4 ws[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) ws[e] = *reinterpret_cast<const int4 *>(wsum[e]);  // sixteen independent 16-byte reads
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            int run = carry + inc[e] - s[e] + (wave > 0 ? ws[e].x : 0) + (wave > 1 ? ws[e].y : 0) + (wave > 2 ? ws[e].z : 0);
-            const int r0 = ((q0 + e) * 256 + threadIdx.x) * 8 + 1;  // rank of the first of this thread's eight bins
-            const int hv[8] = {h[e][0].x, h[e][0].y, h[e][0].z, h[e][0].w, h[e][1].x, h[e][1].y, h[e][1].z, h[e][1].w};
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { run += hv[u]; if (r0 + u <= G && run >= r0 + u) best = max(best, r0 + u); }
-            carry += ws[e].x + ws[e].y + ws[e].z + ws[e].w;
-        }
-        __syncthreads();  // wsum is read by everyone before the next round overwrites it
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(best, o, 64); best = u > best ? u : best; }
-    if (lane == 0) wbest[wave] = best;
-    __syncthreads();
-    const int kstar = max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
+    const int kstar = bh_cut<false>(a.hist, G, G);
     STAMP(a, 9);
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool ind = false;
@@ -1412,6 +1463,255 @@ __global__ __launch_bounds__(256) void kl_mask(IterArgs a)
     a.st->need_full = over;
     a.scal[1] = a.scal[9]; a.scal[2] = a.scal[10]; a.scal[3] = a.scal[11]; a.scal[4] = a.scal[12];
     a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0;
+}
+
+
+// ---------------------------------------------------------------------------
+// The light passes as ONE persistent launch.  Thread i owns gene i for the whole launch: its tally counters, mask bit,
+// delta1, p-value and BH rank stay in registers from pass to pass, and the three global dependencies of a pass (all
+// delta1 -> se; all p -> the BH cut; all mask bits -> the change list and the counts of :418) are grid barriers instead
+// of kernel boundaries.  ceil(G / 256) <= 256 workgroups of 256 threads: all resident on the 256 CUs.
+//
+// Grid barrier: one monotonic counter (zeroed by the host before the launch); every wave drains its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets, lane 0 adds one and polls with sc1 loads until every workgroup of the round
+// has arrived, the workgroup meets again.  No fences: everything that crosses workgroups is stored and loaded through
+// ldc / stc (sc1) or is an agent-scope atomic; measured 2.3 us per round with 80 workgroups against 4.6 us with a
+// release / acquire fence pair (tools/microbench_gridbar.hip).  Every spin is bounded (about 0.5 s): on expiry the
+// workgroup raises st->fault and leaves, and so do the others at their next barrier, so the grid always drains.
+__device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned nwg, unsigned &gen, int *fault)
+{
+    __shared__ int ok_s;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++gen;
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = gen * nwg;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        int ok = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull || __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+// The two order statistics and the slice's moments from the window members and the block partials, by every workgroup
+// for itself (wave 0 sorts window A, wave 1 window B, <= 64 values each).  Returns false when a window lost its order
+// statistic.  sel: LDS scratch [2][4].
+template <bool COH>
+__device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand, int npart, int below_a, int below_b, int cnt_a, int cnt_b,
+                                          double (*sel)[4], double *red, double &se, double &va, double &vb)
+{
+    const int ia = a.a0 - below_a, ib = a.b0 - below_b;  // positions of the order statistics inside the sorted windows
+    if (!(cnt_a <= kCandMax && cnt_b <= kCandMax && ia >= 0 && ia < cnt_a && ib >= 0 && ib < cnt_b)) return false;  // workgroup-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < 2) {
+        const int cnt = wave ? cnt_b : cnt_a, pos = wave ? ib : ia;
+        const double x = sort64(lane < cnt ? ldc<COH>(cand + wave * kCandMax + lane) : INFINITY);
+        const bool in = wave ? lane <= pos : (lane >= pos && lane < cnt);
+        const double n = static_cast<double>(wave ? pos + 1 : cnt - pos);
+        const double mean = wave_sum(in ? x : 0.0) / n;
+        const double q = wave_sum(in ? (x - mean) * (x - mean) : 0.0);
+        const double stat = __shfl(x, pos, 64);
+        if (lane == 0) { sel[wave][0] = stat; sel[wave][1] = n; sel[wave][2] = mean; sel[wave][3] = q; }
+    }
+    // Chan's combination of the block partials (the same bits in every thread of every workgroup; one partial per
+    // thread, loaded once); its barriers also publish sel
+    double pn = 0.0, pm = 0.0, pq = 0.0;
+    if (static_cast<int>(threadIdx.x) < npart) { pn = ldc<COH>(a.part + 3 * threadIdx.x); pm = ldc<COH>(a.part + 3 * threadIdx.x + 1); pq = ldc<COH>(a.part + 3 * threadIdx.x + 2); }
+    double n0 = block_sum_256(pn, red);
+    double mean0 = block_sum_256(pn * pm, red) / n0;
+    double q0 = block_sum_256(pq + pn * (pm - mean0) * (pm - mean0), red);
+    va = sel[0][0]; vb = sel[1][0];
+    const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
+    __syncthreads();  // sel may be rewritten by the next pass
+    if (!(n0 > 0.0)) { mean0 = 0.0; q0 = 0.0; }  // no value between the windows: the mean above divided by zero
+    const double n = n0 + n1 + n2;
+    const double mean = (n0 * mean0 + n1 * mean1 + n2 * mean2) / n;
+    const double m2 = (q0 + n0 * (mean0 - mean) * (mean0 - mean)) + (q1 + n1 * (mean1 - mean) * (mean1 - mean)) +
+                      (q2 + n2 * (mean2 - mean) * (mean2 - mean));
+    se = sqrt(m2 / (n - 1.0));
+    return static_cast<int>(n) == a.b0 - a.a0 + 1;
+}
+
+__global__ __launch_bounds__(256) void kl_persist(IterArgs a, unsigned *bar)
+{
+    IterState *st = a.st;
+    // the state as the previous launch left it (a kernel boundary: plain loads)
+    int t = st->passes, nref = st->nref, nref_prev = st->nref_prev;
+    if (st->done || t >= a.n_iter || st->need_full || st->fault) return;  // the same in every workgroup
+    const int G = a.G, Gp = a.Gp;
+    const unsigned nwg = gridDim.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double red[256];
+    __shared__ double sel[2][4];
+    __shared__ int wcnt[4][3];
+    // this thread's gene: tally counters, mask bit; the quantile windows and their widths
+    int rw[kRaw] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool inref = false;
+    if (live) {
+        const int4 r0 = reinterpret_cast<const int4 *>(a.raw)[2 * i], r1 = reinterpret_cast<const int4 *>(a.raw)[2 * i + 1];
+        rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w; rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
+        inref = a.refbytes[t & 1][i] != 0;
+    }
+    double wa_lo = a.scal[1], wa_hi = a.scal[2], wb_lo = a.scal[3], wb_hi = a.scal[4];
+    const double da_lo = a.scal[5], da_hi = a.scal[6], db_lo = a.scal[7], db_hi = a.scal[8];
+    double d1 = 0.0, p = 1.0;
+    unsigned gen = 0;
+    int executed = 0, done = 0, need_full = 0, raw_pass = t - 1;
+    bool alive = true;
+    while (alive) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        STAMP(a, 0);
+        // ---------------- phase 1: tallies from the changed rows, delta1, window bookkeeping
+        const int n = ldc<true>(&st->delta_cnt[cur]);
+        bool inner = false, inA = false, inB = false, belowA = false, belowB = false;
+        if (live) {
+            int d[kRaw];
+            delta_counts<true>(a.table, a.Wp, a.delta_list + static_cast<size_t>(cur) * Gp, n, i, d);
+#pragma unroll
+            for (int q = 0; q < kRaw; ++q) rw[q] += d[q];
+            int32_t c[9];
+            const int total = nref - (inref ? 1 : 0);
+            c[0] = rw[4]; c[2] = rw[5]; c[6] = rw[6]; c[8] = rw[7];
+            c[1] = rw[0] - rw[4] - rw[5]; c[7] = rw[1] - rw[6] - rw[7]; c[3] = rw[2] - rw[4] - rw[6]; c[5] = rw[3] - rw[5] - rw[7];
+            c[4] = total - (rw[0] + rw[1] + c[3] + c[5]);
+            double o[5];
+            mccullagh3<false>(c, o);
+            d1 = o[1];
+            stc<true>(a.hist + i, 0);
+            belowA = d1 < wa_lo; inA = !belowA && d1 <= wa_hi;
+            belowB = d1 < wb_lo; inB = !belowB && d1 <= wb_hi;
+            inner = d1 > wa_hi && d1 < wb_lo;
+        }
+        raw_pass = t;
+        {
+            const double nb = block_sum_256(inner ? 1.0 : 0.0, red);
+            const double sum = block_sum_256(inner ? d1 : 0.0, red);
+            const double mean = nb > 0.0 ? sum / nb : 0.0;
+            const double m2 = block_sum_256(inner ? (d1 - mean) * (d1 - mean) : 0.0, red);
+            if (threadIdx.x == 0) { stc<true>(a.part + 3 * blockIdx.x, nb); stc<true>(a.part + 3 * blockIdx.x + 1, mean); stc<true>(a.part + 3 * blockIdx.x + 2, m2); }
+        }
+        double *cand = a.cand + static_cast<size_t>(cur) * 2 * kCandMax;
+        {
+            const unsigned long long mA = __ballot(inA), mB = __ballot(inB), bA = __ballot(belowA), bB = __ballot(belowB);
+            int baseA = 0, baseB = 0;
+            if (lane == 0) {
+                if (mA) baseA = atomicAdd(&st->pz_cnt[cur][0], __popcll(mA));
+                if (mB) baseB = atomicAdd(&st->pz_cnt[cur][1], __popcll(mB));
+                wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
+            }
+            baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
+            const unsigned long long lt = (1ULL << lane) - 1ULL;
+            if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) stc<true>(cand + at, d1); }
+            if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) stc<true>(cand + kCandMax + at, d1); }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
+                if (ba) atomicAdd(&st->pz_below[cur][0], ba);
+                if (bb) atomicAdd(&st->pz_below[cur][1], bb);
+            }
+        }
+        STAMP(a, 1);
+        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
+        STAMP(a, 2);
+        // ---------------- phase 2: se, p-values, BH ranks and their histogram
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // every workgroup is past its last look at the other parity's counters and at the change count of the pass before
+            stc<true>(&st->delta_cnt[nxt], 0);
+            stc<true>(&st->pz_cnt[nxt][0], 0); stc<true>(&st->pz_cnt[nxt][1], 0);
+            stc<true>(&st->pz_below[nxt][0], 0); stc<true>(&st->pz_below[nxt][1], 0);
+            stc<true>(&st->pz_nn[nxt], 0); stc<true>(&st->pz_sig[nxt], 0);
+        }
+        double se, va, vb;
+        const bool ok = slice_std<true>(a, cand, static_cast<int>(nwg), ldc<true>(&st->pz_below[cur][0]), ldc<true>(&st->pz_below[cur][1]), ldc<true>(&st->pz_cnt[cur][0]),
+                                        ldc<true>(&st->pz_cnt[cur][1]), sel, red, se, va, vb) && true;
+        const bool wok = ok && (va + da_hi < vb - db_lo);
+        if (!wok) { need_full = 1; break; }  // the same in every workgroup: this pass runs on the sorting path (the tallies are up to date)
+        int m = G + 1;
+        if (live) {
+            p = normal_p(d1, se);
+            m = bh_rank(p, G, a.padj_deg);
+        }
+        {
+            const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
+            if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&a.hist[0], __popcll(first)); }
+            else if (m <= G) atomicAdd(&a.hist[m - 1], 1);
+            if (lane == 0 && finite) atomicAdd(&st->pz_sig[cur], __popcll(finite));  // bounds the scan for the cut
+        }
+        STAMP(a, 3);
+        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
+        STAMP(a, 4);
+        // ---------------- phase 3: the BH cut, inds (:417), mask, change list
+        const int kstar = bh_cut<true>(a.hist, G, ldc<true>(&st->pz_sig[cur]));
+        STAMP(a, 7);
+        const bool ind = live && !(p <= a.pval_deg && m <= kstar);
+        if (i < Gp) a.refbytes[nxt][i] = ind ? 1 : 0;  // (read again only by this thread, and by later launches)
+        {
+            const bool changed = live && ind != inref;
+            const unsigned long long cm = __ballot(changed);
+            if (cm) {
+                int basepos = 0;
+                if (lane == 0) basepos = atomicAdd(&st->delta_cnt[nxt], __popcll(cm));
+                basepos = __shfl(basepos, 0, 64);
+                const int at = basepos + __popcll(cm & ((1ULL << lane) - 1ULL));
+                if (changed && at < kDeltaMax) stc<true>(a.delta_list + static_cast<size_t>(nxt) * Gp + at, (static_cast<uint32_t>(i) << 1) | (ind ? 1u : 0u));
+            }
+            const unsigned long long mk = __ballot(ind);
+            if (lane == 0) {
+                if (i < Gp) { a.refbits[nxt][i >> 5] = static_cast<uint32_t>(mk); a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(mk >> 32); }
+                wcnt[wave][2] = __popcll(mk);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int nn_blk = wcnt[0][2] + wcnt[1][2] + wcnt[2][2] + wcnt[3][2];
+                if (nn_blk) atomicAdd(&st->pz_nn[cur], nn_blk);
+            }
+        }
+        STAMP(a, 5);
+        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
+        STAMP(a, 6);
+        // ---------------- the loop control of :418-424, by every workgroup for itself
+        const int nn = ldc<true>(&st->pz_nn[cur]);
+        const int chg = ldc<true>(&st->delta_cnt[nxt]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.trace[2 * t] = G - nn; a.trace[2 * t + 1] = nn;
+            // the quantile windows of the next light pass: the same widths around this pass's quantiles
+            stc<true>(a.scal + 0, se); stc<true>(a.scal + 1, va - da_lo); stc<true>(a.scal + 2, va + da_hi); stc<true>(a.scal + 3, vb - db_lo); stc<true>(a.scal + 4, vb + db_hi);
+        }
+        wa_lo = va - da_lo; wa_hi = va + da_hi; wb_lo = vb - db_lo; wb_hi = vb + db_hi;
+        nref_prev = nref;
+        const int diff = nref - nn;
+        if ((diff < 0 ? -diff : diff) < a.n_conv) done = 1;  // :419-422
+        else nref = nn;                                       // :423-424
+        inref = ind;
+        ++t; ++executed;
+        if (chg > kDeltaMax) need_full = 1;
+        if (done || t >= a.n_iter || need_full) break;
+    }
+    // ---------------- hand the state back to the launches that follow
+    if (live) {
+        reinterpret_cast<int4 *>(a.raw)[2 * i] = make_int4(rw[0], rw[1], rw[2], rw[3]);
+        reinterpret_cast<int4 *>(a.raw)[2 * i + 1] = make_int4(rw[4], rw[5], rw[6], rw[7]);
+        a.result[11 * static_cast<size_t>(G) + i] = d1;
+        a.result[i] = p;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->passes = t; st->nref = nref; st->nref_prev = nref_prev; st->done = done; st->need_full = need_full;
+        st->i_iter = t - (done ? 1 : 0);
+        st->raw_pass = raw_pass;
+        if (executed) st->last_full = 0;
+    }
 }
 
 }  // namespace
@@ -1610,6 +1910,18 @@ int32_t launch_light_pass(reo_ctx *c)
     kl_derive<<<nb, 256, 0, c->stream>>>(a);
     kl_pvalues<<<nb, 256, 0, c->stream>>>(a);
     kl_mask<<<c->Gp / 256, 256, 0, c->stream>>>(a);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+// Light passes until the state stops them (convergence, n_iter, a pass that needs the sorting path): one persistent launch.
+int32_t launch_light_persistent(reo_ctx *c)
+{
+    const IterArgs a = iter_args(c, 0);
+    const unsigned nwg = static_cast<unsigned>(a.Gp / 256);  // every mask byte, padding included, has its thread
+    REO_HIP_CHECK(hipMemsetAsync(c->gridbar.p, 0, sizeof(unsigned), c->stream));
+    REO_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char *>(c->state.p) + offsetof(IterState, pz_cnt), 0, sizeof(int32_t) * 12, c->stream));
+    kl_persist<<<nwg, 256, 0, c->stream>>>(a, c->gridbar.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

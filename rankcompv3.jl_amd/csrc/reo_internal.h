@@ -40,6 +40,9 @@ struct IterState {
     int32_t tick_a, tick_b;                     // finished workgroups of kl_derive / kl_pvalues
     int32_t below_a, below_b, cnt_a, cnt_b;     // light pass: values below / inside the two quantile windows
     int32_t kstar;     // light pass: the Benjamini-Hochberg cut
+    int32_t fault;     // the persistent light kernel gave up at a grid barrier (bounded spin expired)
+    // persistent light kernel: the same counters by pass parity (reset one pass ahead, between barriers)
+    int32_t pz_cnt[2][2], pz_below[2][2], pz_nn[2], pz_sig[2];
     int32_t pad[3];
 };
 
@@ -155,7 +158,9 @@ struct reo_ctx {
     reo::DevBuf<reo::IterState> state;  // [1]
     reo::DevBuf<int32_t> trace;         // [n_iter][2]
     reo::DevBuf<int32_t> modes;         // [K2 launches] 1 = the launch scanned the whole table, 0 = incremental update or skipped
-    reo::DevBuf<double> cand;           // [2][1024] light passes: values inside the quantile windows
+    reo::DevBuf<double> cand;           // [2 parities][2 windows][64] light passes: values inside the quantile windows
+    reo::DevBuf<unsigned> gridbar;      // [1] arrival counter of the persistent light kernel's grid barrier
+    int light_mode = 2;                 // 0 sorting passes only, 1 light passes as three launches each, 2 persistent (REO_LIGHT)
     reo::DevBuf<int32_t> hist, mrank;   // [G padded to whole 1024-bin tiles], [G] light passes: histogram of the BH ranks, the ranks
     // parameters of the running reo_identify_degs call (kernels.hip, iter_args)
     double it_pval_deg = 1.0, it_padj_deg = 0.05;
@@ -186,6 +191,7 @@ int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
 int32_t launch_tally(reo_ctx *c, int nref);
 int32_t launch_full_pass(reo_ctx *c, bool replay);
 int32_t launch_light_pass(reo_ctx *c);
+int32_t launch_light_persistent(reo_ctx *c);
 int32_t light_min_genes();
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
 
