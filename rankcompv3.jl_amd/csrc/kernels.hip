@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
         a.scal[5] = va - wa_lo; a.scal[6] = wa_hi - va; a.scal[7] = vb - wb_lo; a.scal[8] = wb_hi - vb;
     }
     a.st->need_full = (over || !ok) ? 1 : 0;
-    a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0;  // a light pass may have failed half-way
+    a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0; a.st->sig_cnt = 0;  // a light pass may have failed half-way
 }
 
 // ---------------------------------------------------------------------------
@@ -1263,10 +1263,12 @@ __device__ __forceinline__ int bh_cut(const int32_t *hist, int G, int rmax)
             s[e] = ((hv[e][0] + hv[e][1]) + (hv[e][2] + hv[e][3])) + ((hv[e][4] + hv[e][5]) + (hv[e][6] + hv[e][7]));
             inc[e] = s[e];
         }
+        const int nt = min(16, ntile - q0);  // workgroup-uniform: tiles of this round that hold anything
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { const int u = __shfl_up(inc[e], o, 64); if (lane >= o) inc[e] += u; }
+            for (int e = 0; e < 16; ++e)
+                if (e < nt) { const int u = __shfl_up(inc[e], o, 64); if (lane >= o) inc[e] += u; }
         if (lane == 63)
 #pragma unroll
             for (int e = 0; e < 16; ++e) wsum[e][wave] = inc[e];
@@ -1304,6 +1306,45 @@ __device__ __forceinline__ int bh_rank(double p, int G, double al)
     while (m > 1 && within(m - 1)) --m;
     while (!within(m)) ++m;  // within(G) holds
     return m;
+}
+
+// The two order statistics and the slice's moments from the window members and the block partials, by every workgroup
+// for itself (wave 0 sorts window A, wave 1 window B, <= 64 values each).  Returns false when a window lost its order
+// statistic.  sel: LDS scratch [2][4].
+template <bool COH>
+__device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand, int npart, int below_a, int below_b, int cnt_a, int cnt_b,
+                                          double (*sel)[4], double *red, double &se, double &va, double &vb)
+{
+    const int ia = a.a0 - below_a, ib = a.b0 - below_b;  // positions of the order statistics inside the sorted windows
+    if (!(cnt_a <= kCandMax && cnt_b <= kCandMax && ia >= 0 && ia < cnt_a && ib >= 0 && ib < cnt_b)) return false;  // workgroup-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < 2) {
+        const int cnt = wave ? cnt_b : cnt_a, pos = wave ? ib : ia;
+        const double x = sort64(lane < cnt ? ldc<COH>(cand + wave * kCandMax + lane) : INFINITY);
+        const bool in = wave ? lane <= pos : (lane >= pos && lane < cnt);
+        const double n = static_cast<double>(wave ? pos + 1 : cnt - pos);
+        const double mean = wave_sum(in ? x : 0.0) / n;
+        const double q = wave_sum(in ? (x - mean) * (x - mean) : 0.0);
+        const double stat = __shfl(x, pos, 64);
+        if (lane == 0) { sel[wave][0] = stat; sel[wave][1] = n; sel[wave][2] = mean; sel[wave][3] = q; }
+    }
+    // Chan's combination of the block partials (the same bits in every thread of every workgroup; one partial per
+    // thread, loaded once); its barriers also publish sel
+    double pn = 0.0, pm = 0.0, pq = 0.0;
+    if (static_cast<int>(threadIdx.x) < npart) { pn = ldc<COH>(a.part + 3 * threadIdx.x); pm = ldc<COH>(a.part + 3 * threadIdx.x + 1); pq = ldc<COH>(a.part + 3 * threadIdx.x + 2); }
+    double n0 = block_sum_256(pn, red);
+    double mean0 = block_sum_256(pn * pm, red) / n0;
+    double q0 = block_sum_256(pq + pn * (pm - mean0) * (pm - mean0), red);
+    va = sel[0][0]; vb = sel[1][0];
+    const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
+    __syncthreads();  // sel may be rewritten by the next pass
+    if (!(n0 > 0.0)) { mean0 = 0.0; q0 = 0.0; }  // no value between the windows: the mean above divided by zero
+    const double n = n0 + n1 + n2;
+    const double mean = (n0 * mean0 + n1 * mean1 + n2 * mean2) / n;
+    const double m2 = (q0 + n0 * (mean0 - mean) * (mean0 - mean)) + (q1 + n1 * (mean1 - mean) * (mean1 - mean)) +
+                      (q2 + n2 * (mean2 - mean) * (mean2 - mean));
+    se = sqrt(m2 / (n - 1.0));
+    return static_cast<int>(n) == a.b0 - a.a0 + 1;
 }
 
 // light pass, kernel 1: tallies from the changed rows, delta1, window bookkeeping
@@ -1381,40 +1422,9 @@ __global__ __launch_bounds__(256) void kl_pvalues(IterArgs a)
     const int G = a.G;
     __shared__ double red[256];
     __shared__ double sel[2][4];  // per window: order statistic, count, mean, M2 of its members inside the slice
-    STAMP(a, 0);
-    const int below_a = st->below_a, below_b = st->below_b, cnt_a = st->cnt_a, cnt_b = st->cnt_b;
-    const int ia = a.a0 - below_a, ib = a.b0 - below_b;  // positions of the order statistics inside the sorted windows
-    bool ok = cnt_a <= kCandMax && cnt_b <= kCandMax && ia >= 0 && ia < cnt_a && ib >= 0 && ib < cnt_b;
     double se = 0.0, va = 0.0, vb = 0.0;
-    if (ok) {  // workgroup-uniform
-        // wave 0 sorts window A, wave 1 window B (<= 64 values each, one per lane); the slice takes window A from its
-        // order statistic on and window B up to its order statistic
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (wave < 2) {
-            const int cnt = wave ? cnt_b : cnt_a, pos = wave ? ib : ia;
-            const double x = sort64(lane < cnt ? a.cand[wave * kCandMax + lane] : INFINITY);
-            const bool in = wave ? lane <= pos : (lane >= pos && lane < cnt);
-            const double n = static_cast<double>(wave ? pos + 1 : cnt - pos);
-            const double mean = wave_sum(in ? x : 0.0) / n;
-            const double q = wave_sum(in ? (x - mean) * (x - mean) : 0.0);
-            const double stat = __shfl(x, pos, 64);
-            if (lane == 0) { sel[wave][0] = stat; sel[wave][1] = n; sel[wave][2] = mean; sel[wave][3] = q; }
-        }
-        STAMP(a, 1);
-        double n0, mean0, q0;
-        combine_moments(a.part, (G + 255) / 256, red, n0, mean0, q0);  // (its barriers also publish sel)
-        STAMP(a, 2);
-        va = sel[0][0]; vb = sel[1][0];
-        const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
-        STAMP(a, 3);
-        if (!(n0 > 0.0)) { mean0 = 0.0; q0 = 0.0; }  // no value between the windows: combine_moments divided by zero
-        const double n = n0 + n1 + n2;
-        const double mean = (n0 * mean0 + n1 * mean1 + n2 * mean2) / n;
-        const double m2 = (q0 + n0 * (mean0 - mean) * (mean0 - mean)) + (q1 + n1 * (mean1 - mean) * (mean1 - mean)) +
-                          (q2 + n2 * (mean2 - mean) * (mean2 - mean));
-        se = sqrt(m2 / (n - 1.0));
-        ok = static_cast<int>(n) == a.b0 - a.a0 + 1 && (va + a.scal[6] < vb - a.scal[7]);  // (holds for G >= kLightMinG)
-    }
+    bool ok = slice_std<false>(a, a.cand, (G + 255) / 256, st->below_a, st->below_b, st->cnt_a, st->cnt_b, sel, red, se, va, vb);
+    ok = ok && (va + a.scal[6] < vb - a.scal[7]);  // (holds for G >= kLightMinG)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (ok) {
             a.scal[0] = se;
@@ -1436,9 +1446,10 @@ __global__ __launch_bounds__(256) void kl_pvalues(IterArgs a)
     if (live) a.mrank[i] = m;
     // bin m - 1.  Strongly significant genes all have m = 1: one atomic per wave for that bin, not one per gene
     // (thousands of adds to one word serialise at about 12 ns each)
-    const unsigned long long first = __ballot(m == 1);
+    const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
     if (m == 1) { if ((threadIdx.x & 63) == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&a.hist[0], __popcll(first)); }
     else if (m <= G) atomicAdd(&a.hist[m - 1], 1);
+    if ((threadIdx.x & 63) == 0 && finite) atomicAdd(&st->sig_cnt, __popcll(finite));  // bounds kl_mask's scan for the cut
     STAMP(a, 6);
 }
 
@@ -1451,7 +1462,7 @@ __global__ __launch_bounds__(256) void kl_mask(IterArgs a)
     if (!light_pass_active(a, t)) return;
     const int G = a.G;
     STAMP(a, 8);
-    const int kstar = bh_cut<false>(a.hist, G, G);
+    const int kstar = bh_cut<false>(a.hist, G, a.st->sig_cnt);
     STAMP(a, 9);
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool ind = false;
@@ -1462,7 +1473,7 @@ __global__ __launch_bounds__(256) void kl_mask(IterArgs a)
     if (over < 0) return;
     a.st->need_full = over;
     a.scal[1] = a.scal[9]; a.scal[2] = a.scal[10]; a.scal[3] = a.scal[11]; a.scal[4] = a.scal[12];
-    a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0;
+    a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0; a.st->sig_cnt = 0;
 }
 
 
@@ -1501,45 +1512,6 @@ __device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned nwg, unsign
     }
     __syncthreads();
     return ok_s != 0;
-}
-
-// The two order statistics and the slice's moments from the window members and the block partials, by every workgroup
-// for itself (wave 0 sorts window A, wave 1 window B, <= 64 values each).  Returns false when a window lost its order
-// statistic.  sel: LDS scratch [2][4].
-template <bool COH>
-__device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand, int npart, int below_a, int below_b, int cnt_a, int cnt_b,
-                                          double (*sel)[4], double *red, double &se, double &va, double &vb)
-{
-    const int ia = a.a0 - below_a, ib = a.b0 - below_b;  // positions of the order statistics inside the sorted windows
-    if (!(cnt_a <= kCandMax && cnt_b <= kCandMax && ia >= 0 && ia < cnt_a && ib >= 0 && ib < cnt_b)) return false;  // workgroup-uniform
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave < 2) {
-        const int cnt = wave ? cnt_b : cnt_a, pos = wave ? ib : ia;
-        const double x = sort64(lane < cnt ? ldc<COH>(cand + wave * kCandMax + lane) : INFINITY);
-        const bool in = wave ? lane <= pos : (lane >= pos && lane < cnt);
-        const double n = static_cast<double>(wave ? pos + 1 : cnt - pos);
-        const double mean = wave_sum(in ? x : 0.0) / n;
-        const double q = wave_sum(in ? (x - mean) * (x - mean) : 0.0);
-        const double stat = __shfl(x, pos, 64);
-        if (lane == 0) { sel[wave][0] = stat; sel[wave][1] = n; sel[wave][2] = mean; sel[wave][3] = q; }
-    }
-    // Chan's combination of the block partials (the same bits in every thread of every workgroup; one partial per
-    // thread, loaded once); its barriers also publish sel
-    double pn = 0.0, pm = 0.0, pq = 0.0;
-    if (static_cast<int>(threadIdx.x) < npart) { pn = ldc<COH>(a.part + 3 * threadIdx.x); pm = ldc<COH>(a.part + 3 * threadIdx.x + 1); pq = ldc<COH>(a.part + 3 * threadIdx.x + 2); }
-    double n0 = block_sum_256(pn, red);
-    double mean0 = block_sum_256(pn * pm, red) / n0;
-    double q0 = block_sum_256(pq + pn * (pm - mean0) * (pm - mean0), red);
-    va = sel[0][0]; vb = sel[1][0];
-    const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
-    __syncthreads();  // sel may be rewritten by the next pass
-    if (!(n0 > 0.0)) { mean0 = 0.0; q0 = 0.0; }  // no value between the windows: the mean above divided by zero
-    const double n = n0 + n1 + n2;
-    const double mean = (n0 * mean0 + n1 * mean1 + n2 * mean2) / n;
-    const double m2 = (q0 + n0 * (mean0 - mean) * (mean0 - mean)) + (q1 + n1 * (mean1 - mean) * (mean1 - mean)) +
-                      (q2 + n2 * (mean2 - mean) * (mean2 - mean));
-    se = sqrt(m2 / (n - 1.0));
-    return static_cast<int>(n) == a.b0 - a.a0 + 1;
 }
 
 __global__ __launch_bounds__(256) void kl_persist(IterArgs a, unsigned *bar)

@@ -43,7 +43,8 @@ struct IterState {
     int32_t fault;     // the persistent light kernel gave up at a grid barrier (bounded spin expired)
     // persistent light kernel: the same counters by pass parity (reset one pass ahead, between barriers)
     int32_t pz_cnt[2][2], pz_below[2][2], pz_nn[2], pz_sig[2];
-    int32_t pad[3];
+    int32_t sig_cnt;   // light pass (three launches): genes with a finite BH rank
+    int32_t pad[2];
 };
 
 void set_error(const char *fmt, ...);
@@ -160,7 +161,7 @@ struct reo_ctx {
     reo::DevBuf<int32_t> modes;         // [K2 launches] 1 = the launch scanned the whole table, 0 = incremental update or skipped
     reo::DevBuf<double> cand;           // [2 parities][2 windows][64] light passes: values inside the quantile windows
     reo::DevBuf<unsigned> gridbar;      // [1] arrival counter of the persistent light kernel's grid barrier
-    int light_mode = 2;                 // 0 sorting passes only, 1 light passes as three launches each, 2 persistent (REO_LIGHT)
+    int light_mode = 1;                 // 0 sorting passes only, 1 light passes as three launches each, 2 as one persistent launch (REO_LIGHT)
     reo::DevBuf<int32_t> hist, mrank;   // [G padded to whole 1024-bin tiles], [G] light passes: histogram of the BH ranks, the ranks
     // parameters of the running reo_identify_degs call (kernels.hip, iter_args)
     double it_pval_deg = 1.0, it_padj_deg = 0.05;
