@@ -17,14 +17,18 @@ end
 function identify_degs(data::AbstractMatrix, group::AbstractVector, gene_names::AbstractVector,
                        pval_reo::AbstractFloat, pval_deg::AbstractFloat, padj_deg::AbstractFloat,
                        ref_gene::BitVector, n_iter::Int64, n_conv::Int64;
-                       seed::UInt64 = rand(UInt64), device::Integer = -1)
+                       seed::UInt64 = rand(UInt64), device::Integer = -1, n_gpus::Integer = 1)
     r, c = size(data)
     glev = unique(group)                                            # :353
     c == length(group) || throw(DimensionMismatch("'data' and 'group' do not have compatiable sizes"))
     length(glev) > 1   || throw(DimensionMismatch("Only 1 level in 'group1, at least 2 levels!"))
     gid = Int32[findfirst(==(g), glev) - 1 for g in group]          # 0-based, first-appearance order
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:reo_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, UInt64), ctx, device, seed))
+    if n_gpus == 1                                                  # one GPU; n_gpus = 0: every visible GPU (RCCL inside the library)
+        check(ccall((:reo_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, UInt64), ctx, device, seed))
+    else
+        check(ccall((:reo_create_multi, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, UInt64), ctx, n_gpus, seed))
+    end
     try
         if eltype(data) <: Integer
             X = Matrix{Int64}(data)
