@@ -98,7 +98,8 @@ def main() -> None:
             os.dup2(self.saved, 1)
             os.close(self.saved)
 
-    if world > 1:
+    force_comm = bool(os.environ.get("REO_BENCH_FORCE_COMM"))  # rehearse the N > 1 plumbing with a world of one rank
+    if world > 1 or force_comm:
         with _StdoutToStderr():
             if args.debug_gloo_one_gpu:
                 dist.init_process_group("gloo")
@@ -120,7 +121,7 @@ def main() -> None:
     def make_ctx():
         ctx = pkg.Context(device=local, seed=seed)
         ctx.set_profiling(True)
-        if world > 1:
+        if world > 1 or force_comm:
             if args.debug_gloo_one_gpu:
                 ctx.set_shard(rank, world)
                 ctx.set_allreduce(pkg.dist.allreduce_hook(dev, via_host=True))
@@ -219,7 +220,7 @@ def main() -> None:
     }
     out["stages_ms_per_step"]["iteration_passes_us_each"] = tm["iter_ms"] / args.steps / max(iters, 1) * 1e3
 
-    if world > 1:  # what each rank did (the driver computes the scaling efficiency from the per-N values itself)
+    if world > 1 or force_comm:  # what each rank did (the driver computes the scaling efficiency from the per-N values itself)
         mine = {"rank": rank, "k1_ms": tm["k1_ms"] / args.steps, "tiles_owned": info["tiles_owned"], "tiles_total": info["tiles_total"],
                 "exchange_ms_per_build": tm["exchange_ms"] / args.steps, "transform_ms": tm["transform_ms"] / args.steps,
                 "iter_ms": tm["iter_ms"] / args.steps}
@@ -267,7 +268,7 @@ def main() -> None:
                                                     "positions, SIMD compares (AVX2), bit-plane class table, popcount tallies"}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_comm:
         dist.destroy_process_group()
 
 

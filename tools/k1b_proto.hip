@@ -335,6 +335,132 @@ __global__ __launch_bounds__(256, WPS) void k1q(const uint4 *__restrict__ P, con
     }
 }
 
+
+// Third form: like k1b (four chains, packed counts, skewed A words) but the 16-byte LDS reads of the tile operand are
+// issued TWO QUADS AHEAD of their use, across gene rows: quad order per gene = 3 (plane 0), 0, 1, 2; quad 3 stays
+// live for planes 13, 14.  D = prefetch distance in quads.
+template <int NB, int WPS, int D>
+__global__ __launch_bounds__(256, WPS) void k1s(const uint4 *__restrict__ P, const uint4 *__restrict__ A, int Gp, int nblk,
+                                                int n_units, const uint32_t *__restrict__ unit_map, uint32_t *__restrict__ out,
+                                                int dump_it, int dump_jc, uint32_t *__restrict__ dump)
+{
+    constexpr int RI = 32, RJ = 4, CJ = 1024, kUnitH = 32;
+    const int slot = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int u = (q / kUnitH) * 8 + slot;
+    if (u >= n_units) return;
+    const uint32_t um = unit_map[u];
+    const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + q % kUnitH;
+    const int jc = static_cast<int>(um >> 16);
+    const int i0 = it * RI;
+    if (i0 >= Gp || jc * CJ >= Gp) return;
+    if (jc * CJ + CJ - 1 < i0) return;
+    const int j0 = jc * CJ + threadIdx.x;
+    uint32_t acc[RJ][RI / 2];
+#pragma unroll
+    for (int r = 0; r < RJ; ++r)
+#pragma unroll
+        for (int h = 0; h < RI / 2; ++h) acc[r][h] = 0;
+    constexpr int SB = 4;
+    __shared__ uint4 sm[2 * SB * RI * 4];
+    uint4 st[SB * RI * 4 / 256];
+    auto stage_load = [&](int b0) {
+#pragma unroll
+        for (int e = 0; e < SB * RI * 4 / 256; ++e) {
+            const int idx = threadIdx.x + 256 * e;
+            const int blk = idx / (RI * 4), rem = idx % (RI * 4);
+            const int b = min(b0 + blk, nblk - 1);
+            st[e] = A[(static_cast<size_t>(b) * Gp + i0) * 4 + rem];
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < SB * RI * 4 / 256; ++e) sm[buf * (SB * RI * 4) + threadIdx.x + 256 * e] = st[e];
+    };
+    int buf = 0;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += SB) {
+        const bool more = b0 + SB < nblk;
+        if (more) stage_load(b0 + SB);
+        const int nb = min(SB, nblk - b0);
+        for (int bb = 0; bb < nb; ++bb) {
+            const int b = b0 + bb;
+            uint32_t p[16][RJ];
+#pragma unroll
+            for (int r = 0; r < RJ; ++r)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const uint4 v = P[(static_cast<size_t>(b) * 4 + qq) * Gp + j0 + 256 * r];
+                    p[4 * qq][r] = v.x; p[4 * qq + 1][r] = v.y; p[4 * qq + 2][r] = v.z; p[4 * qq + 3][r] = v.w;
+                }
+            const uint4 *sa = sm + buf * (SB * RI * 4) + bb * RI * 4;
+            // step t = 4 i + s, s = 0..3 reads quad qs[s] of gene i
+            constexpr int NS = RI * 4;
+            auto quad_of = [](int t) { const int s = t & 3; return (t >> 2) * 4 + (s == 0 ? 3 : s - 1); };
+            uint4 ring[D + 1];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ring[d] = sa[quad_of(d)];
+            uint32_t l[4];
+            uint4 q3 = {0, 0, 0, 0};
+#pragma clang loop unroll(full)
+            for (int i = 0; i < RI; ++i) {
+#pragma clang loop unroll(full)
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int t = 4 * i + s4;
+                    if (t + D < NS) ring[(t + D) % (D + 1)] = sa[quad_of(t + D)];
+                    const uint4 a4 = ring[t % (D + 1)];
+                    if (s4 == 0) {  // quad 3: word 3 = plane 0 now, words 0, 1 = planes 13, 14 at the end
+                        q3 = a4;
+                        asm volatile("v_bitop3_b32 %0, %4, %8, %4 bitop3:0x0c\n\tv_bitop3_b32 %1, %5, %8, %5 bitop3:0x0c\n\t"
+                                     "v_bitop3_b32 %2, %6, %8, %6 bitop3:0x0c\n\tv_bitop3_b32 %3, %7, %8, %7 bitop3:0x0c"
+                                     : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+                                     : "v"(p[0][0]), "v"(p[0][1]), "v"(p[0][2]), "v"(p[0][3]), "v"(a4.w));
+                    } else {
+                        const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma clang loop unroll(full)
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 4 * (s4 - 1) + e + 1;  // planes 1..12
+                            asm volatile("v_bitop3_b32 %0, %4, %8, %0 bitop3:0x8e\n\tv_bitop3_b32 %1, %5, %8, %1 bitop3:0x8e\n\t"
+                                         "v_bitop3_b32 %2, %6, %8, %2 bitop3:0x8e\n\tv_bitop3_b32 %3, %7, %8, %3 bitop3:0x8e"
+                                         : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3])
+                                         : "v"(p[k][0]), "v"(p[k][1]), "v"(p[k][2]), "v"(p[k][3]), "v"(aw[e]));
+                        }
+                    }
+                }
+#pragma clang loop unroll(full)
+                for (int k = 13; k < NB; ++k) {
+                    const uint32_t w = k == 13 ? q3.x : q3.y;
+                    asm volatile("v_bitop3_b32 %0, %4, %8, %0 bitop3:0x8e\n\tv_bitop3_b32 %1, %5, %8, %1 bitop3:0x8e\n\t"
+                                 "v_bitop3_b32 %2, %6, %8, %2 bitop3:0x8e\n\tv_bitop3_b32 %3, %7, %8, %3 bitop3:0x8e"
+                                 : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3])
+                                 : "v"(p[k][0]), "v"(p[k][1]), "v"(p[k][2]), "v"(p[k][3]), "v"(w));
+                }
+#pragma clang loop unroll(full)
+                for (int r = 0; r < RJ; ++r) {
+                    if (i & 1) acc[r][i >> 1] += static_cast<uint32_t>(__builtin_popcount(l[r])) << 16;
+                    else acc[r][i >> 1] += __builtin_popcount(l[r]);
+                }
+            }
+        }
+        if (more) stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    uint32_t x = 0;
+#pragma unroll
+    for (int r = 0; r < RJ; ++r)
+#pragma unroll
+        for (int h = 0; h < RI / 2; ++h) x += acc[r][h] * (2 * h + 1 + r);
+    out[blockIdx.x * 256 + threadIdx.x] = x;
+    if (it == dump_it && jc == dump_jc) {
+#pragma unroll
+        for (int r = 0; r < RJ; ++r)
+#pragma unroll
+            for (int h = 0; h < RI / 2; ++h) dump[(r * 256 + threadIdx.x) * (RI / 2) + h] = acc[r][h];
+    }
+}
+
 static uint64_t splitmix(uint64_t &s)
 {
     uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
@@ -343,7 +469,7 @@ static uint64_t splitmix(uint64_t &s)
     return z ^ (z >> 31);
 }
 
-template <int RI, int RJ, int NB, int WPS, bool SMEM, int ILV, bool PACK, int kUnitH, bool QUAD = false, int FEED = 1>
+template <int RI, int RJ, int NB, int WPS, bool SMEM, int ILV, bool PACK, int kUnitH, bool QUAD = false, int FEED = 1, int KS = 0>
 int run(const char *name, const uint4 *dP, const uint4 *dA, int Gp, int G, int nblk, const std::vector<uint16_t> &pos,
         const std::vector<uint16_t> &lo, int S)
 {
@@ -366,7 +492,8 @@ int run(const char *name, const uint4 *dP, const uint4 *dA, int Gp, int G, int n
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(e0));
-        if constexpr (QUAD) k1q<RI, RJ, NB, WPS, kUnitH, FEED><<<grid, 256>>>(dP, dA, Gp, nblk, static_cast<int>(units.size()), dU, dOut, dump_it, dump_jc, dDump);
+        if constexpr (KS > 0) k1s<NB, WPS, KS><<<grid, 256>>>(dP, dA, Gp, nblk, static_cast<int>(units.size()), dU, dOut, dump_it, dump_jc, dDump);
+        else if constexpr (QUAD) k1q<RI, RJ, NB, WPS, kUnitH, FEED><<<grid, 256>>>(dP, dA, Gp, nblk, static_cast<int>(units.size()), dU, dOut, dump_it, dump_jc, dDump);
         else k1b<RI, RJ, NB, WPS, SMEM, ILV, PACK, kUnitH><<<grid, 256>>>(dP, dA, Gp, nblk, static_cast<int>(units.size()), dU, dOut, dump_it, dump_jc, dDump);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
@@ -434,7 +561,8 @@ int main()
     CHECK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
     printf("G=%d Gp=%d S=%d NB=%d (one side of S samples; the real kernel runs two sides of S/2)\n", G, Gp, S, NB);
     if (run<32, 4, 15, 3, false, 1, true, 32>("LDS RJ=4 3w ilv pack skew", dP, dA, Gp, G, nblk, pos, lo, S)) return 1;
-    if (run<32, 4, 15, 3, false, 2, true, 32>("LDS RJ=4 3w ilv2 pack skew", dP, dA, Gp, G, nblk, pos, lo, S)) return 1;
-    if (run<32, 4, 15, 2, false, 2, true, 32>("LDS RJ=4 2w ilv2 pack skew", dP, dA, Gp, G, nblk, pos, lo, S)) return 1;
+    if (run<32, 4, 15, 3, false, 1, true, 32, false, 1, 2>("k1s prefetch 2 quads, 3w", dP, dA, Gp, G, nblk, pos, lo, S)) return 1;
+    if (run<32, 4, 15, 3, false, 1, true, 32, false, 1, 3>("k1s prefetch 3 quads, 3w", dP, dA, Gp, G, nblk, pos, lo, S)) return 1;
+    if (run<32, 4, 15, 3, false, 1, true, 32, false, 1, 1>("k1s prefetch 1 quad, 3w", dP, dA, Gp, G, nblk, pos, lo, S)) return 1;
     return 0;
 }
