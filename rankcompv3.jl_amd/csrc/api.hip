@@ -258,6 +258,9 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->seed = seed;
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
     if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
+    c->light_window = light_window(); c->light_min_g = light_min_genes();
+    if (const char *e = getenv("REO_LIGHT_WINDOW")) c->light_window = std::max(1, std::min(31, atoi(e)));  // 2 W + 1 <= 64 window members
+    if (const char *e = getenv("REO_LIGHT_MIN_G")) c->light_min_g = std::max(64, atoi(e));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return REO_EHIP; }
     *out = c;
@@ -527,7 +530,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // the sorting path -- needed for the first pass, whenever the reference set changed by more genes than a tally
     // update takes, and when a quantile window lost its order statistic -- and the light path.  A batch = two
     // sorting passes (mostly idle launches) + as many light passes as may follow; small problems sort every pass.
-    const bool small = G < light_min_genes() || c->light_mode == 0;
+    const bool small = G < c->light_min_g || c->light_mode == 0;
     int passes = 0, seen_need_full = 1;
     while (n_iter > 0) {  // :400
         const int remaining = n_iter - passes;

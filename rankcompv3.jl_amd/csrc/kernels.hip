@@ -673,6 +673,7 @@ struct IterArgs {
     int32_t *mrank;              // [G]         light passes: m_i
     int replay;                  // 1: recompute the outputs of the last executed pass from its tallies, change no state
     int k2_idx;                  // index of this k2_tally launch (for the stage timers)
+    int window, light_min_g;     // light passes: ranks on either side of a quantile that its window is made to hold; smallest G that uses them
     unsigned long long *stamps;  // diagnostic builds (-DREO_STAMPS): s_memrealtime marks of workgroup 0, else unused
 };
 
@@ -685,8 +686,8 @@ struct IterArgs {
 // scal[]: 0 se of the last pass; 1..4 quantile windows wa_lo wa_hi wb_lo wb_hi for the next light pass;
 // 5..8 their half widths (value units) around the exact quantiles
 constexpr int kCandMax = 64;     // candidates per quantile window (one per lane of the wave that sorts them)
-constexpr int kWindow = 24;      // ranks on either side of the quantile that the window is made to hold
-constexpr int kLightMinG = 4096; // below this the sorting passes are cheap and the windows would overlap
+constexpr int kWindow = 24;      // ranks on either side of the quantile that the window is made to hold (REO_LIGHT_WINDOW overrides: tests)
+constexpr int kLightMinG = 4096; // below this the sorting passes are cheap (REO_LIGHT_MIN_G overrides: tests)
 
 // the pass the kernels of the sorting path work on: the next one, or (replay) the last executed one
 __device__ __forceinline__ bool full_pass_active(const IterArgs &a, int &t, int &nref)
@@ -1172,11 +1173,12 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
     if (over < 0) return;
     // quantile windows: the values kWindow ranks on either side of the slice bounds, kept as widths around the
     // exact quantiles so that a light pass can re-centre them on its own quantiles
-    bool ok = G >= kLightMinG && a.a0 - kWindow >= 0 && a.b0 + kWindow < G;
+    const int W = a.window;
+    bool ok = G >= a.light_min_g && a.a0 - W >= 0 && a.b0 + W < G && a.a0 + W < a.b0 - W;
     if (ok) {
         const double va = a.sorted_d[a.a0], vb = a.sorted_d[a.b0];
-        const double wa_lo = a.sorted_d[a.a0 - kWindow], wa_hi = a.sorted_d[a.a0 + kWindow];
-        const double wb_lo = a.sorted_d[a.b0 - kWindow], wb_hi = a.sorted_d[a.b0 + kWindow];
+        const double wa_lo = a.sorted_d[a.a0 - W], wa_hi = a.sorted_d[a.a0 + W];
+        const double wb_lo = a.sorted_d[a.b0 - W], wb_hi = a.sorted_d[a.b0 + W];
         ok = wa_hi < wb_lo;
         a.scal[1] = wa_lo; a.scal[2] = wa_hi; a.scal[3] = wb_lo; a.scal[4] = wb_hi;
         a.scal[5] = va - wa_lo; a.scal[6] = wa_hi - va; a.scal[7] = vb - wb_lo; a.scal[8] = wb_hi - vb;
@@ -1844,6 +1846,7 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     a.trace = c->trace.p; a.modes = nullptr;
     a.cand = c->cand.p; a.hist = c->hist.p; a.mrank = c->mrank.p;
     a.replay = replay; a.k2_idx = 0;
+    a.window = c->light_window; a.light_min_g = c->light_min_g;
     a.stamps = reinterpret_cast<unsigned long long *>(c->scal.p + 32);
     return a;
 }
@@ -1899,6 +1902,7 @@ int32_t launch_light_persistent(reo_ctx *c)
 }
 
 int32_t light_min_genes() { return kLightMinG; }
+int32_t light_window() { return kWindow; }
 
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out)
 {

@@ -161,6 +161,7 @@ struct reo_ctx {
     reo::DevBuf<int32_t> modes;         // [K2 launches] 1 = the launch scanned the whole table, 0 = incremental update or skipped
     reo::DevBuf<double> cand;           // [2 parities][2 windows][64] light passes: values inside the quantile windows
     reo::DevBuf<unsigned> gridbar;      // [1] arrival counter of the persistent light kernel's grid barrier
+    int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
     int light_mode = 1;                 // 0 sorting passes only, 1 light passes as three launches each, 2 as one persistent launch (REO_LIGHT)
     reo::DevBuf<int32_t> hist, mrank;   // [G padded to whole 1024-bin tiles], [G] light passes: histogram of the BH ranks, the ranks
     // parameters of the running reo_identify_degs call (kernels.hip, iter_args)
@@ -194,6 +195,7 @@ int32_t launch_full_pass(reo_ctx *c, bool replay);
 int32_t launch_light_pass(reo_ctx *c);
 int32_t launch_light_persistent(reo_ctx *c);
 int32_t light_min_genes();
+int32_t light_window();
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
 
 // comm.hip: in-library RCCL.  Returns REO_OK after enqueueing the sum on c->stream, 1 when no communicator is attached

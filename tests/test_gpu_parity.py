@@ -866,3 +866,44 @@ def test_in_library_rccl_and_multi_context_from_python(pkg, oracle):
     exp, eit, etr = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, 6, 1, seed)
     assert it0 == eit and tr0 == etr
     _check_result(res0, exp)
+
+
+@pytest.mark.parametrize("window,light", [("3", "1"), ("1", "1"), ("12", "1"), ("3", "2")])
+def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monkeypatch, window, light):
+    """The light iteration passes (quantile windows + BH cut from the histogram of step-up ranks) on many small random
+    problems: REO_LIGHT_MIN_G lets small gene counts use them, and a window of 1-3 ranks makes windows lose their order
+    statistic now and then, so the fall-back to the sorting path and the hand-over of the tally state between the two
+    kinds of pass are exercised too.  More passes than usual (n_conv = 0 forces them); different padj / pval cut-offs;
+    tie-heavy data puts many equal delta1 values around the quantiles.  light = 2: the persistent one-launch form."""
+    monkeypatch.setenv("REO_LIGHT_MIN_G", "64")
+    monkeypatch.setenv("REO_LIGHT_WINDOW", window)
+    monkeypatch.setenv("REO_LIGHT", light)
+    rng = np.random.default_rng(4242 + int(window) * 7 + int(light))
+    light_batches = 0
+    for case_no in range(14):
+        cs = _random_case(rng)
+        G = max(cs["G"], 120) if cs["G"] >= 120 else 120 + cs["G"]
+        X = cs["X"] if cs["X"].shape[0] == G else np.vstack([cs["X"], rng.permutation(cs["X"], axis=0)])[:G] if cs["X"].shape[0] * 2 >= G else None
+        if X is None:
+            X = rng.integers(0, 9, size=(G, cs["S"]))
+        labels = cs["labels"]
+        gid, lev = pkg.encode_groups(labels)
+        ref0 = pkg.synth.ref_mask(G, max(3, G // 3), cs["seed"])
+        n_iter, n_conv = int(rng.integers(6, 14)), int(rng.choice([0, 0, 1]))
+        pval_deg, padj_deg = float(rng.choice([1.0, 1.0, 0.2])), float(rng.choice([0.05, 0.3, 0.9]))
+        tag = (window, light, case_no, cs["kind"], G, cs["S"], cs["ng"], n_iter, n_conv, pval_deg, padj_deg)
+        run = pkg.run_identify_degs(X, labels, list(range(G)), cs["pval_reo"], pval_deg, padj_deg, ref0, n_iter, n_conv,
+                                    seed=cs["seed"], device=0, profile=True)
+        Xf = np.asarray(X, dtype=np.float64)
+        for cm in run.comparisons:
+            exp, iters, trace = oracle.identify_degs(Xf, gid, len(lev), cs["pval_reo"], pval_deg, padj_deg, ref0, n_iter, n_conv,
+                                                     cs["seed"], k=cm["k"])
+            assert cm["iters_run"] == iters and cm["trace"] == trace, tag
+            assert np.array_equal(cm["result"][:, 2:11], exp[:, 2:11]), tag
+            ok = np.isfinite(exp).all(axis=1)
+            assert np.allclose(cm["result"][ok][:, :2], exp[ok][:, :2], rtol=0, atol=P_ATOL), tag
+            assert np.allclose(cm["result"][ok][:, 11:], exp[ok][:, 11:], rtol=STAT_RTOL, atol=1e-9), tag
+        # a pass that ran light needed no K2 launch: fewer K2 launches than passes means light passes happened
+        if run.timings["k2_launches"] < sum(c["iters_run"] for c in run.comparisons) + 2 * len(run.comparisons):
+            light_batches += 1
+    assert light_batches > 0
