@@ -111,8 +111,8 @@ static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64
     int32_t rc = use(c);
     if (rc) return rc;
     if (!X) { set_error("matrix pointer is null"); return REO_EINVAL; }
-    if (G < 2 || G > 65535 || S < 2 || S > 65535) {
-        set_error("matrix is %lld x %lld; G and S must be in [2, 65535]", (long long)G, (long long)S);
+    if (G < 2 || G > 65535 || S < 2 || S > (1 << 20)) {
+        set_error("matrix is %lld x %lld; G must be in [2, 65535] (16-bit positions) and S in [2, 1048576]", (long long)G, (long long)S);
         return REO_EINVAL;
     }
     if (ld < G) { set_error("leading dimension %lld < G = %lld", (long long)ld, (long long)G); return REO_EINVAL; }
@@ -439,6 +439,7 @@ int32_t reo_pair_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t 
     int32_t rc = use(c);
     if (rc) return rc;
     if ((rc = ensure_transform(c))) return rc;
+    if (c->S > 65535) { set_error("reo_pair_counts returns 16-bit counts: not available with more than 65535 samples"); return REO_EINVAL; }
     if (!n_gt || !n_eq || i0 < 0 || j0 < 0 || i1 > c->G || j1 > c->G || i0 >= i1 || j0 >= j1) {
         set_error("bad pair block [%lld,%lld) x [%lld,%lld)", (long long)i0, (long long)i1, (long long)j0, (long long)j1);
         return REO_EINVAL;

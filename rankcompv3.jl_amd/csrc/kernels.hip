@@ -397,6 +397,139 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k1_pairs(K1Args a)  // wav
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Wide form of the pair loop for more than 65 535 samples (single-cell mode without pseudo-bulking, :608-616): one
+// 32-bit count per register.  Tie-free: 2 genes per lane, two gene rows per step (chains (p0,a_i) (p1,a_i) (p0,a_i+1)
+// (p1,a_i+1)); with ties: 1 gene per lane, chains (p0,lo_i) (p0,hi_i) (p0,lo_i+1) (p0,hi_i+1).  The tile operand is
+// used by half as many chains as in the packed form, so the broadcast LDS reads bind before the VALU does; this
+// path exists for completeness, not speed.
+constexpr int kRJWide = 2, kRJWideTies = 1;
+
+template <int RJ, int NB, bool TIES>
+__device__ __forceinline__ void count_pass_wide(const uint4 *__restrict__ P, const uint4 *__restrict__ AL, const uint4 *__restrict__ AH,
+                                                int Gp, int i0, int jl, int bb, int be, uint32_t (&gt)[RJ][kTileI],
+                                                uint32_t (&ge)[TIES ? RJ : 1][kTileI], uint4 *sm_lo, uint4 *sm_hi, bool idle)
+{
+    static_assert((TIES && RJ == 1) || (!TIES && RJ == 2), "four chains per bit plane");
+    constexpr int RI = kTileI, NQ = (NB + 3) / 4;
+    constexpr int kStageQ = kStageB * RI * 4;
+    constexpr int kPerThread = kStageQ / 256;
+#pragma unroll
+    for (int r = 0; r < RJ; ++r)
+#pragma unroll
+        for (int ii = 0; ii < RI; ++ii) { gt[r][ii] = 0; if (TIES) ge[r][ii] = 0; }
+    if (bb >= be) return;
+    uint4 sl[kPerThread], sh[TIES ? kPerThread : 1];
+    auto stage_load = [&](int b0) {
+#pragma unroll
+        for (int e = 0; e < kPerThread; ++e) {
+            const int idx = threadIdx.x + 256 * e;
+            const int b = min(b0 + idx / (RI * 4), be - 1);
+            const size_t o = (static_cast<size_t>(b) * Gp + i0) * 4 + idx % (RI * 4);
+            sl[e] = AL[o];
+            if (TIES) sh[e] = AH[o];
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < kPerThread; ++e) {
+            sm_lo[buf * kStageQ + threadIdx.x + 256 * e] = sl[e];
+            if (TIES) sm_hi[buf * kStageQ + threadIdx.x + 256 * e] = sh[e];
+        }
+    };
+    stage_load(bb);
+    __syncthreads();
+    stage_store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int b0 = bb; b0 < be; b0 += kStageB) {
+        const bool more = b0 + kStageB < be;
+        if (more) stage_load(b0 + kStageB);
+        const int nb = idle ? 0 : min(kStageB, be - b0);
+        for (int s = 0; s < nb; ++s) {
+            Planes16 p[RJ];
+#pragma unroll
+            for (int r = 0; r < RJ; ++r)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) p[r].set(q, P[(static_cast<size_t>(b0 + s) * 4 + q) * Gp + jl + 64 * r]);
+            const uint4 *al = sm_lo + buf * kStageQ + s * RI * 4;
+            const uint4 *ah = sm_hi + buf * kStageQ + s * RI * 4;
+#pragma clang loop unroll(full)
+            for (int i = 0; i < RI; i += 2) {
+                Planes16 a0, a1, c0, c1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < 3 && 4 * q + 1 > NB - 1) continue;
+                    a0.set(q, al[i * 4 + q]); a1.set(q, al[(i + 1) * 4 + q]);
+                    if (TIES) { c0.set(q, ah[i * 4 + q]); c1.set(q, ah[(i + 1) * 4 + q]); }
+                }
+                uint32_t l[4];
+                if (TIES) {
+                    chains_first(l, p[0].w[0], p[0].w[0], p[0].w[0], p[0].w[0], a0.w[a_word(0)], c0.w[a_word(0)], a1.w[a_word(0)], c1.w[a_word(0)]);
+#pragma unroll
+                    for (int k = 1; k < NB; ++k)
+                        chains_next(l, p[0].w[k], p[0].w[k], p[0].w[k], p[0].w[k], a0.w[a_word(k)], c0.w[a_word(k)], a1.w[a_word(k)], c1.w[a_word(k)]);
+                    gt[0][i] += __builtin_popcount(l[0]); ge[0][i] += __builtin_popcount(l[1]);
+                    gt[0][i + 1] += __builtin_popcount(l[2]); ge[0][i + 1] += __builtin_popcount(l[3]);
+                } else {
+                    chains_first(l, p[0].w[0], p[RJ - 1].w[0], p[0].w[0], p[RJ - 1].w[0], a0.w[a_word(0)], a0.w[a_word(0)], a1.w[a_word(0)], a1.w[a_word(0)]);
+#pragma unroll
+                    for (int k = 1; k < NB; ++k)
+                        chains_next(l, p[0].w[k], p[RJ - 1].w[k], p[0].w[k], p[RJ - 1].w[k], a0.w[a_word(k)], a0.w[a_word(k)], a1.w[a_word(k)], a1.w[a_word(k)]);
+                    gt[0][i] += __builtin_popcount(l[0]); gt[RJ - 1][i] += __builtin_popcount(l[1]);
+                    gt[0][i + 1] += __builtin_popcount(l[2]); gt[RJ - 1][i + 1] += __builtin_popcount(l[3]);
+                }
+            }
+        }
+        if (more) stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+template <int NB, bool TIES, bool MULTI>
+__global__ __launch_bounds__(256, 2) void k1_pairs_wide(K1Args a)
+{
+    constexpr int RI = kTileI, RJ = TIES ? kRJWideTies : kRJWide;
+    int i0, jl;
+    if (!tile_of_block<RI, RJ>(a, i0, jl)) return;
+    const int lane = threadIdx.x & 63, bi = i0 >> 6;
+    __shared__ uint4 sm_lo[2 * kStageB * RI * 4];
+    __shared__ uint4 sm_hi[TIES ? 2 * kStageB * RI * 4 : 1];
+    const bool idle = wave_idle<RJ>(jl & ~63, i0, a.G);
+    uint32_t gt[RJ][RI], ge[TIES ? RJ : 1][RI];
+    auto count_of = [&](int r, int ii, int g) -> int {
+        int nre = static_cast<int>(gt[r][ii]);
+        if (TIES) {
+            const uint32_t neq = ge[r][ii] - gt[r][ii];
+            if (neq) nre += tie_wins(a.seed, i0 + ii, jl + 64 * r, g, neq);
+        }
+        return nre;
+    };
+    count_pass_wide<RJ, NB, TIES>(a.P, a.AL, a.AH, a.Gp, i0, jl, a.cb, a.ce, gt, ge, sm_lo, sm_hi, idle);
+    emit_side<RI, RJ>(a, i0, jl, bi, lane, 0, a.m1, a.nc - a.m1, [&](int r, int ii) { return count_of(r, ii, a.gc); });
+    if (!MULTI) {
+        count_pass_wide<RJ, NB, TIES>(a.P, a.AL, a.AH, a.Gp, i0, jl, a.tb, a.te, gt, ge, sm_lo, sm_hi, idle);
+        emit_side<RI, RJ>(a, i0, jl, bi, lane, 2, a.m2, a.nt - a.m2, [&](int r, int ii) { return count_of(r, ii, a.gt); });
+    } else {
+        int tot[RJ][RI];  // not = sum(nre) - nre[k]  (:374)
+#pragma unroll
+        for (int r = 0; r < RJ; ++r)
+#pragma unroll
+            for (int ii = 0; ii < RI; ++ii) tot[r][ii] = 0;
+        for (int g = 0; g < a.ngroups; ++g) {
+            if (g == a.gc) continue;
+            count_pass_wide<RJ, NB, TIES>(a.P, a.AL, a.AH, a.Gp, i0, jl, a.goff[g], a.goff[g + 1], gt, ge, sm_lo, sm_hi, idle);
+#pragma unroll
+            for (int r = 0; r < RJ; ++r)
+#pragma unroll
+                for (int ii = 0; ii < RI; ++ii) tot[r][ii] += count_of(r, ii, g);
+        }
+        emit_side<RI, RJ>(a, i0, jl, bi, lane, 2, a.m2, a.nt - a.m2, [&](int r, int ii) { return tot[r][ii]; });
+    }
+}
+
 // ---------------------------------------------------------------------------
 // One-vs-rest with C > 2 groups (:375-390,396-436): the C comparisons need the same per-group counts
 // nre_g(i,j) (tie coins are keyed by group, not by comparison), so they are counted once, kept in
@@ -1696,9 +1829,17 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, unsigned *bar)
 static int plane_bits(int64_t G) { return G <= 4095 ? 12 : (G <= 32767 ? 15 : 16); }
 
 template <int NB>
-static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool shared, bool multi, size_t plane_elems)
+static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool shared, bool multi, size_t plane_elems, bool wide)
 {
-    if (shared) {
+    if (wide) {  // more than 65 535 samples: 32-bit counts (never the shared per-group planes, which are 16-bit)
+        if (multi) {
+            if (c->has_ties) k1_pairs_wide<NB, true, true><<<grid, 256, 0, c->stream>>>(a);
+            else k1_pairs_wide<NB, false, true><<<grid, 256, 0, c->stream>>>(a);
+        } else {
+            if (c->has_ties) k1_pairs_wide<NB, true, false><<<grid, 256, 0, c->stream>>>(a);
+            else k1_pairs_wide<NB, false, false><<<grid, 256, 0, c->stream>>>(a);
+        }
+    } else if (shared) {
         if (!c->gc_valid) {
             if (c->has_ties) k1_group_counts<NB, true><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
             else k1_group_counts<NB, false><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
@@ -1732,7 +1873,8 @@ int32_t launch_k1(reo_ctx *c, int k)
 
     // work units: panel p = Q consecutive j-chunks, cut into i-ranges of kUnitH tiles.  Q keeps the
     // panel's pos planes (Q x 256 RJ genes x nblk blocks x 64 B) within about 2 MiB of the 4 MiB L2 of an XCD.
-    const int RJ = c->has_ties ? kRJTies : kRJ;  // genes j per lane
+    const bool wide = c->S > 65535;  // a count may not fit 16 bits: the unpacked form of the pair loop
+    const int RJ = wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ);  // genes j per lane
     const int CJ = kTileJ * RJ;
     const int NJ = (c->Gp + CJ - 1) / CJ, NIT = c->Gp / kTileI;
     const size_t chunk_bytes = static_cast<size_t>(CJ) * (c->goff32[c->ngroups] / 32) * 64;
@@ -1769,7 +1911,7 @@ int32_t launch_k1(reo_ctx *c, int k)
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
     // > 2 groups: count every group once, then classify per comparison -- if the planes fit
     const size_t plane_elems = static_cast<size_t>(c->Gp) * c->Gp;
-    bool shared = multi && c->share_counts;
+    bool shared = multi && c->share_counts && !wide;
     if (shared && !c->gc_valid) {
         size_t free_b = 0, total_b = 0;
         REO_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
@@ -1781,9 +1923,9 @@ int32_t launch_k1(reo_ctx *c, int k)
     c->last_k1_shared = shared ? 1 : 0;
     tic(c, 1);
     switch (plane_bits(c->G)) {
-    case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems); break;
-    case 15: launch_pair_kernels<15>(c, a, grid, shared, multi, plane_elems); break;
-    default: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems); break;
+    case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems, wide); break;
+    case 15: launch_pair_kernels<15>(c, a, grid, shared, multi, plane_elems, wide); break;
+    default: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems, wide); break;
     }
     toc(c);
     REO_HIP_CHECK(hipGetLastError());

@@ -400,7 +400,7 @@ int32_t transform_impl(reo_ctx *c)
     }
 
     // column batches: rocprim takes a 32-bit element count
-    const int CB = std::max(1, std::min(S, static_cast<int>((1u << 27) / static_cast<unsigned>(G))));
+    const int CB = std::max(1, std::min(std::min(S, 65535), static_cast<int>((1u << 27) / static_cast<unsigned>(G))));  // (grid y <= 65535)
     DevBuf<uint64_t> &k_in = c->t_kin, &k_out = c->t_kout;
     DevBuf<uint16_t> &v_in = c->t_vin, &v_out = c->t_vout;
     const size_t bn = static_cast<size_t>(CB) * G;

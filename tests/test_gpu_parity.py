@@ -907,3 +907,29 @@ def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monke
         if run.timings["k2_launches"] < sum(c["iters_run"] for c in run.comparisons) + 2 * len(run.comparisons):
             light_batches += 1
     assert light_batches > 0
+
+
+@pytest.mark.parametrize("family,ngroups", [("t1", 2), ("t0", 2), ("float", 2), ("t1", 3)])
+def test_more_than_65535_samples(pkg, oracle, family, ngroups):
+    """Single-cell mode without pseudo-bulking (src/RankCompV3.jl:608-616 with n_pseudo = 0) can hand over more samples
+    than a 16-bit count holds: the wide form of the pair kernel (32-bit counts).  66 100 samples, the whole run."""
+    G, seed = 260, 0x5EED0091
+    sizes = [33100, 33000] if ngroups == 2 else [33000, 33040, 60]
+    S = sum(sizes)
+    gen = {"t0": pkg.synth.t0_ranks, "t1": pkg.synth.t1_counts, "float": pkg.synth.float_expr}[family]
+    X = gen(G, S, seed)
+    gid = np.concatenate([[g] * n for g, n in enumerate(sizes)]).astype(np.int32)
+    if ngroups == 3:  # interleave the two small groups into the big one (group ids stay in order of first appearance)
+        perm = np.concatenate([[0, 33000, 66040], np.random.default_rng(1).permutation(np.setdiff1d(np.arange(S), [0, 33000, 66040]))])
+        X, gid = X[:, perm], gid[perm]
+    ref0 = pkg.synth.ref_mask(G, 80, seed)
+    run = pkg.run_identify_degs(X, gid, list(range(G)), 0.01, 1.0, 0.05, ref0, 5, 1, seed=seed, device=0)
+    assert run.info["S"] == S
+    for cm in run.comparisons:
+        exp, eit, etr = oracle.identify_degs(X.astype(np.float64), gid, ngroups, 0.01, 1.0, 0.05, ref0, 5, 1, seed, k=cm["k"])
+        assert cm["iters_run"] == eit and cm["trace"] == etr, (family, cm["k"])
+        _check_result(cm["result"], exp)
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, ngroups)
+        with pytest.raises(pkg.DimensionMismatch):
+            ctx.pair_counts(0, 8, 0, 8)          # 16-bit outputs cannot hold these counts
