@@ -161,7 +161,7 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         (rc = c->state.ensure(1)) ||
         (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * (kSortChunk + kSortChunk / 32))) ||
         (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))) ||
-        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure((G + 32767) / 32768 * 32768)) || (rc = c->mrank.ensure(G)) || (rc = c->scal.ensure(64)))
+        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(2 * ((G + 32767) / 32768 * 32768))) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->scal.ensure(64)))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
@@ -257,7 +257,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->device = device;
     c->seed = seed;
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
-    if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
+    if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 3));
     c->light_window = light_window(); c->light_min_g = light_min_genes();
     if (const char *e = getenv("REO_LIGHT_WINDOW")) c->light_window = std::max(1, std::min(31, atoi(e)));  // 2 W + 1 <= 64 window members
     if (const char *e = getenv("REO_LIGHT_MIN_G")) c->light_min_g = std::max(64, atoi(e));
@@ -285,7 +285,7 @@ void reo_destroy(reo_ctx *c)
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
+    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -536,12 +536,14 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     while (n_iter > 0) {  // :400
         const int remaining = n_iter - passes;
         const int nfull = small ? std::min(8, remaining) : std::min(2, remaining);
-        const int nlight = (small || seen_need_full) ? 0 : std::min(32, remaining);
+        const int nlight = (small || seen_need_full) ? 0 : std::min(kLightBatch, remaining);
         tic(c, 3);
         for (int t = 0; t < nfull; ++t)
             if ((rc = launch_full_pass(c, false))) return rc;
         if (nlight > 0 && c->light_mode == 2) {
             if ((rc = launch_light_persistent(c))) return rc;  // runs light passes until the state stops them
+        } else if (nlight > 0 && c->light_mode == 3) {
+            if ((rc = launch_light_batch(c, nlight))) return rc;
         } else {
             for (int t = 0; t < nlight; ++t)
                 if ((rc = launch_light_pass(c))) return rc;
@@ -577,7 +579,15 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     if (getenv("REO_DEBUG_STAMPS")) {  // diagnostic builds (-DREO_STAMPS): marks of the last light pass, 10 ns units
         unsigned long long st[24];
         REO_HIP_CHECK(hipMemcpy(st, c->scal.p + 32, sizeof st, hipMemcpyDeviceToHost));
-        fprintf(stderr, "stamps persistent (phase1 B1 phase2 B2 [cut] phase3 B3):");
+        fprintf(stderr, "stamps kl_head (loads issued, cut, mask scan, deltas, delta1, window flags, block sums, end):");
+        for (int k = 0; k <= 7; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[8]));
+        fprintf(stderr, "  [scan from cut: barrier %lld, row maxima %lld, changes %lld, own bit + barrier %lld]", (long long)(st[14] - st[1]), (long long)(st[15] - st[1]), (long long)(st[16] - st[1]), (long long)(st[17] - st[1]));
+        fprintf(stderr, "  [all loads back %lld]", (long long)(st[18] - st[8]));
+        fprintf(stderr, "  [shader clock %.0f MHz]", (double)(st[13] - st[12]) / ((double)(st[7] - st[8]) * 0.01));
+        fprintf(stderr, "  [prologue: hist asked %lld, ranks asked %lld, raw asked %lld]", (long long)(st[9] - st[8]), (long long)(st[10] - st[8]), (long long)(st[11] - st[8]));
+        fprintf(stderr, "\nstamps kl_rank (loads back, selection + se, p + BH rank, end):");
+        for (int k = 20; k <= 23; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[19]));
+        fprintf(stderr, "\nstamps persistent (phase1 B1 phase2 B2 [cut] phase3 B3):");
         fprintf(stderr, " %lld %lld %lld %lld [%lld] %lld %lld |", (long long)(st[1] - st[0]), (long long)(st[2] - st[1]), (long long)(st[3] - st[2]),
                 (long long)(st[4] - st[3]), (long long)(st[7] - st[4]), (long long)(st[5] - st[4]), (long long)(st[6] - st[5]));
         fprintf(stderr, " kl_pvalues:");

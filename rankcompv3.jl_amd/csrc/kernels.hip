@@ -733,23 +733,24 @@ __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, cons
 // by the mirror rule (:386) column j of the table is row j with L and H swapped, so gene j entering
 // (leaving) the reference set adds (removes), for every gene i, the class bits found at bit i of ROW j:
 // one contiguous row per changed gene instead of the whole table.  Exact (integer sums).
-template <bool COH>
+template <bool COH, int U = 4>
 __device__ __forceinline__ void delta_counts(const uint32_t *__restrict__ table, int Wp, const uint32_t *list, int n, int i, int (&d)[kRaw])
 {
     const int w = i >> 5, sh = i & 31;
 #pragma unroll
     for (int q = 0; q < kRaw; ++q) d[q] = 0;
-    for (int e0 = 0; e0 < n; e0 += 4) {  // four list entries per step: sixteen independent loads in flight
-        uint32_t ent[4], w0[4], w1[4], w2[4], w3[4];
+    for (int e0 = 0; e0 < n; e0 += U) {  // U list entries per step: 4 U independent loads in flight (one round trip per step)
+        uint32_t ent[U], w0[U], w1[U], w2[U], w3[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ent[u] = ldc<COH>(list + min(e0 + u, n - 1));  // wave-uniform
+        for (int u = 0; u < U; ++u) ent[u] = ldc<COH>(list + min(e0 + u, n - 1));  // wave-uniform
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
+            if (U > 4 && e0 + u >= n) { w0[u] = w1[u] = w2[u] = w3[u] = 0; continue; }  // (uniform)
             const uint32_t *row = table + static_cast<size_t>(ent[u] >> 1) * kPlanes * Wp + w;
             w0[u] = row[0]; w1[u] = row[Wp]; w2[u] = row[2 * Wp]; w3[u] = row[3 * Wp];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (e0 + u >= n) continue;
             const int sgn = (ent[u] & 1u) ? 1 : -1;
             // pair (i, j) seen from gene i: cL(i,j) = cH(j,i), cH(i,j) = cL(j,i), likewise for the treat side
@@ -802,8 +803,9 @@ struct IterArgs {
     double *part; double *blockmin; double *scal;
     int32_t *trace; int32_t *modes;
     double *cand;                // [2][kCandMax] light passes: values inside the two quantile windows
-    int32_t *hist;               // [G + 2]     light passes: histogram of the BH ranks m_i
-    int32_t *mrank;              // [G]         light passes: m_i
+    int32_t *hist;               // [2][hist_stride] light passes: histogram of the BH ranks m_i (second copy: two-launch form, by launch parity)
+    int hist_stride;
+    int32_t *mrank;              // [Gp]        light passes: m_i
     int replay;                  // 1: recompute the outputs of the last executed pass from its tallies, change no state
     int k2_idx;                  // index of this k2_tally launch (for the stage timers)
     int window, light_min_g;     // light passes: ranks on either side of a quantile that its window is made to hold; smallest G that uses them
@@ -958,6 +960,14 @@ __global__ __launch_bounds__(256) void k3_derive(IterArgs a)
     result[13 * Gs + i] = o[3]; result[14 * Gs + i] = o[4];
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding global
+// load and STORE of the wave (s_waitcnt vmcnt(0): a write round trip of a microsecond or two in these latency-bound
+// kernels); this waits for the LDS traffic alone.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Sum over the 256 threads of a workgroup, the same bits in every thread and every workgroup: an
 // xor-butterfly inside each wave (a + b == b + a, so all lanes of a wave agree at every step), then the
 // four wave sums in a fixed order.  Two barriers (the second lets `red` be reused at once).
@@ -966,9 +976,9 @@ __device__ __forceinline__ double block_sum_256(double v, double *red)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     const double r = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
+    lds_barrier();
     return r;
 }
 
@@ -1446,16 +1456,17 @@ __device__ __forceinline__ int bh_rank(double p, int G, double al)
 // The two order statistics and the slice's moments from the window members and the block partials, by every workgroup
 // for itself (wave 0 sorts window A, wave 1 window B, <= 64 values each).  Returns false when a window lost its order
 // statistic.  sel: LDS scratch [2][4].
-template <bool COH>
-__device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand, int npart, int below_a, int below_b, int cnt_a, int cnt_b,
-                                          double (*sel)[4], double *red, double &se, double &va, double &vb)
+// x: the window member this lane holds (wave 0: window A, wave 1: window B; lanes past the count: anything);
+// pn, pm, pq: the block partial this thread holds (threads past the number of partials: zeros).
+__device__ __forceinline__ bool slice_std_vals(const IterArgs &a, double x, double pn, double pm, double pq, int below_a, int below_b, int cnt_a, int cnt_b,
+                                               double (*sel)[4], double *red, double &se, double &va, double &vb)
 {
     const int ia = a.a0 - below_a, ib = a.b0 - below_b;  // positions of the order statistics inside the sorted windows
     if (!(cnt_a <= kCandMax && cnt_b <= kCandMax && ia >= 0 && ia < cnt_a && ib >= 0 && ib < cnt_b)) return false;  // workgroup-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave < 2) {
         const int cnt = wave ? cnt_b : cnt_a, pos = wave ? ib : ia;
-        const double x = sort64(lane < cnt ? ldc<COH>(cand + wave * kCandMax + lane) : INFINITY);
+        x = sort64(lane < cnt ? x : INFINITY);
         const bool in = wave ? lane <= pos : (lane >= pos && lane < cnt);
         const double n = static_cast<double>(wave ? pos + 1 : cnt - pos);
         const double mean = wave_sum(in ? x : 0.0) / n;
@@ -1464,15 +1475,13 @@ __device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand,
         if (lane == 0) { sel[wave][0] = stat; sel[wave][1] = n; sel[wave][2] = mean; sel[wave][3] = q; }
     }
     // Chan's combination of the block partials (the same bits in every thread of every workgroup; one partial per
-    // thread, loaded once); its barriers also publish sel
-    double pn = 0.0, pm = 0.0, pq = 0.0;
-    if (static_cast<int>(threadIdx.x) < npart) { pn = ldc<COH>(a.part + 3 * threadIdx.x); pm = ldc<COH>(a.part + 3 * threadIdx.x + 1); pq = ldc<COH>(a.part + 3 * threadIdx.x + 2); }
+    // thread); its barriers also publish sel
     double n0 = block_sum_256(pn, red);
     double mean0 = block_sum_256(pn * pm, red) / n0;
     double q0 = block_sum_256(pq + pn * (pm - mean0) * (pm - mean0), red);
     va = sel[0][0]; vb = sel[1][0];
     const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
-    __syncthreads();  // sel may be rewritten by the next pass
+    lds_barrier();  // sel may be rewritten by the next pass
     if (!(n0 > 0.0)) { mean0 = 0.0; q0 = 0.0; }  // no value between the windows: the mean above divided by zero
     const double n = n0 + n1 + n2;
     const double mean = (n0 * mean0 + n1 * mean1 + n2 * mean2) / n;
@@ -1480,6 +1489,17 @@ __device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand,
                       (q2 + n2 * (mean2 - mean) * (mean2 - mean));
     se = sqrt(m2 / (n - 1.0));
     return static_cast<int>(n) == a.b0 - a.a0 + 1;
+}
+
+template <bool COH>
+__device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand, int npart, int below_a, int below_b, int cnt_a, int cnt_b,
+                                          double (*sel)[4], double *red, double &se, double &va, double &vb)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double x = 0.0, pn = 0.0, pm = 0.0, pq = 0.0;
+    if (wave < 2 && lane < (wave ? cnt_b : cnt_a) && lane < kCandMax) x = ldc<COH>(cand + wave * kCandMax + lane);
+    if (static_cast<int>(threadIdx.x) < npart) { pn = ldc<COH>(a.part + 3 * threadIdx.x); pm = ldc<COH>(a.part + 3 * threadIdx.x + 1); pq = ldc<COH>(a.part + 3 * threadIdx.x + 2); }
+    return slice_std_vals(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
 }
 
 // light pass, kernel 1: tallies from the changed rows, delta1, window bookkeeping
@@ -1821,6 +1841,378 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, unsigned *bar)
     }
 }
 
+// ---------------------------------------------------------------------------
+// The light passes as TWO launches per pass.  A pass has two grid-wide dependencies (all delta1 -> se; all BH ranks ->
+// the cut), so two launches is the least without a grid barrier: the mask step of pass t (cut, inds, change list, loop
+// control) moves to the front of the launch that derives pass t + 1, and every workgroup does it for ALL genes by
+// itself -- the cut from the histogram (a few thousand bins), the new mask from the G ranks (4 G bytes from L2), the
+// change list (<= 128 entries) into LDS -- so nothing of it crosses workgroups.  The loop state is a log (LightState,
+// reo_internal.h): launch b reads slot b - 1 and the outputs of the launches before it, and only its workgroup 0 writes
+// the record of slot b; every pass has its own counters (zeroed with the log), the histogram alternates by launch parity.  The order of the change
+// list differs between workgroups (LDS atomics); it only feeds integer sums.  A batch ends with the TAIL form, which
+// does the last mask step and writes the state back to IterState for the sorting path and the host.
+// The BH cut from the first four 2048-bin tiles of the histogram, already in registers (hv[e]: bins (e * 256 + thread) * 8
+// ...+7): bh_cut for a histogram whose finite ranks number at most 8192.  Bins past the bound may hold counts; they
+// cannot qualify (H never exceeds the number of finite ranks), so no masking is needed.
+__device__ __forceinline__ int bh_cut4(const int (&hv)[4][8], int G)
+{
+    __shared__ __attribute__((aligned(16))) int wsum[4][4];
+    __shared__ int wbest[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int s[4], inc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s[e] = ((hv[e][0] + hv[e][1]) + (hv[e][2] + hv[e][3])) + ((hv[e][4] + hv[e][5]) + (hv[e][6] + hv[e][7]));
+        inc[e] = s[e];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+        { const int u = __shfl_up(inc[e], o, 64); if (lane >= o) inc[e] += u; }
+    if (lane == 63)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wsum[e][wave] = inc[e];
+    lds_barrier();
+    int best = 0, carry = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int4 ws = *reinterpret_cast<const int4 *>(wsum[e]);
+        int run = carry + inc[e] - s[e] + (wave > 0 ? ws.x : 0) + (wave > 1 ? ws.y : 0) + (wave > 2 ? ws.z : 0);
+        const int r0 = (e * 256 + threadIdx.x) * 8 + 1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { run += hv[e][u]; if (r0 + u <= G && run >= r0 + u) best = max(best, r0 + u); }
+        carry += ws.x + ws.y + ws.z + ws.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(best, o, 64); best = u > best ? u : best; }
+    if (lane == 0) wbest[wave] = best;
+    lds_barrier();
+    return max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
+}
+
+// Touch every 64-byte line of the kernel's argument block at once.  The compiler loads arguments where they are first
+// used, one scalar-cache miss after the other (measured: ~5 us from kernel start to the first vector load of kl_head);
+// after this they all hit.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs()
+{
+    const uint32_t *ka = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();  // (address-space cast: C style)
+    uint32_t t[(BYTES + 63) / 64];
+#pragma unroll
+    for (int q = 0; q < (BYTES + 63) / 64; ++q) t[q] = ka[16 * q];
+#pragma unroll
+    for (int q = 0; q < (BYTES + 63) / 64; ++q) asm volatile("" ::"s"(t[q]));
+}
+
+constexpr int kHeadPre = 20;  // rows of 256 genes per wave whose BH ranks are requested at kernel start (20 000 genes: all of them)
+
+// mrank of the two-launch form.  Layout: the word of gene 256 R + 64 c + l (row R, wave c, lane l of kl_rank) is stored at
+// 256 R + 4 l + c, so that lane l of any wave gets the words of genes (c = 0..3, l) of a row with one coalesced 16-byte
+// load.  Word: the BH rank (G + 2: the gene fails the p-value criterion) with the gene's CURRENT mask bit in bit 31, so
+// that the mask step compares per lane, with no mask words and no cross-lane traffic; padding slots of the last row
+// hold 0 (rank 0 is always inside the cut: new bit 0 = old bit).
+__device__ __forceinline__ int mrank_slot(int i) { return (i & ~255) + 4 * (i & 63) + ((i >> 6) & 3); }
+
+template <bool TAIL>
+__global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b)
+{
+    const int G = a.G, Gp = a.Gp;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t dl[kDeltaMax];
+    __shared__ int s_n, s_nn;
+    __shared__ double red[256];
+    __shared__ int wcnt[4][2];
+    warm_kernargs<sizeof(IterArgs) + 16>();
+    if (!TAIL) STAMP(a, 8);
+#ifdef REO_STAMPS
+    if (!TAIL && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[12] = __builtin_amdgcn_s_memtime();
+#endif
+    const int pb = (b - 1) & 1;
+    // ---- everything whose address does not depend on loaded data is requested first: the launch is a chain of
+    // dependent round trips otherwise (measured: 22 us with the loads where they are used, most of it waiting)
+    LightRec r;
+    int bfail = 0, sig = 0;
+    int hv[4][8];
+    int4 mv[kHeadPre];
+    int own_m = 0;
+    int4 r0 = make_int4(0, 0, 0, 0), r1 = make_int4(0, 0, 0, 0);
+    double win[4];
+    const int nrow = (G + 255) >> 8;
+    if (b > 0) {
+        const int32_t *hist = a.hist + static_cast<size_t>(pb) * a.hist_stride;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int4 *hp = reinterpret_cast<const int4 *>(hist + (e * 256 + threadIdx.x) * 8);
+            const int4 h0 = hp[0], h1 = hp[1];
+            hv[e][0] = h0.x; hv[e][1] = h0.y; hv[e][2] = h0.z; hv[e][3] = h0.w; hv[e][4] = h1.x; hv[e][5] = h1.y; hv[e][6] = h1.z; hv[e][7] = h1.w;
+        }
+#ifdef REO_SERIAL_LOADS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        if (!TAIL) STAMP(a, 9);
+#pragma unroll
+        for (int q = 0; q < kHeadPre; ++q) {
+            const int R = wave + 4 * q;
+            mv[q] = make_int4(0, 0, 0, 0);
+            if (R < nrow) mv[q] = reinterpret_cast<const int4 *>(a.mrank)[R * 64 + lane];  // wave-uniform
+        }
+#ifdef REO_SERIAL_LOADS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        if (!TAIL) STAMP(a, 10);
+        if (i < G) own_m = a.mrank[mrank_slot(i)];
+    }
+    if (!TAIL && i < G) {
+        const int4 *o = reinterpret_cast<const int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
+        r0 = o[0]; r1 = o[1];
+    }
+#ifdef REO_SERIAL_LOADS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    if (!TAIL) STAMP(a, 11);
+    if (b > 0) {  // (after the vector loads: its values are needed in scalar registers, which waits for them)
+        const LightSlot *ps = &ls->slot[b - 1];
+        r = ps->rec; bfail = ps->bfail; sig = ps->lc.sig;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) win[q] = ps->wnext[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) win[q] = a.scal[1 + q];
+    }
+    if (!TAIL) STAMP(a, 0);
+#ifdef REO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!TAIL) STAMP(a, 18);
+#endif
+    int n = 0;           // entries of dl: the genes whose mask bit changes in front of the pass derived here
+    bool inref = false;  // this thread's gene is in the reference set of that pass
+    bool stepped = false;
+    if (b == 0) {
+        const IterState *st = a.st;  // no light launch writes IterState except the TAIL
+        r.t = st->passes; r.nref = st->nref; r.nref_prev = st->nref_prev; r.done = st->done; r.need_full = st->need_full;
+        r.raw_pass = st->raw_pass; r.ran = 0; r.dcnt = st->delta_cnt[r.t & 1];
+        r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
+        if (r.active) {
+            n = r.raw_pass == r.t ? 0 : min(r.dcnt, kDeltaMax);  // (need_full == 0 implies dcnt <= kDeltaMax)
+            if (static_cast<int>(threadIdx.x) < n) dl[threadIdx.x] = a.delta_list[static_cast<size_t>(r.t & 1) * Gp + threadIdx.x];
+            inref = i < G && a.refbytes[r.t & 1][i] != 0;
+            lds_barrier();
+        }
+    } else if (r.active && bfail) {
+        r.active = 0; r.need_full = 1;  // pass r.t lost a quantile window: the sorting path redoes it (its tallies are in place)
+    } else if (r.active) {
+        // ---- the mask step of pass r.t (:413-424)
+        const int t = r.t, cur = t & 1, nxt = cur ^ 1;
+        const int kstar = sig <= 8192 ? bh_cut4(hv, G) : bh_cut<false>(a.hist + static_cast<size_t>(pb) * a.hist_stride, G, sig);
+        if (!TAIL) STAMP(a, 1);
+        if (threadIdx.x == 0) { s_n = 0; s_nn = 0; }
+        lds_barrier();
+        if (!TAIL) STAMP(a, 14);
+        // One subtract per gene: with u = its word (rank | current bit << 31) the bit changes iff kstar < u <= kstar + 2^31,
+        // i.e. iff u - (kstar + 1), as a signed number, is >= 0 (rank > kstar with the bit clear, or rank <= kstar with
+        // it set).  Changes are rare (a handful per pass): every lane reduces its rows to "how many of my rows hold a
+        // change, and the last such row", without a branch -- a taken branch over a block of cold code costs an
+        // instruction-cache miss, and a chain of twenty of them was two microseconds -- and the changed genes of that
+        // one row are then noted by the wave together.  sum(inds) follows from the old count and the changes.
+        const uint32_t base = static_cast<uint32_t>(kstar) + 1u;
+        int4 sel = make_int4(0, 0, 0, 0);
+        int selq = 0, nflag = 0;
+#pragma unroll
+        for (int q = 0; q < kHeadPre; ++q) {  // (rows past the last one hold zeros: never a change)
+            const int d0 = static_cast<int>(static_cast<uint32_t>(mv[q].x) - base), d1 = static_cast<int>(static_cast<uint32_t>(mv[q].y) - base);
+            const int d2 = static_cast<int>(static_cast<uint32_t>(mv[q].z) - base), d3 = static_cast<int>(static_cast<uint32_t>(mv[q].w) - base);
+            const bool f = max(max(d0, d1), max(d2, d3)) >= 0;
+            sel.x = f ? mv[q].x : sel.x; sel.y = f ? mv[q].y : sel.y; sel.z = f ? mv[q].z : sel.z; sel.w = f ? mv[q].w : sel.w;
+            selq = f ? q : selq;
+            nflag += f ? 1 : 0;
+        }
+        if (!TAIL) STAMP(a, 15);
+        auto note_changes = [&](bool on, int R, const int4 &m) {  // whole wave; lane l (if on): genes 256 R + 64 c + l, c = 0..3
+            const uint32_t e[4] = {static_cast<uint32_t>(m.x), static_cast<uint32_t>(m.y), static_cast<uint32_t>(m.z), static_cast<uint32_t>(m.w)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool chd = on && static_cast<int>(e[c] - base) >= 0;
+                const unsigned long long cm = __ballot(chd);
+                if (cm) {  // wave-uniform
+                    const uint32_t nb = (e[c] >> 31) ^ 1u;  // the new bit: inds = .!(pval <= pval_deg .& padj <= padj_deg), :417
+                    const unsigned long long am = __ballot(chd && nb);
+                    int pos = 0;
+                    if (lane == 0) { pos = atomicAdd(&s_n, __popcll(cm)); atomicAdd(&s_nn, 2 * __popcll(am) - __popcll(cm)); }
+                    pos = __shfl(pos, 0, 64);
+                    const int at = pos + __popcll(cm & ((1ULL << lane) - 1ULL));
+                    if (chd && at < kDeltaMax) dl[at] = (static_cast<uint32_t>(R * 256 + c * 64 + lane) << 1) | nb;
+                }
+            }
+        };
+        const bool crowded = __ballot(nflag > 1) != 0;  // a lane with changes in two rows (about one pass in fifty): the wave reads its rows again
+        if (!crowded && __ballot(nflag == 1)) note_changes(nflag == 1, wave + 4 * selq, sel);
+        if (!TAIL) STAMP(a, 16);
+#pragma unroll 1
+        for (int R = crowded ? wave : wave + 4 * kHeadPre; R < nrow; R += 4) note_changes(true, R, reinterpret_cast<const int4 *>(a.mrank)[R * 64 + lane]);
+        const bool ind = i < G && static_cast<int>(static_cast<uint32_t>(own_m) & 0x7FFFFFFFu) > kstar;
+        if (i < Gp) a.refbytes[nxt][i] = ind ? 1 : 0;
+        const unsigned long long mk = __ballot(ind);
+        if (lane == 0 && i < Gp) { a.refbits[nxt][i >> 5] = static_cast<uint32_t>(mk); a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(mk >> 32); }
+        lds_barrier();
+        if (!TAIL) STAMP(a, 17);
+        const int chg = s_n, nn = r.nref + s_nn;  // sum(inds), :417-418: the old mask's count (r.nref) + added - removed
+        if (!TAIL) STAMP(a, 2);
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) { a.trace[2 * t] = G - nn; a.trace[2 * t + 1] = nn; }
+            if (static_cast<int>(threadIdx.x) < min(chg, kDeltaMax)) a.delta_list[static_cast<size_t>(nxt) * Gp + threadIdx.x] = dl[threadIdx.x];
+        }
+        r.nref_prev = r.nref;
+        const int diff = r.nref - nn;
+        if ((diff < 0 ? -diff : diff) < a.n_conv) r.done = 1;  // :419-422
+        else r.nref = nn;                                      // :423-424
+        r.t = t + 1; r.ran = 1; r.dcnt = chg;
+        r.need_full = chg > kDeltaMax ? 1 : 0;
+        r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
+        inref = ind;
+        n = min(chg, kDeltaMax);
+        stepped = true;
+    }
+    if (TAIL) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            IterState *st = a.st;
+            st->passes = r.t; st->nref = r.nref; st->nref_prev = r.nref_prev; st->done = r.done; st->need_full = r.need_full;
+            st->i_iter = r.t - (r.done ? 1 : 0);
+            st->raw_pass = r.raw_pass;
+            st->delta_cnt[r.t & 1] = r.dcnt;
+            if (r.ran) st->last_full = 0;
+            if (stepped) { a.scal[1] = win[0]; a.scal[2] = win[1]; a.scal[3] = win[2]; a.scal[4] = win[3]; }
+        }
+        return;
+    }
+    if (r.active) r.raw_pass = r.t;  // the tallies of pass r.t are made below
+    if (blockIdx.x == 0 && threadIdx.x == 0) ls->slot[b].rec = r;
+    if (!r.active || static_cast<int>(blockIdx.x) * 256 >= G) return;
+    // ---- pass r.t: tallies from the changed rows, delta1, window bookkeeping
+    const int pbuf = b & 1;
+    LightCnt *lc = &ls->slot[b].lc;
+    const double wa_lo = win[0], wa_hi = win[1], wb_lo = win[2], wb_hi = win[3];
+    double v = 0.0;
+    bool inner = false, inA = false, inB = false, belowA = false, belowB = false;
+    if (i < G) {
+        if (n) {
+            int d[kRaw];
+            delta_counts<false, 8>(a.table, a.Wp, dl, n, i, d);
+            if (!TAIL) STAMP(a, 3);
+            r0.x += d[0]; r0.y += d[1]; r0.z += d[2]; r0.w += d[3];
+            r1.x += d[4]; r1.y += d[5]; r1.z += d[6]; r1.w += d[7];
+            int4 *o = reinterpret_cast<int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
+            o[0] = r0; o[1] = r1;
+        }
+        int32_t c[9];
+        const int total = r.nref - (inref ? 1 : 0);  // the diagonal is never set (:363,385)
+        c[0] = r1.x; c[2] = r1.y; c[6] = r1.z; c[8] = r1.w;
+        c[1] = r0.x - r1.x - r1.y; c[7] = r0.y - r1.z - r1.w; c[3] = r0.z - r1.x - r1.z; c[5] = r0.w - r1.y - r1.w;
+        c[4] = total - (r0.x + r0.y + c[3] + c[5]);
+        double out[5];
+        mccullagh3<false>(c, out);
+        v = out[1];
+        if (!TAIL) STAMP(a, 4);
+        a.result[11 * static_cast<size_t>(G) + i] = v;
+        a.hist[static_cast<size_t>(pbuf) * a.hist_stride + i] = 0;  // this launch parity's histogram: last read two launches ago
+        belowA = v < wa_lo; inA = !belowA && v <= wa_hi;
+        belowB = v < wb_lo; inB = !belowB && v <= wb_hi;
+        inner = v > wa_hi && v < wb_lo;
+    }
+    if (!TAIL) STAMP(a, 5);
+    {
+        const double nb = block_sum_256(inner ? 1.0 : 0.0, red);
+        const double sum = block_sum_256(inner ? v : 0.0, red);
+        const double mean = nb > 0.0 ? sum / nb : 0.0;
+        const double m2 = block_sum_256(inner ? (v - mean) * (v - mean) : 0.0, red);
+        if (threadIdx.x == 0) { a.part[3 * blockIdx.x] = nb; a.part[3 * blockIdx.x + 1] = mean; a.part[3 * blockIdx.x + 2] = m2; }
+    }
+    if (!TAIL) STAMP(a, 6);
+    const unsigned long long mA = __ballot(inA), mB = __ballot(inB), bA = __ballot(belowA), bB = __ballot(belowB);
+    int baseA = 0, baseB = 0;
+    if (lane == 0) {
+        if (mA) baseA = atomicAdd(&lc->cnt_a, __popcll(mA));
+        if (mB) baseB = atomicAdd(&lc->cnt_b, __popcll(mB));
+        wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
+    }
+    baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) a.cand[at] = v; }
+    if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) a.cand[kCandMax + at] = v; }
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
+        if (ba) atomicAdd(&lc->below_a, ba);
+        if (bb) atomicAdd(&lc->below_b, bb);
+    }
+    if (!TAIL) STAMP(a, 7);
+#ifdef REO_STAMPS
+    if (!TAIL && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[13] = __builtin_amdgcn_s_memtime();
+#endif
+}
+
+// second launch of a two-launch light pass: every workgroup finishes the selection for itself (slice_std), then p-values
+// (:412), BH ranks and their histogram for its genes.  A rank is stored as "never" (G + 2) when the gene fails the
+// p-value criterion of :417, so that the next launch's mask step needs the ranks only.  Like kl_head it asks for all its
+// inputs before it looks at any of them.
+__global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b)
+{
+    warm_kernargs<sizeof(IterArgs) + 16>();
+    STAMP(a, 19);
+    const int G = a.G, pbuf = b & 1;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool live = i < G;
+    LightSlot *sl = &ls->slot[b];
+    LightCnt *lc = &sl->lc;
+    const int active = sl->rec.active;
+    const int below_a = lc->below_a, below_b = lc->below_b, cnt_a = lc->cnt_a, cnt_b = lc->cnt_b;
+    const double x = wave < 2 ? a.cand[wave * kCandMax + lane] : 0.0;  // (every slot of cand exists; slots past the count are ignored)
+    double pn = 0.0, pm = 0.0, pq = 0.0;
+    if (static_cast<int>(threadIdx.x) < (G + 255) / 256) { pn = a.part[3 * threadIdx.x]; pm = a.part[3 * threadIdx.x + 1]; pq = a.part[3 * threadIdx.x + 2]; }
+    const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
+    const double d1 = live ? a.result[11 * static_cast<size_t>(G) + i] : 0.0;
+    if (!active) return;
+#ifdef REO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(a, 20);
+    __shared__ double red[256];
+    __shared__ double sel[2][4];
+    double se = 0.0, va = 0.0, vb = 0.0;
+    bool ok = slice_std_vals(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
+    ok = ok && (va + wd1 < vb - wd2);
+    STAMP(a, 21);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (ok) {
+            a.scal[0] = se;
+            sl->wnext[0] = va - wd0; sl->wnext[1] = va + wd1; sl->wnext[2] = vb - wd2; sl->wnext[3] = vb + wd3;
+        } else {
+            sl->bfail = 1;
+        }
+    }
+    if (!ok) return;
+    const double p = live ? normal_p(d1, se) : 1.0;
+    if (live) a.result[i] = p;
+    const int m = live ? bh_rank(p, G, a.padj_deg) : G + 1;
+    STAMP(a, 22);
+    {   // every slot of the row is written (the mask step reads whole rows), transposed through LDS so that each wave
+        // stores whole cache lines: rows written as scattered 4-byte pieces came back slowly in the next launch
+        __shared__ int32_t row[256];
+        const uint32_t oldbit = live && a.refbytes[sl->rec.t & 1][i] != 0 ? 0x80000000u : 0u;
+        row[4 * lane + wave] = live ? static_cast<int32_t>(static_cast<uint32_t>(p <= a.pval_deg ? m : G + 2) | oldbit) : 0;
+        lds_barrier();
+        a.mrank[blockIdx.x * 256 + threadIdx.x] = row[threadIdx.x];
+    }
+    int32_t *hist = a.hist + static_cast<size_t>(pbuf) * a.hist_stride;
+    const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
+    if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&hist[0], __popcll(first)); }
+    else if (m <= G) atomicAdd(&hist[m - 1], 1);
+    if (lane == 0 && finite) atomicAdd(&lc->sig, __popcll(finite));
+    STAMP(a, 23);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
@@ -1986,7 +2378,7 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     a.sorted_p = c->sorted_p.p; a.rank_s = c->rank_s.p; a.rank_a = c->rank_a.p;
     a.part = c->part.p; a.blockmin = c->blockmin.p; a.scal = c->scal.p;
     a.trace = c->trace.p; a.modes = nullptr;
-    a.cand = c->cand.p; a.hist = c->hist.p; a.mrank = c->mrank.p;
+    a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / 2); a.mrank = c->mrank.p;
     a.replay = replay; a.k2_idx = 0;
     a.window = c->light_window; a.light_min_g = c->light_min_g;
     a.stamps = reinterpret_cast<unsigned long long *>(c->scal.p + 32);
@@ -2039,6 +2431,22 @@ int32_t launch_light_persistent(reo_ctx *c)
     REO_HIP_CHECK(hipMemsetAsync(c->gridbar.p, 0, sizeof(unsigned), c->stream));
     REO_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char *>(c->state.p) + offsetof(IterState, pz_cnt), 0, sizeof(int32_t) * 12, c->stream));
     kl_persist<<<nwg, 256, 0, c->stream>>>(a, c->gridbar.p);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+// A batch of light passes in the two-launch form: nlight x (kl_head, kl_rank) and the tail that ends the last pass.
+int32_t launch_light_batch(reo_ctx *c, int nlight)
+{
+    const IterArgs a = iter_args(c, 0);
+    const int nb = (a.G + 255) / 256, nbp = a.Gp / 256;  // (the head writes every mask byte, padding included)
+    if (nlight < 1 || nlight > kLightBatch) { set_error("light batch of %d passes", nlight); return REO_EINVAL; }
+    REO_HIP_CHECK(hipMemsetAsync(c->lstate.p, 0, sizeof(LightState), c->stream));
+    for (int b = 0; b < nlight; ++b) {
+        kl_head<false><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, b);
+        kl_rank<<<nb, 256, 0, c->stream>>>(a, c->lstate.p, b);
+    }
+    kl_head<true><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, nlight);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

@@ -47,6 +47,34 @@ struct IterState {
     int32_t pad[2];
 };
 
+// Light passes as two launches per pass (kernels.hip, kl_head / kl_rank): the loop state of one batch of launches as an
+// append-only log, so that no kernel reads a word that another workgroup of the same launch writes.  rec[b] = the state
+// in front of light pass b of the batch (rec of slot nlight: behind the last one), written by workgroup 0 of launch b,
+// read by the launches after it.
+constexpr int kLightBatch = 32;  // light passes per batch of launches
+struct LightRec {
+    int32_t active;     // pass `t` is to run as a light pass
+    int32_t t;          // passes executed so far = index of the next pass
+    int32_t nref, nref_prev, done, need_full, raw_pass;  // as in IterState
+    int32_t ran;        // a light pass of this batch has been completed
+    int32_t dcnt;       // genes whose mask bit changed in front of pass t
+};                      // (no padding array inside: copying one through registers made the compiler keep it in LDS, indexed by a
+                        //  thread id that it computed from the dispatch packet -- a 3 us read of host memory at kernel start)
+struct LightCnt { int32_t cnt_a, cnt_b, below_a, below_b, sig, pad[3]; };  // window bookkeeping + genes with a finite BH rank
+// everything the launches after pass b of a batch need of it, in one block (one load): rec = the state in FRONT of pass
+// b; the rest is made by pass b itself.  Zeroed by the host in front of the batch.
+struct LightSlot {
+    LightRec rec;
+    int32_t pad0[7];
+    LightCnt lc;
+    int32_t bfail;      // pass b lost a quantile window: it is redone on the sorting path
+    int32_t pad[7];
+    double wnext[4];    // quantile windows for the pass after pass b
+    double pad2[4];
+};
+struct LightState { LightSlot slot[kLightBatch + 2]; };
+static_assert(sizeof(LightSlot) == 192, "LightSlot layout");
+
 void set_error(const char *fmt, ...);
 
 #define REO_HIP_CHECK(expr)                                                              \
@@ -161,9 +189,10 @@ struct reo_ctx {
     reo::DevBuf<int32_t> modes;         // [K2 launches] 1 = the launch scanned the whole table, 0 = incremental update or skipped
     reo::DevBuf<double> cand;           // [2 parities][2 windows][64] light passes: values inside the quantile windows
     reo::DevBuf<unsigned> gridbar;      // [1] arrival counter of the persistent light kernel's grid barrier
+    reo::DevBuf<reo::LightState> lstate;  // [1] batch log of the two-launch light passes
     int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
-    int light_mode = 1;                 // 0 sorting passes only, 1 light passes as three launches each, 2 as one persistent launch (REO_LIGHT)
-    reo::DevBuf<int32_t> hist, mrank;   // [G padded to whole 1024-bin tiles], [G] light passes: histogram of the BH ranks, the ranks
+    int light_mode = 3;                 // 0 sorting passes only, 1 light passes as three launches each, 2 as one persistent launch, 3 as two launches each (REO_LIGHT)
+    reo::DevBuf<int32_t> hist, mrank;   // [2][G padded to whole 32768-bin rounds], [Gp] light passes: histogram of the BH ranks (by launch parity), the ranks
     // parameters of the running reo_identify_degs call (kernels.hip, iter_args)
     double it_pval_deg = 1.0, it_padj_deg = 0.05;
     int it_n_iter = 0, it_n_conv = 0, it_a0 = 0, it_b0 = 0;
@@ -194,6 +223,7 @@ int32_t launch_tally(reo_ctx *c, int nref);
 int32_t launch_full_pass(reo_ctx *c, bool replay);
 int32_t launch_light_pass(reo_ctx *c);
 int32_t launch_light_persistent(reo_ctx *c);
+int32_t launch_light_batch(reo_ctx *c, int nlight);
 int32_t light_min_genes();
 int32_t light_window();
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
