@@ -257,7 +257,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->device = device;
     c->seed = seed;
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
-    if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 3));
+    if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
     c->light_window = light_window(); c->light_min_g = light_min_genes();
     if (const char *e = getenv("REO_LIGHT_WINDOW")) c->light_window = std::max(1, std::min(31, atoi(e)));  // 2 W + 1 <= 64 window members
     if (const char *e = getenv("REO_LIGHT_MIN_G")) c->light_min_g = std::max(64, atoi(e));
@@ -542,11 +542,8 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
             if ((rc = launch_full_pass(c, false))) return rc;
         if (nlight > 0 && c->light_mode == 2) {
             if ((rc = launch_light_persistent(c))) return rc;  // runs light passes until the state stops them
-        } else if (nlight > 0 && c->light_mode == 3) {
+        } else if (nlight > 0) {
             if ((rc = launch_light_batch(c, nlight))) return rc;
-        } else {
-            for (int t = 0; t < nlight; ++t)
-                if ((rc = launch_light_pass(c))) return rc;
         }
         toc(c);
         REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
@@ -576,26 +573,18 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         c->k2_modes.assign(c->k2_idx, 0);
         REO_HIP_CHECK(hipMemcpyAsync(c->k2_modes.data(), c->modes.p, sizeof(int32_t) * nk2, hipMemcpyDeviceToHost, c->stream));
     }
-    if (getenv("REO_DEBUG_STAMPS")) {  // diagnostic builds (-DREO_STAMPS): marks of the last light pass, 10 ns units
+    if (getenv("REO_DEBUG_STAMPS")) {  // diagnostic builds (-DREO_STAMPS): marks of workgroup 0 in the last light launches, 10 ns units
         unsigned long long st[24];
         REO_HIP_CHECK(hipMemcpy(st, c->scal.p + 32, sizeof st, hipMemcpyDeviceToHost));
-        fprintf(stderr, "stamps kl_head (loads issued, cut, mask scan, deltas, delta1, window flags, block sums, end):");
-        for (int k = 0; k <= 7; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[8]));
-        fprintf(stderr, "  [scan from cut: barrier %lld, row maxima %lld, changes %lld, own bit + barrier %lld]", (long long)(st[14] - st[1]), (long long)(st[15] - st[1]), (long long)(st[16] - st[1]), (long long)(st[17] - st[1]));
-        fprintf(stderr, "  [all loads back %lld]", (long long)(st[18] - st[8]));
-        fprintf(stderr, "  [shader clock %.0f MHz]", (double)(st[13] - st[12]) / ((double)(st[7] - st[8]) * 0.01));
-        fprintf(stderr, "  [prologue: hist asked %lld, ranks asked %lld, raw asked %lld]", (long long)(st[9] - st[8]), (long long)(st[10] - st[8]), (long long)(st[11] - st[8]));
-        fprintf(stderr, "\nstamps kl_rank (loads back, selection + se, p + BH rank, end):");
-        for (int k = 20; k <= 23; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[19]));
-        fprintf(stderr, "\nstamps persistent (phase1 B1 phase2 B2 [cut] phase3 B3):");
-        fprintf(stderr, " %lld %lld %lld %lld [%lld] %lld %lld |", (long long)(st[1] - st[0]), (long long)(st[2] - st[1]), (long long)(st[3] - st[2]),
-                (long long)(st[4] - st[3]), (long long)(st[7] - st[4]), (long long)(st[5] - st[4]), (long long)(st[6] - st[5]));
-        fprintf(stderr, " kl_pvalues:");
-        for (int k = 1; k <= 6; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[0]));
-        fprintf(stderr, "  kl_mask:");
-        for (int k = 9; k <= 11; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[8]));
-        fprintf(stderr, "  kl_derive:");
-        for (int k = 14; k <= 17; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[13]));
+        if (c->light_mode == 2) {
+            fprintf(stderr, "stamps kl_persist, one pass (phase 1, barrier, phase 2, barrier, loads asked, cut, mask step):");
+            for (int k = 1; k <= 7; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[0]));
+        } else {
+            fprintf(stderr, "stamps kl_head (inputs back, cut, mask step, changed rows, delta1, window flags, block sums, end):");
+            for (int k = 0; k <= 7; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[8]));
+            fprintf(stderr, "\nstamps kl_rank (inputs back, selection + se, p + BH rank, end):");
+            for (int k = 20; k <= 23; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[19]));
+        }
         fprintf(stderr, "  (x 10 ns)\n");
     }
     if (iters_run) *iters_run = passes;

@@ -833,13 +833,6 @@ __device__ __forceinline__ bool full_pass_active(const IterArgs &a, int &t, int 
     return !st->done && st->passes < a.n_iter && st->need_full;
 }
 
-__device__ __forceinline__ bool light_pass_active(const IterArgs &a, int &t)
-{
-    const IterState *st = a.st;
-    t = st->passes;
-    return !st->done && st->passes < a.n_iter && !st->need_full;
-}
-
 // The K2 stage of a sorting pass: one launch, the device picks the form (whole-table scan, or update from the rows
 // of the genes whose mask bit changed).  Skipped when a light pass has already brought the counters up to date.
 __global__ __launch_bounds__(256) void k2_tally(IterArgs a)
@@ -980,6 +973,18 @@ __device__ __forceinline__ double block_sum_256(double v, double *red)
     const double r = (red[0] + red[1]) + (red[2] + red[3]);
     lds_barrier();
     return r;
+}
+
+// two sums at once (the same bits as two calls of block_sum_256: the same operations in the same order on each value)
+__device__ __forceinline__ void block_sum2_256(double v, double w, double *red, double &rv, double &rw)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double pv = __shfl_xor(v, o, 64), pw = __shfl_xor(w, o, 64); v += pv; w += pw; }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v; red[4 + (threadIdx.x >> 6)] = w; }
+    lds_barrier();
+    rv = (red[0] + red[1]) + (red[2] + red[3]);
+    rw = (red[4] + red[5]) + (red[6] + red[7]);
+    lds_barrier();
 }
 
 // ---- ranking: the sort of :409 and the order BH needs (:413) ---------------
@@ -1225,13 +1230,13 @@ __global__ __launch_bounds__(1024) void k3_bh_local(IterArgs a)
     if (threadIdx.x == 0) a.blockmin[blockIdx.x] = v;
 }
 
-// The end of a pass, shared by the sorting path (k3_finalize) and the light path (kl_mask): the non-DEG mask
+// The end of a sorting pass (k3_finalize): the non-DEG mask
 // inds (:417) of gene i as bytes and bits for the next pass, the list of genes whose mask bit changes (the next
 // pass updates its tallies from their rows alone, delta_genes), and -- by the last workgroup to finish -- the loop
 // control of :418-424 on the device-side iteration state.  Every thread of the grid (Gp threads) must call it.
 // Returns -1 except in thread 0 of the last workgroup, where it returns 1 when more genes changed than a tally
 // update can take (the next pass must scan the table) and 0 otherwise; that thread then sets st->need_full.
-__device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, bool ind, bool light)
+__device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, bool ind)
 {
     IterState *st = a.st;
     const int cur = t & 1, nxt = 1 - cur;
@@ -1275,7 +1280,7 @@ __device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, boo
         st->i_iter += 1;    // :423
         st->nref = nn;      // ref_gene_vec = inds, :424
     }
-    st->last_full = light ? 0 : 1;
+    st->last_full = 1;
     st->nn_acc = 0;
     st->ticket = 0;
     return atomicAdd(&st->delta_cnt[nxt], 0) > kDeltaMax ? 1 : 0;
@@ -1312,7 +1317,7 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
         ind = !(a.result[i] <= a.pval_deg && q <= a.padj_deg);
     }
     if (a.replay) return;
-    const int over = publish_mask(a, t, i, ind, false);
+    const int over = publish_mask(a, t, i, ind);
     if (over < 0) return;
     // quantile windows: the values kWindow ranks on either side of the slice bounds, kept as widths around the
     // exact quantiles so that a light pass can re-centre them on its own quantiles
@@ -1327,45 +1332,69 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
         a.scal[5] = va - wa_lo; a.scal[6] = wa_hi - va; a.scal[7] = vb - wb_lo; a.scal[8] = wb_hi - vb;
     }
     a.st->need_full = (over || !ok) ? 1 : 0;
-    a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0; a.st->sig_cnt = 0;  // a light pass may have failed half-way
 }
 
 // ---------------------------------------------------------------------------
 // Light passes.  A pass needs three things of the G values delta1: the trimmed standard deviation (:409-411), the
 // BH decision padj <= padj_deg (:413,417) and the counts of :418 -- none of which needs the sorted vector:
 //  * the slice bounds are two order statistics.  From one pass to the next delta1 moves little, so the values that
-//    can hold rank a0 (b0) are those inside a narrow window around the previous pass's quantile: kl_derive counts
-//    the values below each window, collects the few hundred inside, and its last workgroup sorts just those, reads
+//    can hold rank a0 (b0) are those inside a narrow window around the previous pass's quantile: the pass counts
+//    the values below each window, collects the (at most 64) values inside, and every workgroup sorts just those, reads
 //    the exact order statistics off them and combines the slice's moments (block partials of the values strictly
 //    between the windows + the window values inside the slice).  A window that fails to hold its order statistic
-//    makes the pass fall back to the sorting path (st->need_full);
+//    makes the pass fall back to the sorting path;
 //  * BH: with m_i = min{r : p_i (n/r) <= padj_deg} (the same floating-point expression as the step-up rule) and
 //    H(r) = #{i : m_i <= r}, the rule's cut is k* = max{r : H(r) >= r} and padj_i <= padj_deg <=> m_i <= k*:
 //    a histogram and one scan instead of a sort (proof in DESIGN.md).
 // Only the pass that ends the loop needs padj values and the other output columns: they are recomputed from its
-// tallies by the sorting path (replay).  Three kernels per pass instead of seven, none of them searching or sorting
-// G values.
+// tallies by the sorting path (replay).  Two launches per pass (kl_head, kl_rank) instead of seven, or one persistent
+// launch (kl_persist); none of them searches or sorts G values.
 
-// Bitonic sort of the 64 doubles a wave holds (one per lane), ascending by lane: 21 shuffle stages, no LDS, no barrier.
+// Value of lane (l ^ J): quad permutes (DPP, no LDS traffic) for J = 1, 2; ds_swizzle (no address register) for
+// J = 4, 8, 16; ds_bpermute for 32.  __shfl_xor always takes the last route (two dependent LDS round trips per double);
+// the 21 stages of the sort below were 2.2 us of kl_rank that way.
+template <int J>
+__device__ __forceinline__ int lane_xor_b32(int v)
+{
+    if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (J < 32) return __builtin_amdgcn_ds_swizzle(v, (J << 10) | 0x1F);          // bit mode: and 0x1F, or 0, xor J
+    else return __shfl_xor(v, J, 64);
+}
+template <int J>
+__device__ __forceinline__ double lane_xor(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = lane_xor_b32<J>(static_cast<int>(b)), hi = lane_xor_b32<J>(static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+// Bitonic sort of the 64 doubles a wave holds (one per lane), ascending by lane: 21 compare-exchange stages, no barrier.
+template <int K, int J>
+__device__ __forceinline__ void sort_stage(double &x, int t)
+{
+    const bool up = (t & K) == 0 || K == 64;
+    const bool keep_min = ((t & J) == 0) == up;
+    const double px = lane_xor<J>(x);
+    const bool take = ((px < x) & keep_min) | ((px > x) & !keep_min);  // (bitwise: the ?: form became divergent branches to far-away blocks)
+    x = take ? px : x;
+}
 __device__ __forceinline__ double sort64(double x)
 {
     const int t = threadIdx.x & 63;
-    for (int k = 2; k <= 64; k <<= 1) {
-        const bool up = (t & k) == 0 || k == 64;
-        for (int j = k >> 1; j >= 1; j >>= 1) {
-            const bool keep_min = ((t & j) == 0) == up;
-            const double px = __shfl_xor(x, j, 64);
-            if (keep_min ? (px < x) : (px > x)) x = px;
-        }
-    }
+    sort_stage<2, 1>(x, t);
+    sort_stage<4, 2>(x, t); sort_stage<4, 1>(x, t);
+    sort_stage<8, 4>(x, t); sort_stage<8, 2>(x, t); sort_stage<8, 1>(x, t);
+    sort_stage<16, 8>(x, t); sort_stage<16, 4>(x, t); sort_stage<16, 2>(x, t); sort_stage<16, 1>(x, t);
+    sort_stage<32, 16>(x, t); sort_stage<32, 8>(x, t); sort_stage<32, 4>(x, t); sort_stage<32, 2>(x, t); sort_stage<32, 1>(x, t);
+    sort_stage<64, 32>(x, t); sort_stage<64, 16>(x, t); sort_stage<64, 8>(x, t); sort_stage<64, 4>(x, t); sort_stage<64, 2>(x, t); sort_stage<64, 1>(x, t);
     return x;
 }
 
-// sum over the 64 lanes of a wave, the same bits in every lane (xor butterfly)
+// sum over the 64 lanes of a wave, the same bits in every lane (xor butterfly, 32 first)
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += lane_xor<32>(v); v += lane_xor<16>(v); v += lane_xor<8>(v); v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);
     return v;
 }
 
@@ -1476,8 +1505,9 @@ __device__ __forceinline__ bool slice_std_vals(const IterArgs &a, double x, doub
     }
     // Chan's combination of the block partials (the same bits in every thread of every workgroup; one partial per
     // thread); its barriers also publish sel
-    double n0 = block_sum_256(pn, red);
-    double mean0 = block_sum_256(pn * pm, red) / n0;
+    double n0, mean0;
+    block_sum2_256(pn, pn * pm, red, n0, mean0);
+    mean0 /= n0;
     double q0 = block_sum_256(pq + pn * (pm - mean0) * (pm - mean0), red);
     va = sel[0][0]; vb = sel[1][0];
     const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
@@ -1500,345 +1530,6 @@ __device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand,
     if (wave < 2 && lane < (wave ? cnt_b : cnt_a) && lane < kCandMax) x = ldc<COH>(cand + wave * kCandMax + lane);
     if (static_cast<int>(threadIdx.x) < npart) { pn = ldc<COH>(a.part + 3 * threadIdx.x); pm = ldc<COH>(a.part + 3 * threadIdx.x + 1); pq = ldc<COH>(a.part + 3 * threadIdx.x + 2); }
     return slice_std_vals(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
-}
-
-// light pass, kernel 1: tallies from the changed rows, delta1, window bookkeeping
-__global__ __launch_bounds__(256) void kl_derive(IterArgs a)
-{
-    int t;
-    if (!light_pass_active(a, t)) return;
-    IterState *st = a.st;
-    const int G = a.G, cur = t & 1;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) {
-        st->delta_cnt[1 - cur] = 0;  // kl_mask of this pass fills that list
-        st->raw_pass = t;
-    }
-    STAMP(a, 13);
-    __shared__ double red[256];
-    __shared__ int wcnt[4][2];
-    const double wa_lo = a.scal[1], wa_hi = a.scal[2], wb_lo = a.scal[3], wb_hi = a.scal[4];
-    double v = 0.0;
-    bool inner = false, inA = false, inB = false, belowA = false, belowB = false;
-    if (i < G) {
-        delta_gene(a.table, a.Wp, a.delta_list + static_cast<size_t>(cur) * a.Gp, st->delta_cnt[cur], a.raw, i);
-        STAMP(a, 14);
-        int32_t c[9];
-        tallies_of(a.raw, a.refbytes[cur][i] != 0, st->nref, i, c);
-        double o[5];
-        mccullagh3<false>(c, o);
-        v = o[1];
-        STAMP(a, 15);
-        a.result[11 * static_cast<size_t>(G) + i] = v;
-        a.hist[i] = 0;  // bins G .. of the padded histogram are never touched (zeroed once per call)
-        belowA = v < wa_lo; inA = !belowA && v <= wa_hi;
-        belowB = v < wb_lo; inB = !belowB && v <= wb_hi;
-        inner = v > wa_hi && v < wb_lo;
-    }
-    // block partial moments of the values strictly between the windows (always inside the slice)
-    {
-        const double nb = block_sum_256(inner ? 1.0 : 0.0, red);
-        const double sum = block_sum_256(inner ? v : 0.0, red);
-        const double mean = nb > 0.0 ? sum / nb : 0.0;
-        const double m2 = block_sum_256(inner ? (v - mean) * (v - mean) : 0.0, red);
-        if (threadIdx.x == 0) { a.part[3 * blockIdx.x] = nb; a.part[3 * blockIdx.x + 1] = mean; a.part[3 * blockIdx.x + 2] = m2; }
-    }
-    STAMP(a, 16);
-    // counts below the windows and the window members (one atomic per wave each)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long mA = __ballot(inA), mB = __ballot(inB), bA = __ballot(belowA), bB = __ballot(belowB);
-    int baseA = 0, baseB = 0;
-    if (lane == 0) {
-        if (mA) baseA = atomicAdd(&st->cnt_a, __popcll(mA));
-        if (mB) baseB = atomicAdd(&st->cnt_b, __popcll(mB));
-        wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
-    }
-    baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
-    const unsigned long long lt = (1ULL << lane) - 1ULL;
-    if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) a.cand[at] = v; }
-    if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) a.cand[kCandMax + at] = v; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
-        if (ba) atomicAdd(&st->below_a, ba);
-        if (bb) atomicAdd(&st->below_b, bb);
-    }
-    STAMP(a, 17);
-}
-
-// light pass, kernel 2: every workgroup finishes the selection for itself (the two order statistics and the slice
-// moments from the window members and the block partials: a few hundred values), then p-values (:412), BH ranks
-// m_i and their histogram for its genes.  Workgroup 0 also publishes se, the next windows, or the failure.
-__global__ __launch_bounds__(256) void kl_pvalues(IterArgs a)
-{
-    int t;
-    if (!light_pass_active(a, t)) return;
-    IterState *st = a.st;
-    const int G = a.G;
-    __shared__ double red[256];
-    __shared__ double sel[2][4];  // per window: order statistic, count, mean, M2 of its members inside the slice
-    double se = 0.0, va = 0.0, vb = 0.0;
-    bool ok = slice_std<false>(a, a.cand, (G + 255) / 256, st->below_a, st->below_b, st->cnt_a, st->cnt_b, sel, red, se, va, vb);
-    ok = ok && (va + a.scal[6] < vb - a.scal[7]);  // (holds for G >= kLightMinG)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (ok) {
-            a.scal[0] = se;
-            // windows for the next light pass: the same widths around this pass's quantiles (9..12: read by no kernel
-            // of this pass; kl_mask's last workgroup moves them to 1..4)
-            a.scal[9] = va - a.scal[5]; a.scal[10] = va + a.scal[6]; a.scal[11] = vb - a.scal[7]; a.scal[12] = vb + a.scal[8];
-        } else {
-            st->need_full = 1;  // a window lost its order statistic: this pass runs on the sorting path (tallies are up to date)
-        }
-    }
-    if (!ok) return;
-    STAMP(a, 4);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < G;
-    const double p = live ? normal_p(a.result[11 * static_cast<size_t>(G) + i], se) : 1.0;
-    if (live) a.result[i] = p;
-    const int m = live ? bh_rank(p, G, a.padj_deg) : G + 1;
-    STAMP(a, 5);
-    if (live) a.mrank[i] = m;
-    // bin m - 1.  Strongly significant genes all have m = 1: one atomic per wave for that bin, not one per gene
-    // (thousands of adds to one word serialise at about 12 ns each)
-    const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
-    if (m == 1) { if ((threadIdx.x & 63) == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&a.hist[0], __popcll(first)); }
-    else if (m <= G) atomicAdd(&a.hist[m - 1], 1);
-    if ((threadIdx.x & 63) == 0 && finite) atomicAdd(&st->sig_cnt, __popcll(finite));  // bounds kl_mask's scan for the cut
-    STAMP(a, 6);
-}
-
-// light pass, kernel 3: every workgroup finds the BH cut k* = max{r in 1..G : H(r) >= r} (H = running sum of the
-// histogram: 4 G bytes, read coalesced) for itself, then inds (:417) from p and the cut, mask, change list, loop
-// control (:418-424).
-__global__ __launch_bounds__(256) void kl_mask(IterArgs a)
-{
-    int t;
-    if (!light_pass_active(a, t)) return;
-    const int G = a.G;
-    STAMP(a, 8);
-    const int kstar = bh_cut<false>(a.hist, G, a.st->sig_cnt);
-    STAMP(a, 9);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    bool ind = false;
-    if (i < G) ind = !(a.result[i] <= a.pval_deg && a.mrank[i] <= kstar);
-    STAMP(a, 10);
-    const int over = publish_mask(a, t, i, ind, true);
-    STAMP(a, 11);
-    if (over < 0) return;
-    a.st->need_full = over;
-    a.scal[1] = a.scal[9]; a.scal[2] = a.scal[10]; a.scal[3] = a.scal[11]; a.scal[4] = a.scal[12];
-    a.st->below_a = 0; a.st->below_b = 0; a.st->cnt_a = 0; a.st->cnt_b = 0; a.st->sig_cnt = 0;
-}
-
-
-// ---------------------------------------------------------------------------
-// The light passes as ONE persistent launch.  Thread i owns gene i for the whole launch: its tally counters, mask bit,
-// delta1, p-value and BH rank stay in registers from pass to pass, and the three global dependencies of a pass (all
-// delta1 -> se; all p -> the BH cut; all mask bits -> the change list and the counts of :418) are grid barriers instead
-// of kernel boundaries.  ceil(G / 256) <= 256 workgroups of 256 threads: all resident on the 256 CUs.
-//
-// Grid barrier: one monotonic counter (zeroed by the host before the launch); every wave drains its stores
-// (s_waitcnt vmcnt(0)), the workgroup meets, lane 0 adds one and polls with sc1 loads until every workgroup of the round
-// has arrived, the workgroup meets again.  No fences: everything that crosses workgroups is stored and loaded through
-// ldc / stc (sc1) or is an agent-scope atomic; measured 2.3 us per round with 80 workgroups against 4.6 us with a
-// release / acquire fence pair (tools/microbench_gridbar.hip).  Every spin is bounded (about 0.5 s): on expiry the
-// workgroup raises st->fault and leaves, and so do the others at their next barrier, so the grid always drains.
-__device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned nwg, unsigned &gen, int *fault)
-{
-    __shared__ int ok_s;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        ++gen;
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = gen * nwg;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-        int ok = 1;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull || __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-        ok_s = ok;
-    }
-    __syncthreads();
-    return ok_s != 0;
-}
-
-__global__ __launch_bounds__(256) void kl_persist(IterArgs a, unsigned *bar)
-{
-    IterState *st = a.st;
-    // the state as the previous launch left it (a kernel boundary: plain loads)
-    int t = st->passes, nref = st->nref, nref_prev = st->nref_prev;
-    if (st->done || t >= a.n_iter || st->need_full || st->fault) return;  // the same in every workgroup
-    const int G = a.G, Gp = a.Gp;
-    const unsigned nwg = gridDim.x;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ double red[256];
-    __shared__ double sel[2][4];
-    __shared__ int wcnt[4][3];
-    // this thread's gene: tally counters, mask bit; the quantile windows and their widths
-    int rw[kRaw] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool inref = false;
-    if (live) {
-        const int4 r0 = reinterpret_cast<const int4 *>(a.raw)[2 * i], r1 = reinterpret_cast<const int4 *>(a.raw)[2 * i + 1];
-        rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w; rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
-        inref = a.refbytes[t & 1][i] != 0;
-    }
-    double wa_lo = a.scal[1], wa_hi = a.scal[2], wb_lo = a.scal[3], wb_hi = a.scal[4];
-    const double da_lo = a.scal[5], da_hi = a.scal[6], db_lo = a.scal[7], db_hi = a.scal[8];
-    double d1 = 0.0, p = 1.0;
-    unsigned gen = 0;
-    int executed = 0, done = 0, need_full = 0, raw_pass = t - 1;
-    bool alive = true;
-    while (alive) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        STAMP(a, 0);
-        // ---------------- phase 1: tallies from the changed rows, delta1, window bookkeeping
-        const int n = ldc<true>(&st->delta_cnt[cur]);
-        bool inner = false, inA = false, inB = false, belowA = false, belowB = false;
-        if (live) {
-            int d[kRaw];
-            delta_counts<true>(a.table, a.Wp, a.delta_list + static_cast<size_t>(cur) * Gp, n, i, d);
-#pragma unroll
-            for (int q = 0; q < kRaw; ++q) rw[q] += d[q];
-            int32_t c[9];
-            const int total = nref - (inref ? 1 : 0);
-            c[0] = rw[4]; c[2] = rw[5]; c[6] = rw[6]; c[8] = rw[7];
-            c[1] = rw[0] - rw[4] - rw[5]; c[7] = rw[1] - rw[6] - rw[7]; c[3] = rw[2] - rw[4] - rw[6]; c[5] = rw[3] - rw[5] - rw[7];
-            c[4] = total - (rw[0] + rw[1] + c[3] + c[5]);
-            double o[5];
-            mccullagh3<false>(c, o);
-            d1 = o[1];
-            stc<true>(a.hist + i, 0);
-            belowA = d1 < wa_lo; inA = !belowA && d1 <= wa_hi;
-            belowB = d1 < wb_lo; inB = !belowB && d1 <= wb_hi;
-            inner = d1 > wa_hi && d1 < wb_lo;
-        }
-        raw_pass = t;
-        {
-            const double nb = block_sum_256(inner ? 1.0 : 0.0, red);
-            const double sum = block_sum_256(inner ? d1 : 0.0, red);
-            const double mean = nb > 0.0 ? sum / nb : 0.0;
-            const double m2 = block_sum_256(inner ? (d1 - mean) * (d1 - mean) : 0.0, red);
-            if (threadIdx.x == 0) { stc<true>(a.part + 3 * blockIdx.x, nb); stc<true>(a.part + 3 * blockIdx.x + 1, mean); stc<true>(a.part + 3 * blockIdx.x + 2, m2); }
-        }
-        double *cand = a.cand + static_cast<size_t>(cur) * 2 * kCandMax;
-        {
-            const unsigned long long mA = __ballot(inA), mB = __ballot(inB), bA = __ballot(belowA), bB = __ballot(belowB);
-            int baseA = 0, baseB = 0;
-            if (lane == 0) {
-                if (mA) baseA = atomicAdd(&st->pz_cnt[cur][0], __popcll(mA));
-                if (mB) baseB = atomicAdd(&st->pz_cnt[cur][1], __popcll(mB));
-                wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
-            }
-            baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
-            const unsigned long long lt = (1ULL << lane) - 1ULL;
-            if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) stc<true>(cand + at, d1); }
-            if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) stc<true>(cand + kCandMax + at, d1); }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
-                if (ba) atomicAdd(&st->pz_below[cur][0], ba);
-                if (bb) atomicAdd(&st->pz_below[cur][1], bb);
-            }
-        }
-        STAMP(a, 1);
-        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
-        STAMP(a, 2);
-        // ---------------- phase 2: se, p-values, BH ranks and their histogram
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            // every workgroup is past its last look at the other parity's counters and at the change count of the pass before
-            stc<true>(&st->delta_cnt[nxt], 0);
-            stc<true>(&st->pz_cnt[nxt][0], 0); stc<true>(&st->pz_cnt[nxt][1], 0);
-            stc<true>(&st->pz_below[nxt][0], 0); stc<true>(&st->pz_below[nxt][1], 0);
-            stc<true>(&st->pz_nn[nxt], 0); stc<true>(&st->pz_sig[nxt], 0);
-        }
-        double se, va, vb;
-        const bool ok = slice_std<true>(a, cand, static_cast<int>(nwg), ldc<true>(&st->pz_below[cur][0]), ldc<true>(&st->pz_below[cur][1]), ldc<true>(&st->pz_cnt[cur][0]),
-                                        ldc<true>(&st->pz_cnt[cur][1]), sel, red, se, va, vb) && true;
-        const bool wok = ok && (va + da_hi < vb - db_lo);
-        if (!wok) { need_full = 1; break; }  // the same in every workgroup: this pass runs on the sorting path (the tallies are up to date)
-        int m = G + 1;
-        if (live) {
-            p = normal_p(d1, se);
-            m = bh_rank(p, G, a.padj_deg);
-        }
-        {
-            const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
-            if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&a.hist[0], __popcll(first)); }
-            else if (m <= G) atomicAdd(&a.hist[m - 1], 1);
-            if (lane == 0 && finite) atomicAdd(&st->pz_sig[cur], __popcll(finite));  // bounds the scan for the cut
-        }
-        STAMP(a, 3);
-        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
-        STAMP(a, 4);
-        // ---------------- phase 3: the BH cut, inds (:417), mask, change list
-        const int kstar = bh_cut<true>(a.hist, G, ldc<true>(&st->pz_sig[cur]));
-        STAMP(a, 7);
-        const bool ind = live && !(p <= a.pval_deg && m <= kstar);
-        if (i < Gp) a.refbytes[nxt][i] = ind ? 1 : 0;  // (read again only by this thread, and by later launches)
-        {
-            const bool changed = live && ind != inref;
-            const unsigned long long cm = __ballot(changed);
-            if (cm) {
-                int basepos = 0;
-                if (lane == 0) basepos = atomicAdd(&st->delta_cnt[nxt], __popcll(cm));
-                basepos = __shfl(basepos, 0, 64);
-                const int at = basepos + __popcll(cm & ((1ULL << lane) - 1ULL));
-                if (changed && at < kDeltaMax) stc<true>(a.delta_list + static_cast<size_t>(nxt) * Gp + at, (static_cast<uint32_t>(i) << 1) | (ind ? 1u : 0u));
-            }
-            const unsigned long long mk = __ballot(ind);
-            if (lane == 0) {
-                if (i < Gp) { a.refbits[nxt][i >> 5] = static_cast<uint32_t>(mk); a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(mk >> 32); }
-                wcnt[wave][2] = __popcll(mk);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int nn_blk = wcnt[0][2] + wcnt[1][2] + wcnt[2][2] + wcnt[3][2];
-                if (nn_blk) atomicAdd(&st->pz_nn[cur], nn_blk);
-            }
-        }
-        STAMP(a, 5);
-        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
-        STAMP(a, 6);
-        // ---------------- the loop control of :418-424, by every workgroup for itself
-        const int nn = ldc<true>(&st->pz_nn[cur]);
-        const int chg = ldc<true>(&st->delta_cnt[nxt]);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            a.trace[2 * t] = G - nn; a.trace[2 * t + 1] = nn;
-            // the quantile windows of the next light pass: the same widths around this pass's quantiles
-            stc<true>(a.scal + 0, se); stc<true>(a.scal + 1, va - da_lo); stc<true>(a.scal + 2, va + da_hi); stc<true>(a.scal + 3, vb - db_lo); stc<true>(a.scal + 4, vb + db_hi);
-        }
-        wa_lo = va - da_lo; wa_hi = va + da_hi; wb_lo = vb - db_lo; wb_hi = vb + db_hi;
-        nref_prev = nref;
-        const int diff = nref - nn;
-        if ((diff < 0 ? -diff : diff) < a.n_conv) done = 1;  // :419-422
-        else nref = nn;                                       // :423-424
-        inref = ind;
-        ++t; ++executed;
-        if (chg > kDeltaMax) need_full = 1;
-        if (done || t >= a.n_iter || need_full) break;
-    }
-    // ---------------- hand the state back to the launches that follow
-    if (live) {
-        reinterpret_cast<int4 *>(a.raw)[2 * i] = make_int4(rw[0], rw[1], rw[2], rw[3]);
-        reinterpret_cast<int4 *>(a.raw)[2 * i + 1] = make_int4(rw[4], rw[5], rw[6], rw[7]);
-        a.result[11 * static_cast<size_t>(G) + i] = d1;
-        a.result[i] = p;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->passes = t; st->nref = nref; st->nref_prev = nref_prev; st->done = done; st->need_full = need_full;
-        st->i_iter = t - (done ? 1 : 0);
-        st->raw_pass = raw_pass;
-        if (executed) st->last_full = 0;
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1914,6 +1605,65 @@ constexpr int kHeadPre = 20;  // rows of 256 genes per wave whose BH ranks are r
 // hold 0 (rank 0 is always inside the cut: new bit 0 = old bit).
 __device__ __forceinline__ int mrank_slot(int i) { return (i & ~255) + 4 * (i & 63) + ((i >> 6) & 3); }
 
+// lane l's four words of row R of mrank (COH: coherent 8-byte loads, for the persistent kernel)
+template <bool COH>
+__device__ __forceinline__ int4 load_rank_row(const int32_t *mrank, int R, int lane)
+{
+    if (!COH) return reinterpret_cast<const int4 *>(mrank)[R * 64 + lane];
+    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(mrank) + (static_cast<size_t>(R) * 64 + lane) * 2;
+    const unsigned long long lo = ldc<true>(p), hi = ldc<true>(p + 1);
+    return make_int4(static_cast<int>(lo), static_cast<int>(lo >> 32), static_cast<int>(hi), static_cast<int>(hi >> 32));
+}
+
+// The mask step's look at the BH ranks: which genes change their mask bit under the cut kstar.  mv: this lane's words of
+// the wave's first kHeadPre rows (row wave + 4 q; zeros past the last row); further rows, and all rows again in the
+// crowded case, are read from mrank.  Appends (gene << 1 | new bit) to dl (at most kDeltaMax entries kept), counts the
+// changes in *s_n and added - removed in *s_nn (both zeroed by the caller, behind a barrier).  Whole workgroup.
+// One subtract per gene: with u = its word (rank | current bit << 31) the bit changes iff kstar < u <= kstar + 2^31,
+// i.e. iff u - (kstar + 1), as a signed number, is >= 0 (rank > kstar with the bit clear, or rank <= kstar with it set).
+// Changes are rare (a handful per pass): every lane reduces its rows to "how many of my rows hold a change, and the
+// last such row" without a branch -- a taken branch over a block of cold code costs an instruction-cache miss, and a
+// chain of twenty of them was two microseconds -- and the changed genes of that one row are then noted by the wave
+// together.  sum(inds) follows from the old count and the changes.
+template <bool COH>
+__device__ __forceinline__ void mask_scan(const int4 (&mv)[kHeadPre], int kstar, int nrow, const int32_t *mrank, uint32_t *dl, int *s_n, int *s_nn)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base = static_cast<uint32_t>(kstar) + 1u;
+    int4 sel = make_int4(0, 0, 0, 0);
+    int selq = 0, nflag = 0;
+#pragma unroll
+    for (int q = 0; q < kHeadPre; ++q) {  // (rows past the last one hold zeros: never a change)
+        const int d0 = static_cast<int>(static_cast<uint32_t>(mv[q].x) - base), d1 = static_cast<int>(static_cast<uint32_t>(mv[q].y) - base);
+        const int d2 = static_cast<int>(static_cast<uint32_t>(mv[q].z) - base), d3 = static_cast<int>(static_cast<uint32_t>(mv[q].w) - base);
+        const bool f = max(max(d0, d1), max(d2, d3)) >= 0;
+        sel.x = f ? mv[q].x : sel.x; sel.y = f ? mv[q].y : sel.y; sel.z = f ? mv[q].z : sel.z; sel.w = f ? mv[q].w : sel.w;
+        selq = f ? q : selq;
+        nflag += f ? 1 : 0;
+    }
+    auto note_changes = [&](bool on, int R, const int4 &m) {  // whole wave; lane l (if on): genes 256 R + 64 c + l, c = 0..3
+        const uint32_t e[4] = {static_cast<uint32_t>(m.x), static_cast<uint32_t>(m.y), static_cast<uint32_t>(m.z), static_cast<uint32_t>(m.w)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool chd = on && static_cast<int>(e[c] - base) >= 0;
+            const unsigned long long cm = __ballot(chd);
+            if (cm) {  // wave-uniform
+                const uint32_t nb = (e[c] >> 31) ^ 1u;  // the new bit: inds = .!(pval <= pval_deg .& padj <= padj_deg), :417
+                const unsigned long long am = __ballot(chd && nb);
+                int pos = 0;
+                if (lane == 0) { pos = atomicAdd(s_n, __popcll(cm)); atomicAdd(s_nn, 2 * __popcll(am) - __popcll(cm)); }
+                pos = __shfl(pos, 0, 64);
+                const int at = pos + __popcll(cm & ((1ULL << lane) - 1ULL));
+                if (chd && at < kDeltaMax) dl[at] = (static_cast<uint32_t>(R * 256 + c * 64 + lane) << 1) | nb;
+            }
+        }
+    };
+    const bool crowded = __ballot(nflag > 1) != 0;  // a lane with changes in two rows (about one pass in fifty): the wave reads its rows again
+    if (!crowded && __ballot(nflag == 1)) note_changes(nflag == 1, wave + 4 * selq, sel);
+#pragma unroll 1
+    for (int R = crowded ? wave : wave + 4 * kHeadPre; R < nrow; R += 4) note_changes(true, R, load_rank_row<COH>(mrank, R, lane));
+}
+
 template <bool TAIL>
 __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b)
 {
@@ -1926,9 +1676,6 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     __shared__ int wcnt[4][2];
     warm_kernargs<sizeof(IterArgs) + 16>();
     if (!TAIL) STAMP(a, 8);
-#ifdef REO_STAMPS
-    if (!TAIL && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[12] = __builtin_amdgcn_s_memtime();
-#endif
     const int pb = (b - 1) & 1;
     // ---- everything whose address does not depend on loaded data is requested first: the launch is a chain of
     // dependent round trips otherwise (measured: 22 us with the loads where they are used, most of it waiting)
@@ -1948,33 +1695,23 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
             const int4 h0 = hp[0], h1 = hp[1];
             hv[e][0] = h0.x; hv[e][1] = h0.y; hv[e][2] = h0.z; hv[e][3] = h0.w; hv[e][4] = h1.x; hv[e][5] = h1.y; hv[e][6] = h1.z; hv[e][7] = h1.w;
         }
-#ifdef REO_SERIAL_LOADS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        if (!TAIL) STAMP(a, 9);
 #pragma unroll
         for (int q = 0; q < kHeadPre; ++q) {
             const int R = wave + 4 * q;
             mv[q] = make_int4(0, 0, 0, 0);
             if (R < nrow) mv[q] = reinterpret_cast<const int4 *>(a.mrank)[R * 64 + lane];  // wave-uniform
         }
-#ifdef REO_SERIAL_LOADS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        if (!TAIL) STAMP(a, 10);
         if (i < G) own_m = a.mrank[mrank_slot(i)];
     }
     if (!TAIL && i < G) {
         const int4 *o = reinterpret_cast<const int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
         r0 = o[0]; r1 = o[1];
     }
-#ifdef REO_SERIAL_LOADS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    if (!TAIL) STAMP(a, 11);
     if (b > 0) {  // (after the vector loads: its values are needed in scalar registers, which waits for them)
         const LightSlot *ps = &ls->slot[b - 1];
-        r = ps->rec; bfail = ps->bfail; sig = ps->lc.sig;
+        r = ps->rec; bfail = ps->bfail;
+#pragma unroll
+        for (int q = 0; q < kSpread; ++q) sig += ps->lc.sig[q][0];
 #pragma unroll
         for (int q = 0; q < 4; ++q) win[q] = ps->wnext[q];
     } else {
@@ -1982,10 +1719,6 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         for (int q = 0; q < 4; ++q) win[q] = a.scal[1 + q];
     }
     if (!TAIL) STAMP(a, 0);
-#ifdef REO_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!TAIL) STAMP(a, 18);
-#endif
     int n = 0;           // entries of dl: the genes whose mask bit changes in front of the pass derived here
     bool inref = false;  // this thread's gene is in the reference set of that pass
     bool stepped = false;
@@ -2009,54 +1742,12 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         if (!TAIL) STAMP(a, 1);
         if (threadIdx.x == 0) { s_n = 0; s_nn = 0; }
         lds_barrier();
-        if (!TAIL) STAMP(a, 14);
-        // One subtract per gene: with u = its word (rank | current bit << 31) the bit changes iff kstar < u <= kstar + 2^31,
-        // i.e. iff u - (kstar + 1), as a signed number, is >= 0 (rank > kstar with the bit clear, or rank <= kstar with
-        // it set).  Changes are rare (a handful per pass): every lane reduces its rows to "how many of my rows hold a
-        // change, and the last such row", without a branch -- a taken branch over a block of cold code costs an
-        // instruction-cache miss, and a chain of twenty of them was two microseconds -- and the changed genes of that
-        // one row are then noted by the wave together.  sum(inds) follows from the old count and the changes.
-        const uint32_t base = static_cast<uint32_t>(kstar) + 1u;
-        int4 sel = make_int4(0, 0, 0, 0);
-        int selq = 0, nflag = 0;
-#pragma unroll
-        for (int q = 0; q < kHeadPre; ++q) {  // (rows past the last one hold zeros: never a change)
-            const int d0 = static_cast<int>(static_cast<uint32_t>(mv[q].x) - base), d1 = static_cast<int>(static_cast<uint32_t>(mv[q].y) - base);
-            const int d2 = static_cast<int>(static_cast<uint32_t>(mv[q].z) - base), d3 = static_cast<int>(static_cast<uint32_t>(mv[q].w) - base);
-            const bool f = max(max(d0, d1), max(d2, d3)) >= 0;
-            sel.x = f ? mv[q].x : sel.x; sel.y = f ? mv[q].y : sel.y; sel.z = f ? mv[q].z : sel.z; sel.w = f ? mv[q].w : sel.w;
-            selq = f ? q : selq;
-            nflag += f ? 1 : 0;
-        }
-        if (!TAIL) STAMP(a, 15);
-        auto note_changes = [&](bool on, int R, const int4 &m) {  // whole wave; lane l (if on): genes 256 R + 64 c + l, c = 0..3
-            const uint32_t e[4] = {static_cast<uint32_t>(m.x), static_cast<uint32_t>(m.y), static_cast<uint32_t>(m.z), static_cast<uint32_t>(m.w)};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const bool chd = on && static_cast<int>(e[c] - base) >= 0;
-                const unsigned long long cm = __ballot(chd);
-                if (cm) {  // wave-uniform
-                    const uint32_t nb = (e[c] >> 31) ^ 1u;  // the new bit: inds = .!(pval <= pval_deg .& padj <= padj_deg), :417
-                    const unsigned long long am = __ballot(chd && nb);
-                    int pos = 0;
-                    if (lane == 0) { pos = atomicAdd(&s_n, __popcll(cm)); atomicAdd(&s_nn, 2 * __popcll(am) - __popcll(cm)); }
-                    pos = __shfl(pos, 0, 64);
-                    const int at = pos + __popcll(cm & ((1ULL << lane) - 1ULL));
-                    if (chd && at < kDeltaMax) dl[at] = (static_cast<uint32_t>(R * 256 + c * 64 + lane) << 1) | nb;
-                }
-            }
-        };
-        const bool crowded = __ballot(nflag > 1) != 0;  // a lane with changes in two rows (about one pass in fifty): the wave reads its rows again
-        if (!crowded && __ballot(nflag == 1)) note_changes(nflag == 1, wave + 4 * selq, sel);
-        if (!TAIL) STAMP(a, 16);
-#pragma unroll 1
-        for (int R = crowded ? wave : wave + 4 * kHeadPre; R < nrow; R += 4) note_changes(true, R, reinterpret_cast<const int4 *>(a.mrank)[R * 64 + lane]);
+        mask_scan<false>(mv, kstar, nrow, a.mrank, dl, &s_n, &s_nn);
         const bool ind = i < G && static_cast<int>(static_cast<uint32_t>(own_m) & 0x7FFFFFFFu) > kstar;
         if (i < Gp) a.refbytes[nxt][i] = ind ? 1 : 0;
         const unsigned long long mk = __ballot(ind);
         if (lane == 0 && i < Gp) { a.refbits[nxt][i >> 5] = static_cast<uint32_t>(mk); a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(mk >> 32); }
         lds_barrier();
-        if (!TAIL) STAMP(a, 17);
         const int chg = s_n, nn = r.nref + s_nn;  // sum(inds), :417-418: the old mask's count (r.nref) + added - removed
         if (!TAIL) STAMP(a, 2);
         if (blockIdx.x == 0) {
@@ -2122,8 +1813,8 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     }
     if (!TAIL) STAMP(a, 5);
     {
-        const double nb = block_sum_256(inner ? 1.0 : 0.0, red);
-        const double sum = block_sum_256(inner ? v : 0.0, red);
+        double nb, sum;
+        block_sum2_256(inner ? 1.0 : 0.0, inner ? v : 0.0, red, nb, sum);
         const double mean = nb > 0.0 ? sum / nb : 0.0;
         const double m2 = block_sum_256(inner ? (v - mean) * (v - mean) : 0.0, red);
         if (threadIdx.x == 0) { a.part[3 * blockIdx.x] = nb; a.part[3 * blockIdx.x + 1] = mean; a.part[3 * blockIdx.x + 2] = m2; }
@@ -2143,13 +1834,10 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     lds_barrier();
     if (threadIdx.x == 0) {
         const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
-        if (ba) atomicAdd(&lc->below_a, ba);
-        if (bb) atomicAdd(&lc->below_b, bb);
+        if (ba) atomicAdd(&lc->below_a[blockIdx.x & (kSpread - 1)][0], ba);
+        if (bb) atomicAdd(&lc->below_b[blockIdx.x & (kSpread - 1)][0], bb);
     }
     if (!TAIL) STAMP(a, 7);
-#ifdef REO_STAMPS
-    if (!TAIL && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[13] = __builtin_amdgcn_s_memtime();
-#endif
 }
 
 // second launch of a two-launch light pass: every workgroup finishes the selection for itself (slice_std), then p-values
@@ -2167,16 +1855,16 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     LightSlot *sl = &ls->slot[b];
     LightCnt *lc = &sl->lc;
     const int active = sl->rec.active;
-    const int below_a = lc->below_a, below_b = lc->below_b, cnt_a = lc->cnt_a, cnt_b = lc->cnt_b;
+    const int cnt_a = lc->cnt_a, cnt_b = lc->cnt_b;
+    int below_a = 0, below_b = 0;
+#pragma unroll
+    for (int q = 0; q < kSpread; ++q) { below_a += lc->below_a[q][0]; below_b += lc->below_b[q][0]; }
     const double x = wave < 2 ? a.cand[wave * kCandMax + lane] : 0.0;  // (every slot of cand exists; slots past the count are ignored)
     double pn = 0.0, pm = 0.0, pq = 0.0;
     if (static_cast<int>(threadIdx.x) < (G + 255) / 256) { pn = a.part[3 * threadIdx.x]; pm = a.part[3 * threadIdx.x + 1]; pq = a.part[3 * threadIdx.x + 2]; }
     const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
     const double d1 = live ? a.result[11 * static_cast<size_t>(G) + i] : 0.0;
     if (!active) return;
-#ifdef REO_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     STAMP(a, 20);
     __shared__ double red[256];
     __shared__ double sel[2][4];
@@ -2209,8 +1897,243 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
     if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&hist[0], __popcll(first)); }
     else if (m <= G) atomicAdd(&hist[m - 1], 1);
-    if (lane == 0 && finite) atomicAdd(&lc->sig, __popcll(finite));
+    if (lane == 0 && finite) atomicAdd(&lc->sig[blockIdx.x & (kSpread - 1)][0], __popcll(finite));
     STAMP(a, 23);
+}
+
+// ---------------------------------------------------------------------------
+// The light passes as ONE persistent launch: the two launches of a pass (kl_head, kl_rank) become the two phases of a
+// loop, and their boundaries two grid barriers.  Thread i owns gene i for the whole launch: its tally counters, mask bit,
+// delta1, p-value and BH rank stay in registers; what crosses workgroups (histogram, rank rows, window members, block
+// moments, counters) goes through coherent loads / stores (ldc / stc: sc1) or agent-scope atomics.  The loop state is
+// computed by every workgroup for itself, identically.  Gp / 256 <= 256 workgroups of 256 threads: all resident.
+//
+// Grid barrier: one monotonic counter (zeroed by the host before the launch); every wave drains its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets, lane 0 adds one and polls with sc1 loads until every workgroup of the round
+// has arrived, the workgroup meets again.  No fences: measured 2.3 us per round with 80 workgroups against 4.6 us with a
+// release / acquire fence pair (tools/microbench_gridbar.hip).  Every spin is bounded (about 0.5 s): on expiry the
+// workgroup raises st->fault and leaves, and so do the others at their next barrier, so the grid always drains.
+__device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned nwg, unsigned &gen, int *fault)
+{
+    __shared__ int ok_s;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++gen;
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = gen * nwg;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        int ok = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull || __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+__global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, unsigned *bar)
+{
+    IterState *st = a.st;
+    LightRec r;  // the state as the previous launch left it (a kernel boundary: plain loads)
+    r.t = st->passes; r.nref = st->nref; r.nref_prev = st->nref_prev; r.done = st->done; r.need_full = st->need_full;
+    r.raw_pass = st->raw_pass; r.ran = 0; r.dcnt = st->delta_cnt[r.t & 1];
+    r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
+    if (!r.active || st->fault) return;  // the same in every workgroup
+    const int G = a.G, Gp = a.Gp;
+    const unsigned nwg = gridDim.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < G, holds = static_cast<int>(blockIdx.x) * 256 < G;  // (workgroups of padding genes only help with the barriers)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nrow = (G + 255) >> 8;
+    __shared__ uint32_t dl[kDeltaMax];
+    __shared__ int s_n, s_nn;
+    __shared__ double red[256];
+    __shared__ double sel[2][4];
+    __shared__ int wcnt[4][2];
+    __shared__ int32_t row[256];
+    int4 r0 = make_int4(0, 0, 0, 0), r1 = make_int4(0, 0, 0, 0);
+    bool inref = false;
+    if (live) {
+        const int4 *o = reinterpret_cast<const int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
+        r0 = o[0]; r1 = o[1];
+        inref = a.refbytes[r.t & 1][i] != 0;
+    }
+    double win[4] = {a.scal[1], a.scal[2], a.scal[3], a.scal[4]};
+    const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
+    int n = r.raw_pass == r.t ? 0 : min(r.dcnt, kDeltaMax);
+    if (static_cast<int>(threadIdx.x) < n) dl[threadIdx.x] = a.delta_list[static_cast<size_t>(r.t & 1) * Gp + threadIdx.x];
+    lds_barrier();
+    double d1 = 0.0, p = 1.0, se = 0.0;
+    int own_rank = 0;
+    unsigned gen = 0;
+    bool windows_moved = false;
+    while (true) {
+        const int par = r.t & 1;
+        LightCnt *lc = &ls->slot[par].lc;
+        int32_t *hist = a.hist + static_cast<size_t>(par) * a.hist_stride;
+        STAMP(a, 0);
+        // ---------------- phase 1 (kl_head's second half): tallies from the changed rows, delta1, window bookkeeping
+        bool inner = false, inA = false, inB = false, belowA = false, belowB = false;
+        if (live) {
+            if (n) {
+                int d[kRaw];
+                delta_counts<false, 8>(a.table, a.Wp, dl, n, i, d);  // (the table does not change: plain loads)
+                r0.x += d[0]; r0.y += d[1]; r0.z += d[2]; r0.w += d[3];
+                r1.x += d[4]; r1.y += d[5]; r1.z += d[6]; r1.w += d[7];
+            }
+            int32_t c[9];
+            const int total = r.nref - (inref ? 1 : 0);  // the diagonal is never set (:363,385)
+            c[0] = r1.x; c[2] = r1.y; c[6] = r1.z; c[8] = r1.w;
+            c[1] = r0.x - r1.x - r1.y; c[7] = r0.y - r1.z - r1.w; c[3] = r0.z - r1.x - r1.z; c[5] = r0.w - r1.y - r1.w;
+            c[4] = total - (r0.x + r0.y + c[3] + c[5]);
+            double out[5];
+            mccullagh3<false>(c, out);
+            d1 = out[1];
+            stc<true>(hist + i, 0);  // this parity's histogram: last read two passes ago
+            belowA = d1 < win[0]; inA = !belowA && d1 <= win[1];
+            belowB = d1 < win[2]; inB = !belowB && d1 <= win[3];
+            inner = d1 > win[1] && d1 < win[2];
+        }
+        r.raw_pass = r.t;
+        {
+            double nb, sum;
+            block_sum2_256(inner ? 1.0 : 0.0, inner ? d1 : 0.0, red, nb, sum);
+            const double mean = nb > 0.0 ? sum / nb : 0.0;
+            const double m2 = block_sum_256(inner ? (d1 - mean) * (d1 - mean) : 0.0, red);
+            if (threadIdx.x == 0 && holds) { stc<true>(a.part + 3 * blockIdx.x, nb); stc<true>(a.part + 3 * blockIdx.x + 1, mean); stc<true>(a.part + 3 * blockIdx.x + 2, m2); }
+        }
+        {
+            const unsigned long long mA = __ballot(inA), mB = __ballot(inB), bA = __ballot(belowA), bB = __ballot(belowB);
+            int baseA = 0, baseB = 0;
+            if (lane == 0) {
+                if (mA) baseA = atomicAdd(&lc->cnt_a, __popcll(mA));
+                if (mB) baseB = atomicAdd(&lc->cnt_b, __popcll(mB));
+                wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
+            }
+            baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
+            const unsigned long long lt = (1ULL << lane) - 1ULL;
+            if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) stc<true>(a.cand + at, d1); }
+            if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) stc<true>(a.cand + kCandMax + at, d1); }
+            lds_barrier();
+            if (threadIdx.x == 0) {
+                const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
+                if (ba) atomicAdd(&lc->below_a[blockIdx.x & (kSpread - 1)][0], ba);
+                if (bb) atomicAdd(&lc->below_b[blockIdx.x & (kSpread - 1)][0], bb);
+            }
+        }
+        STAMP(a, 1);
+        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
+        STAMP(a, 2);
+        // ---------------- phase 2 (kl_rank): the selection, p-values, BH ranks and their histogram
+        if (blockIdx.x == 0 && threadIdx.x < kSpread) {
+            // the other parity's counters: every workgroup is past its last look at them (the mask step in front of phase 1)
+            LightCnt *z = &ls->slot[par ^ 1].lc;
+            if (threadIdx.x == 0) { stc<true>(&z->cnt_a, 0); stc<true>(&z->cnt_b, 0); }
+            stc<true>(&z->below_a[threadIdx.x][0], 0); stc<true>(&z->below_b[threadIdx.x][0], 0); stc<true>(&z->sig[threadIdx.x][0], 0);
+        }
+        {
+            const int cnt_a = ldc<true>(&lc->cnt_a), cnt_b = ldc<true>(&lc->cnt_b);
+            int below_a = 0, below_b = 0;
+#pragma unroll
+            for (int q = 0; q < kSpread; ++q) { below_a += ldc<true>(&lc->below_a[q][0]); below_b += ldc<true>(&lc->below_b[q][0]); }
+            const double x = wave < 2 ? ldc<true>(a.cand + wave * kCandMax + lane) : 0.0;
+            double pn = 0.0, pm = 0.0, pq = 0.0;
+            if (static_cast<int>(threadIdx.x) < nrow) { pn = ldc<true>(a.part + 3 * threadIdx.x); pm = ldc<true>(a.part + 3 * threadIdx.x + 1); pq = ldc<true>(a.part + 3 * threadIdx.x + 2); }
+            double va = 0.0, vb = 0.0;
+            bool ok = slice_std_vals(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
+            ok = ok && (va + wd1 < vb - wd2);
+            if (!ok) { r.active = 0; r.need_full = 1; break; }  // the same in every workgroup: this pass runs on the sorting path (its tallies are in place)
+            win[0] = va - wd0; win[1] = va + wd1; win[2] = vb - wd2; win[3] = vb + wd3;  // the next pass's windows
+            windows_moved = true;
+        }
+        int m = G + 1;
+        if (live) {
+            p = normal_p(d1, se);
+            m = bh_rank(p, G, a.padj_deg);
+            own_rank = p <= a.pval_deg ? m : G + 2;
+        }
+        row[4 * lane + wave] = live ? static_cast<int32_t>(static_cast<uint32_t>(own_rank) | (inref ? 0x80000000u : 0u)) : 0;
+        lds_barrier();
+        stc<true>(a.mrank + blockIdx.x * 256 + threadIdx.x, row[threadIdx.x]);
+        {
+            const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
+            if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&hist[0], __popcll(first)); }
+            else if (m <= G) atomicAdd(&hist[m - 1], 1);
+            if (lane == 0 && finite) atomicAdd(&lc->sig[blockIdx.x & (kSpread - 1)][0], __popcll(finite));
+        }
+        STAMP(a, 3);
+        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
+        STAMP(a, 4);
+        // ---------------- the mask step of pass r.t (kl_head's first half, :413-424), by every workgroup for itself
+        int hv[4][8];
+        int4 mv[kHeadPre];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long *hp = reinterpret_cast<const unsigned long long *>(hist + (e * 256 + threadIdx.x) * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const unsigned long long w = ldc<true>(hp + u); hv[e][2 * u] = static_cast<int>(w); hv[e][2 * u + 1] = static_cast<int>(w >> 32); }
+        }
+#pragma unroll
+        for (int q = 0; q < kHeadPre; ++q) {
+            const int R = wave + 4 * q;
+            mv[q] = make_int4(0, 0, 0, 0);
+            if (R < nrow) mv[q] = load_rank_row<true>(a.mrank, R, lane);
+        }
+        int sig = 0;
+#pragma unroll
+        for (int q = 0; q < kSpread; ++q) sig += ldc<true>(&lc->sig[q][0]);
+        STAMP(a, 5);
+        const int t = r.t, nxt = par ^ 1;
+        const int kstar = sig <= 8192 ? bh_cut4(hv, G) : bh_cut<true>(hist, G, sig);
+        STAMP(a, 6);
+        if (threadIdx.x == 0) { s_n = 0; s_nn = 0; }
+        lds_barrier();
+        mask_scan<true>(mv, kstar, nrow, a.mrank, dl, &s_n, &s_nn);
+        const bool ind = live && own_rank > kstar;
+        if (i < Gp) a.refbytes[nxt][i] = ind ? 1 : 0;  // (read again by later launches only)
+        const unsigned long long mk = __ballot(ind);
+        if (lane == 0 && i < Gp) { a.refbits[nxt][i >> 5] = static_cast<uint32_t>(mk); a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(mk >> 32); }
+        lds_barrier();
+        const int chg = s_n, nn = r.nref + s_nn;  // sum(inds), :417-418
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) { a.trace[2 * t] = G - nn; a.trace[2 * t + 1] = nn; }
+            if (static_cast<int>(threadIdx.x) < min(chg, kDeltaMax)) a.delta_list[static_cast<size_t>(nxt) * Gp + threadIdx.x] = dl[threadIdx.x];
+        }
+        STAMP(a, 7);
+        r.nref_prev = r.nref;
+        const int diff = r.nref - nn;
+        if ((diff < 0 ? -diff : diff) < a.n_conv) r.done = 1;  // :419-422
+        else r.nref = nn;                                      // :423-424
+        r.t = t + 1; r.ran = 1; r.dcnt = chg;
+        r.need_full = chg > kDeltaMax ? 1 : 0;
+        r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
+        inref = ind;
+        n = min(chg, kDeltaMax);
+        if (!r.active) break;
+    }
+    // ---------------- hand the state back to the launches that follow
+    if (live) {
+        int4 *o = reinterpret_cast<int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
+        o[0] = r0; o[1] = r1;
+        a.result[11 * static_cast<size_t>(G) + i] = d1;
+        a.result[i] = p;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->passes = r.t; st->nref = r.nref; st->nref_prev = r.nref_prev; st->done = r.done; st->need_full = r.need_full;
+        st->i_iter = r.t - (r.done ? 1 : 0);
+        st->raw_pass = r.raw_pass;
+        st->delta_cnt[r.t & 1] = r.dcnt;
+        if (r.ran) st->last_full = 0;
+        a.scal[0] = se;
+        if (windows_moved) { a.scal[1] = win[0]; a.scal[2] = win[1]; a.scal[3] = win[2]; a.scal[4] = win[3]; }
+    }
 }
 
 }  // namespace
@@ -2411,26 +2334,14 @@ int32_t launch_full_pass(reo_ctx *c, bool replay)
     return REO_OK;
 }
 
-// One light pass (three kernels, no sort); returns at once on the device unless the state allows one.
-int32_t launch_light_pass(reo_ctx *c)
-{
-    const IterArgs a = iter_args(c, 0);
-    const int nb = (a.G + 255) / 256;
-    kl_derive<<<nb, 256, 0, c->stream>>>(a);
-    kl_pvalues<<<nb, 256, 0, c->stream>>>(a);
-    kl_mask<<<c->Gp / 256, 256, 0, c->stream>>>(a);
-    REO_HIP_CHECK(hipGetLastError());
-    return REO_OK;
-}
-
 // Light passes until the state stops them (convergence, n_iter, a pass that needs the sorting path): one persistent launch.
 int32_t launch_light_persistent(reo_ctx *c)
 {
     const IterArgs a = iter_args(c, 0);
     const unsigned nwg = static_cast<unsigned>(a.Gp / 256);  // every mask byte, padding included, has its thread
     REO_HIP_CHECK(hipMemsetAsync(c->gridbar.p, 0, sizeof(unsigned), c->stream));
-    REO_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char *>(c->state.p) + offsetof(IterState, pz_cnt), 0, sizeof(int32_t) * 12, c->stream));
-    kl_persist<<<nwg, 256, 0, c->stream>>>(a, c->gridbar.p);
+    REO_HIP_CHECK(hipMemsetAsync(c->lstate.p, 0, 2 * sizeof(LightSlot), c->stream));  // the counters of both pass parities
+    kl_persist<<<nwg, 256, 0, c->stream>>>(a, c->lstate.p, c->gridbar.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

@@ -37,14 +37,8 @@ struct IterState {
     int32_t raw_pass;  // the tally counters hold the tallies of this pass (-1: none)
     int32_t nref_prev; // nref of the last executed pass (for recomputing its outputs)
     int32_t last_full; // the last executed pass ran on the sorting path: every output column is in place
-    int32_t tick_a, tick_b;                     // finished workgroups of kl_derive / kl_pvalues
-    int32_t below_a, below_b, cnt_a, cnt_b;     // light pass: values below / inside the two quantile windows
-    int32_t kstar;     // light pass: the Benjamini-Hochberg cut
     int32_t fault;     // the persistent light kernel gave up at a grid barrier (bounded spin expired)
-    // persistent light kernel: the same counters by pass parity (reset one pass ahead, between barriers)
-    int32_t pz_cnt[2][2], pz_below[2][2], pz_nn[2], pz_sig[2];
-    int32_t sig_cnt;   // light pass (three launches): genes with a finite BH rank
-    int32_t pad[2];
+    int32_t pad[3];
 };
 
 // Light passes as two launches per pass (kernels.hip, kl_head / kl_rank): the loop state of one batch of launches as an
@@ -60,20 +54,30 @@ struct LightRec {
     int32_t dcnt;       // genes whose mask bit changed in front of pass t
 };                      // (no padding array inside: copying one through registers made the compiler keep it in LDS, indexed by a
                         //  thread id that it computed from the dispatch packet -- a 3 us read of host memory at kernel start)
-struct LightCnt { int32_t cnt_a, cnt_b, below_a, below_b, sig, pad[3]; };  // window bookkeeping + genes with a finite BH rank
-// everything the launches after pass b of a batch need of it, in one block (one load): rec = the state in FRONT of pass
-// b; the rest is made by pass b itself.  Zeroed by the host in front of the batch.
+// Counters of one light pass.  A launch cannot end before its atomics have been performed, and atomics on one address
+// are performed one after the other (about 12 ns each): 316 waves adding to one word kept kl_rank alive for 3 us after
+// its last instruction.  Sums that need no return value are therefore spread over kSpread cache lines (by workgroup)
+// and added up by their readers.
+constexpr int kSpread = 8;
+struct LightCnt {
+    int32_t cnt_a, cnt_b;            // members of the two quantile windows (slot allocation: returned values)
+    int32_t pad[30];
+    int32_t below_a[kSpread][32];    // values below window A   ([k][0] used: one cache line per part)
+    int32_t below_b[kSpread][32];
+    int32_t sig[kSpread][32];        // genes with a finite BH rank
+};
+// everything the launches after pass b of a batch need of it: rec = the state in FRONT of pass b; the rest is made by
+// pass b itself.  Zeroed by the host in front of the batch.
 struct LightSlot {
     LightRec rec;
-    int32_t pad0[7];
-    LightCnt lc;
     int32_t bfail;      // pass b lost a quantile window: it is redone on the sorting path
-    int32_t pad[7];
+    int32_t pad0[6];
     double wnext[4];    // quantile windows for the pass after pass b
-    double pad2[4];
+    double pad1[4];
+    LightCnt lc;
 };
 struct LightState { LightSlot slot[kLightBatch + 2]; };
-static_assert(sizeof(LightSlot) == 192, "LightSlot layout");
+static_assert(sizeof(LightSlot) % 128 == 0, "LightSlot layout");
 
 void set_error(const char *fmt, ...);
 
@@ -191,7 +195,7 @@ struct reo_ctx {
     reo::DevBuf<unsigned> gridbar;      // [1] arrival counter of the persistent light kernel's grid barrier
     reo::DevBuf<reo::LightState> lstate;  // [1] batch log of the two-launch light passes
     int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
-    int light_mode = 3;                 // 0 sorting passes only, 1 light passes as three launches each, 2 as one persistent launch, 3 as two launches each (REO_LIGHT)
+    int light_mode = 1;                 // 0 sorting passes only, 1 light passes as two launches each, 2 as one persistent launch (REO_LIGHT)
     reo::DevBuf<int32_t> hist, mrank;   // [2][G padded to whole 32768-bin rounds], [Gp] light passes: histogram of the BH ranks (by launch parity), the ranks
     // parameters of the running reo_identify_degs call (kernels.hip, iter_args)
     double it_pval_deg = 1.0, it_padj_deg = 0.05;
@@ -221,7 +225,6 @@ int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
 int32_t launch_tally(reo_ctx *c, int nref);
 int32_t launch_full_pass(reo_ctx *c, bool replay);
-int32_t launch_light_pass(reo_ctx *c);
 int32_t launch_light_persistent(reo_ctx *c);
 int32_t launch_light_batch(reo_ctx *c, int nlight);
 int32_t light_min_genes();
