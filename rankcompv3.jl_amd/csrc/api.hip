@@ -161,7 +161,7 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         (rc = c->state.ensure(1)) ||
         (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * (kSortChunk + kSortChunk / 32))) ||
         (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))) ||
-        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(2 * ((G + 32767) / 32768 * 32768))) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->scal.ensure(64)))
+        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(2 * ((G + 32767) / 32768 * 32768))) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->clist.ensure(2 * kListStride)) || (rc = c->scal.ensure(64)))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
@@ -257,6 +257,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->device = device;
     c->seed = seed;
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
+    if (const char *e = getenv("REO_LIGHT_BAND")) c->light_band = std::max(0, atoi(e));
     if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
     c->light_window = light_window(); c->light_min_g = light_min_genes();
     if (const char *e = getenv("REO_LIGHT_WINDOW")) c->light_window = std::max(1, std::min(31, atoi(e)));  // 2 W + 1 <= 64 window members
@@ -285,7 +286,7 @@ void reo_destroy(reo_ctx *c)
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
+    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -530,13 +531,18 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // other kind of pass is due), and the host reads the state once per batch.  Two kinds of pass (kernels.hip):
     // the sorting path -- needed for the first pass, whenever the reference set changed by more genes than a tally
     // update takes, and when a quantile window lost its order statistic -- and the light path.  A batch = two
-    // sorting passes (mostly idle launches) + as many light passes as may follow; small problems sort every pass.
+    // sorting passes, or a run of light passes; small problems sort every pass.
     const bool small = G < c->light_min_g || c->light_mode == 0;
-    int passes = 0, seen_need_full = 1;
+    int passes = 0, seen_need_full = 1, light_batches = 0;
     while (n_iter > 0) {  // :400
         const int remaining = n_iter - passes;
-        const int nfull = small ? std::min(8, remaining) : std::min(2, remaining);
-        const int nlight = (small || seen_need_full) ? 0 : std::min(kLightBatch, remaining);
+        // the state read after the last batch says which kind of pass is due: sorting launches are enqueued only then
+        // (they would return at once otherwise: seven idle launches each), light launches only behind a pass that left
+        // windows.  The first light batch is short, because a run that converges does so within a few passes and every
+        // launch after that is idle; later ones are longer.
+        const int nfull = small ? std::min(8, remaining) : (seen_need_full ? std::min(2, remaining) : 0);
+        const int nlight = (small || seen_need_full) ? 0 : std::min(light_batches == 0 ? kLightBatch / 2 : kLightBatch, remaining);
+        if (nlight > 0) ++light_batches;
         tic(c, 3);
         for (int t = 0; t < nfull; ++t)
             if ((rc = launch_full_pass(c, false))) return rc;

@@ -808,6 +808,7 @@ struct IterArgs {
     int32_t *mrank;              // [Gp]        light passes: m_i
     int replay;                  // 1: recompute the outputs of the last executed pass from its tallies, change no state
     int k2_idx;                  // index of this k2_tally launch (for the stage timers)
+    int32_t *clist; int band;    // light passes: genes near the BH cut listed by kl_rank ([2][kListStride]); half width of "near" in ranks
     int window, light_min_g;     // light passes: ranks on either side of a quantile that its window is made to hold; smallest G that uses them
     unsigned long long *stamps;  // diagnostic builds (-DREO_STAMPS): s_memrealtime marks of workgroup 0, else unused
 };
@@ -1596,6 +1597,7 @@ __device__ __forceinline__ void warm_kernargs()
     for (int q = 0; q < (BYTES + 63) / 64; ++q) asm volatile("" ::"s"(t[q]));
 }
 
+constexpr int kListPre = 5;   // rounds of 256 list entries requested at kernel start (80 workgroups' parts)
 constexpr int kHeadPre = 20;  // rows of 256 genes per wave whose BH ranks are requested at kernel start (20 000 genes: all of them)
 
 // mrank of the two-launch form.  Layout: the word of gene 256 R + 64 c + l (row R, wave c, lane l of kl_rank) is stored at
@@ -1626,7 +1628,7 @@ __device__ __forceinline__ int4 load_rank_row(const int32_t *mrank, int R, int l
 // chain of twenty of them was two microseconds -- and the changed genes of that one row are then noted by the wave
 // together.  sum(inds) follows from the old count and the changes.
 template <bool COH>
-__device__ __forceinline__ void mask_scan(const int4 (&mv)[kHeadPre], int kstar, int nrow, const int32_t *mrank, uint32_t *dl, int *s_n, int *s_nn)
+__device__ __forceinline__ void mask_scan(const int4 (&mv)[kHeadPre], int kstar, int nrow, const int32_t *mrank, uint32_t *dl, int *s_n, int *s_nn, bool reload_all = false)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t base = static_cast<uint32_t>(kstar) + 1u;
@@ -1658,20 +1660,20 @@ __device__ __forceinline__ void mask_scan(const int4 (&mv)[kHeadPre], int kstar,
             }
         }
     };
-    const bool crowded = __ballot(nflag > 1) != 0;  // a lane with changes in two rows (about one pass in fifty): the wave reads its rows again
+    const bool crowded = reload_all || __ballot(nflag > 1) != 0;  // a lane with changes in two rows (about one pass in fifty): the wave reads its rows again
     if (!crowded && __ballot(nflag == 1)) note_changes(nflag == 1, wave + 4 * selq, sel);
 #pragma unroll 1
     for (int R = crowded ? wave : wave + 4 * kHeadPre; R < nrow; R += 4) note_changes(true, R, load_rank_row<COH>(mrank, R, lane));
 }
 
-template <bool TAIL>
+template <bool TAIL, bool LIST>
 __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b)
 {
     const int G = a.G, Gp = a.Gp;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ uint32_t dl[kDeltaMax];
-    __shared__ int s_n, s_nn;
+    __shared__ int s_n, s_nn, s_fb;
     __shared__ double red[256];
     __shared__ int wcnt[4][2];
     warm_kernargs<sizeof(IterArgs) + 16>();
@@ -1683,6 +1685,8 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     int bfail = 0, sig = 0;
     int hv[4][8];
     int4 mv[kHeadPre];
+    int2 le[kListPre];
+    int lcnt[kListPre];
     int own_m = 0;
     int4 r0 = make_int4(0, 0, 0, 0), r1 = make_int4(0, 0, 0, 0);
     double win[4];
@@ -1699,7 +1703,16 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         for (int q = 0; q < kHeadPre; ++q) {
             const int R = wave + 4 * q;
             mv[q] = make_int4(0, 0, 0, 0);
-            if (R < nrow) mv[q] = reinterpret_cast<const int4 *>(a.mrank)[R * 64 + lane];  // wave-uniform
+            if (!LIST && R < nrow) mv[q] = reinterpret_cast<const int4 *>(a.mrank)[R * 64 + lane];  // wave-uniform
+        }
+        if (LIST) {  // the genes near the cut, as listed by the launch before (kl_rank): entry e of workgroup e / kListCap
+            const int32_t *cl = a.clist + static_cast<size_t>(pb) * kListStride;
+#pragma unroll
+            for (int q = 0; q < kListPre; ++q) {
+                const int e = threadIdx.x + 256 * q, blk = e / kListCap;
+                le[q] = make_int2(0, 0); lcnt[q] = 0;
+                if (blk < nrow) { lcnt[q] = cl[blk]; le[q] = reinterpret_cast<const int2 *>(cl + 256)[e]; }
+            }
         }
         if (i < G) own_m = a.mrank[mrank_slot(i)];
     }
@@ -1725,7 +1738,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     if (b == 0) {
         const IterState *st = a.st;  // no light launch writes IterState except the TAIL
         r.t = st->passes; r.nref = st->nref; r.nref_prev = st->nref_prev; r.done = st->done; r.need_full = st->need_full;
-        r.raw_pass = st->raw_pass; r.ran = 0; r.dcnt = st->delta_cnt[r.t & 1];
+        r.raw_pass = st->raw_pass; r.ran = 0; r.dcnt = st->delta_cnt[r.t & 1]; r.kstar = -1;
         r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
         if (r.active) {
             n = r.raw_pass == r.t ? 0 : min(r.dcnt, kDeltaMax);  // (need_full == 0 implies dcnt <= kDeltaMax)
@@ -1740,9 +1753,43 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         const int t = r.t, cur = t & 1, nxt = cur ^ 1;
         const int kstar = sig <= 8192 ? bh_cut4(hv, G) : bh_cut<false>(a.hist + static_cast<size_t>(pb) * a.hist_stride, G, sig);
         if (!TAIL) STAMP(a, 1);
-        if (threadIdx.x == 0) { s_n = 0; s_nn = 0; }
+        if (threadIdx.x == 0) { s_n = 0; s_nn = 0; s_fb = 0; }
         lds_barrier();
-        mask_scan<false>(mv, kstar, nrow, a.mrank, dl, &s_n, &s_nn);
+        if (LIST) {
+            // every gene whose bit can change is in the list if the cut stayed within `band` ranks of the cut the list was
+            // made for (kl_rank) and no workgroup's part overflowed; otherwise all ranks are read (mask_scan)
+            const uint32_t base = static_cast<uint32_t>(kstar) + 1u;
+            bool bad = r.kstar < 0 || kstar < r.kstar - a.band || kstar > r.kstar + a.band;  // (the same in every workgroup)
+            auto note = [&](int cnt, int2 ent, int e) {
+                bad = bad || cnt > kListCap;
+                const bool chd = (e % kListCap) < cnt && static_cast<int>(static_cast<uint32_t>(ent.x) - base) >= 0;
+                const unsigned long long cm = __ballot(chd);
+                if (cm) {  // wave-uniform
+                    const uint32_t nb = (static_cast<uint32_t>(ent.x) >> 31) ^ 1u;
+                    const unsigned long long am = __ballot(chd && nb);
+                    int pos = 0;
+                    if (lane == 0) { pos = atomicAdd(&s_n, __popcll(cm)); atomicAdd(&s_nn, 2 * __popcll(am) - __popcll(cm)); }
+                    pos = __shfl(pos, 0, 64);
+                    const int at = pos + __popcll(cm & ((1ULL << lane) - 1ULL));
+                    if (chd && at < kDeltaMax) dl[at] = (static_cast<uint32_t>(ent.y) << 1) | nb;
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < kListPre; ++q) note(lcnt[q], le[q], threadIdx.x + 256 * q);
+            const int32_t *cl = a.clist + static_cast<size_t>(pb) * kListStride;
+#pragma unroll 1
+            for (int e = threadIdx.x + 256 * kListPre; e < nrow * kListCap; e += 256) note(cl[e / kListCap], reinterpret_cast<const int2 *>(cl + 256)[e], e);
+            if (__ballot(bad) && lane == 0) s_fb = 1;
+            lds_barrier();
+            if (s_fb) {  // workgroup-uniform (and, the inputs being the same, the same in every workgroup)
+                lds_barrier();
+                if (threadIdx.x == 0) { s_n = 0; s_nn = 0; }
+                lds_barrier();
+                mask_scan<false>(mv, kstar, nrow, a.mrank, dl, &s_n, &s_nn, true);
+            }
+        } else {
+            mask_scan<false>(mv, kstar, nrow, a.mrank, dl, &s_n, &s_nn);
+        }
         const bool ind = i < G && static_cast<int>(static_cast<uint32_t>(own_m) & 0x7FFFFFFFu) > kstar;
         if (i < Gp) a.refbytes[nxt][i] = ind ? 1 : 0;
         const unsigned long long mk = __ballot(ind);
@@ -1758,7 +1805,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         const int diff = r.nref - nn;
         if ((diff < 0 ? -diff : diff) < a.n_conv) r.done = 1;  // :419-422
         else r.nref = nn;                                      // :423-424
-        r.t = t + 1; r.ran = 1; r.dcnt = chg;
+        r.t = t + 1; r.ran = 1; r.dcnt = chg; r.kstar = kstar;
         r.need_full = chg > kDeltaMax ? 1 : 0;
         r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
         inref = ind;
@@ -1893,6 +1940,25 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
         lds_barrier();
         a.mrank[blockIdx.x * 256 + threadIdx.x] = row[threadIdx.x];
     }
+    if (sl->rec.kstar >= 0) {
+        // the genes whose mask bit can change at the next mask step if its cut lands within `band` ranks of the last one:
+        // ranks inside the band, and bits that are wrong for every cut in it.  By workgroup, no global atomics.
+        __shared__ int s_c;
+        if (threadIdx.x == 0) s_c = 0;
+        lds_barrier();
+        const int kp = sl->rec.kstar, rk = p <= a.pval_deg ? m : G + 2;
+        const bool ob = a.refbytes[sl->rec.t & 1][live ? i : 0] != 0;
+        const bool want = live && ((rk > kp - a.band && rk <= kp + a.band) || (rk > kp + a.band && !ob) || (rk <= kp - a.band && ob));
+        const unsigned long long cm = __ballot(want);
+        int pos = 0;
+        if (cm && lane == 0) pos = atomicAdd(&s_c, __popcll(cm));
+        pos = __shfl(pos, 0, 64) + __popcll(cm & ((1ULL << lane) - 1ULL));
+        int32_t *cl = a.clist + static_cast<size_t>(pbuf) * kListStride;
+        if (want && pos < kListCap)
+            reinterpret_cast<int2 *>(cl + 256)[blockIdx.x * kListCap + pos] = make_int2(static_cast<int>(static_cast<uint32_t>(rk) | (ob ? 0x80000000u : 0u)), i);
+        lds_barrier();
+        if (threadIdx.x == 0) cl[blockIdx.x] = min(s_c, kListCap + 1);
+    }
     int32_t *hist = a.hist + static_cast<size_t>(pbuf) * a.hist_stride;
     const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
     if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&hist[0], __popcll(first)); }
@@ -1943,7 +2009,7 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
     IterState *st = a.st;
     LightRec r;  // the state as the previous launch left it (a kernel boundary: plain loads)
     r.t = st->passes; r.nref = st->nref; r.nref_prev = st->nref_prev; r.done = st->done; r.need_full = st->need_full;
-    r.raw_pass = st->raw_pass; r.ran = 0; r.dcnt = st->delta_cnt[r.t & 1];
+    r.raw_pass = st->raw_pass; r.ran = 0; r.dcnt = st->delta_cnt[r.t & 1]; r.kstar = -1;
     r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
     if (!r.active || st->fault) return;  // the same in every workgroup
     const int G = a.G, Gp = a.Gp;
@@ -2303,6 +2369,7 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     a.trace = c->trace.p; a.modes = nullptr;
     a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / 2); a.mrank = c->mrank.p;
     a.replay = replay; a.k2_idx = 0;
+    a.clist = c->clist.p; a.band = c->light_band;
     a.window = c->light_window; a.light_min_g = c->light_min_g;
     a.stamps = reinterpret_cast<unsigned long long *>(c->scal.p + 32);
     return a;
@@ -2352,12 +2419,16 @@ int32_t launch_light_batch(reo_ctx *c, int nlight)
     const IterArgs a = iter_args(c, 0);
     const int nb = (a.G + 255) / 256, nbp = a.Gp / 256;  // (the head writes every mask byte, padding included)
     if (nlight < 1 || nlight > kLightBatch) { set_error("light batch of %d passes", nlight); return REO_EINVAL; }
-    REO_HIP_CHECK(hipMemsetAsync(c->lstate.p, 0, sizeof(LightState), c->stream));
+    REO_HIP_CHECK(hipMemsetAsync(c->lstate.p, 0, static_cast<size_t>(nlight + 1) * sizeof(LightSlot), c->stream));  // the slots this batch writes
+    // the first mask step of a batch reads all BH ranks (the launch before it had no cut to make a list around); later
+    // ones read the list of genes near the cut
     for (int b = 0; b < nlight; ++b) {
-        kl_head<false><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, b);
+        if (b < 2) kl_head<false, false><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, b);
+        else kl_head<false, true><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, b);
         kl_rank<<<nb, 256, 0, c->stream>>>(a, c->lstate.p, b);
     }
-    kl_head<true><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, nlight);
+    if (nlight < 2) kl_head<true, false><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, nlight);
+    else kl_head<true, true><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, nlight);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

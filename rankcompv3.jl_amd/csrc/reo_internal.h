@@ -45,13 +45,14 @@ struct IterState {
 // append-only log, so that no kernel reads a word that another workgroup of the same launch writes.  rec[b] = the state
 // in front of light pass b of the batch (rec of slot nlight: behind the last one), written by workgroup 0 of launch b,
 // read by the launches after it.
-constexpr int kLightBatch = 32;  // light passes per batch of launches
+constexpr int kLightBatch = 64;  // light passes per batch of launches (the first batch of a call: half)
 struct LightRec {
     int32_t active;     // pass `t` is to run as a light pass
     int32_t t;          // passes executed so far = index of the next pass
     int32_t nref, nref_prev, done, need_full, raw_pass;  // as in IterState
     int32_t ran;        // a light pass of this batch has been completed
     int32_t dcnt;       // genes whose mask bit changed in front of pass t
+    int32_t kstar;      // the BH cut of the mask step that made this record (-1: none, the record comes from a sorting pass)
 };                      // (no padding array inside: copying one through registers made the compiler keep it in LDS, indexed by a
                         //  thread id that it computed from the dispatch packet -- a 3 us read of host memory at kernel start)
 // Counters of one light pass.  A launch cannot end before its atomics have been performed, and atomics on one address
@@ -59,6 +60,8 @@ struct LightRec {
 // its last instruction.  Sums that need no return value are therefore spread over kSpread cache lines (by workgroup)
 // and added up by their readers.
 constexpr int kSpread = 8;
+constexpr int kListCap = 16;   // genes near the BH cut that one workgroup of kl_rank can list
+constexpr int kListStride = 256 + 256 * kListCap * 2;  // int32 per parity: counts by workgroup, then (word, gene) pairs
 struct LightCnt {
     int32_t cnt_a, cnt_b;            // members of the two quantile windows (slot allocation: returned values)
     int32_t pad[30];
@@ -71,7 +74,7 @@ struct LightCnt {
 struct LightSlot {
     LightRec rec;
     int32_t bfail;      // pass b lost a quantile window: it is redone on the sorting path
-    int32_t pad0[6];
+    int32_t pad0[5];
     double wnext[4];    // quantile windows for the pass after pass b
     double pad1[4];
     LightCnt lc;
@@ -194,6 +197,8 @@ struct reo_ctx {
     reo::DevBuf<double> cand;           // [2 parities][2 windows][64] light passes: values inside the quantile windows
     reo::DevBuf<unsigned> gridbar;      // [1] arrival counter of the persistent light kernel's grid barrier
     reo::DevBuf<reo::LightState> lstate;  // [1] batch log of the two-launch light passes
+    reo::DevBuf<int32_t> clist;         // [2][256 + 256 * kListCap * 2] genes near the BH cut, by workgroup (kernels.hip, kl_rank)
+    int light_band = 32;                // REO_LIGHT_BAND (tests)
     int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
     int light_mode = 1;                 // 0 sorting passes only, 1 light passes as two launches each, 2 as one persistent launch (REO_LIGHT)
     reo::DevBuf<int32_t> hist, mrank;   // [2][G padded to whole 32768-bin rounds], [Gp] light passes: histogram of the BH ranks (by launch parity), the ranks
