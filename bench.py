@@ -11,8 +11,8 @@ data: two comparisons per pair and sample) as `tie_rich`.
 
 `dtype` is "u16": the pair kernel compares 16-bit sorted positions, bit-sliced over 32-sample blocks (v_bitop3_b32
 borrow chains + v_bcnt_u32_b32); the tallies are integer popcounts and the per-gene statistics fp64.
-`scaling` is "strong": with N GPUs the same 20k x 1k problem is split over the ranks (pair tiles; one RCCL all-reduce
-of the class table inside reo_build_pairs, in-library: reo_comm_init_rank).
+`scaling` is "strong": with N GPUs the same 20k x 1k problem is split over the ranks (pair tiles; one RCCL all-gather
+of the ranks' own class-table words inside reo_build_pairs, in-library: reo_comm_init_rank).
 
 python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with torch.distributed.run (one rank per GPU).
 """
@@ -229,7 +229,9 @@ def main() -> None:
         rep = (mine["transform_ms"] + mine["iter_ms"]) / (dt / args.steps * 1e3)
         out["ranks"] = allr
         out["replicated_stage_share"] = rep     # transform + iteration passes run identically on every rank
-        out["collective"] = "one ncclAllReduce(sum, uint32) of the class table (%d MB) per reo_build_pairs, in-library RCCL" % (G * info["Gp"] // 2 // 1000000)
+        out["collective"] = ("one ncclAllGather per reo_build_pairs, in-library RCCL: every rank sends the forward words of its own pair "
+                             "tiles (about %d MB over all ranks; the whole table is %d MB), mirror words are derived on arrival; "
+                             "exchange_ms_per_build = pack + collective + unpack") % (G * info["Gp"] // 4 // 1000000, G * info["Gp"] // 2 // 1000000)
 
     if not args.no_tie_rich and args.family == "t0":
         st = max(3, args.steps // 4)

@@ -58,17 +58,18 @@ void reo_destroy(reo_ctx *ctx);
 /* ---- several GPUs ---------------------------------------------------------------------------------------
  * The reference is one process with shared-memory threads (src/RankCompV3.jl:368,402) and has no multi-device
  * path; this is the build's own.  The pair tiles of the G x G triangle are dealt to `world` shards; every shard
- * builds the class-table words of its tiles, ONE integer sum per class table (the shards' bits are disjoint)
- * gives every shard the whole table, and the iteration passes run with no further collective.
+ * builds the class-table words of its tiles, ONE exchange per class table (the shards' bits are disjoint: an
+ * all-gather of their own words, or an in-place sum) gives every shard the whole table, and the iteration passes
+ * run with no further collective.
  *
  * (a) one process, all GPUs: reo_create_multi(&ctx, n_gpus (0 = all visible), seed) returns a context that is
  *     used exactly like a one-GPU context; it drives one device context each, sums the tables onto device 0
  *     with RCCL (ncclReduce) inside reo_build_pairs and runs the passes there.
  * (b) one process per GPU: rank 0 calls reo_comm_unique_id and hands the 128 bytes to the other ranks by any
  *     means; every rank calls reo_comm_init_rank(ctx, id, rank, world) (ncclCommInitRank + reo_set_shard).
- *     reo_build_pairs then ends with an ncclAllReduce of the table on the context's stream; all ranks get
- *     identical results.
- * (c) bring your own collective: reo_set_shard + reo_set_allreduce (hook below).  */
+ *     reo_build_pairs then ends with an ncclAllGather of the shards' own table words on the context's stream (see
+ *     reo_set_allgather for the protocol); all ranks get identical results.
+ * (c) bring your own collective: reo_set_shard + reo_set_allgather or reo_set_allreduce (hooks below).  */
 enum { REO_UNIQUE_ID_BYTES = 128 };
 int32_t reo_create_multi(reo_ctx **out, int32_t n_gpus, uint64_t seed);
 int32_t reo_comm_unique_id(void *id /* REO_UNIQUE_ID_BYTES */);
@@ -89,6 +90,16 @@ int32_t reo_set_shard(reo_ctx *ctx, int32_t rank, int32_t world);
  * synchronise `stream` itself before and after.  Return 0 on success. */
 typedef int32_t (*reo_allreduce_fn)(void *dev_buf, int64_t count, void *stream, void *user);
 int32_t reo_set_allreduce(reo_ctx *ctx, reo_allreduce_fn fn, void *user);
+
+/* The cheaper form of the same exchange, and what the in-library RCCL path does: every shard packs the table words of
+ * ITS OWN pair tiles (upper triangle only, about a quarter of what an in-place sum of the whole table moves), the
+ * packs are gathered, and every shard unpacks the others' words and derives the mirror words (the pair seen from the
+ * other gene, src/RankCompV3.jl:386) itself.  The hook is an all-gather: `bytes_per_rank` bytes at device pointer
+ * `send` of every shard have to arrive at `recv + r * bytes_per_rank` of every shard, r = the sender's shard number,
+ * ordered on `stream` like the sum above (RCCL: ncclAllGather(send, recv, bytes_per_rank, ncclUint8, comm, stream)).
+ * When both hooks are set this one is used. */
+typedef int32_t (*reo_allgather_fn)(const void *send, void *recv, int64_t bytes_per_rank, void *stream, void *user);
+int32_t reo_set_allgather(reo_ctx *ctx, reo_allgather_fn fn, void *user);
 
 /* Expression matrix, G genes x S samples, column-major with leading dimension
  * ld >= G: the `data` argument of identify_degs (src/RankCompV3.jl:340) as

@@ -20,7 +20,7 @@ NTIMINGS = 12
 
 # every symbol include/reo_hip.h declares
 SYMBOLS = [
-    "reo_version", "reo_last_error", "reo_create", "reo_destroy", "reo_set_shard", "reo_set_allreduce",
+    "reo_version", "reo_last_error", "reo_create", "reo_destroy", "reo_set_shard", "reo_set_allreduce", "reo_set_allgather",
     "reo_create_multi", "reo_comm_unique_id", "reo_comm_init_rank",
     "reo_set_matrix_f64", "reo_set_matrix_i64", "reo_set_matrix_dev_f64", "reo_set_matrix_dev_i64",
     "reo_set_groups", "reo_compute_thresholds", "reo_set_thresholds", "reo_get_thresholds", "reo_threshold",
@@ -30,6 +30,7 @@ SYMBOLS = [
 ]
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class LibraryMissing(RuntimeError):
@@ -84,6 +85,7 @@ def lib() -> ctypes.CDLL:
         "reo_comm_unique_id": (i32, [vp]),
         "reo_comm_init_rank": (i32, [vp, vp, i32, i32]),
         "reo_set_allreduce": (i32, [vp, ALLREDUCE_FN, vp]),
+        "reo_set_allgather": (i32, [vp, ALLGATHER_FN, vp]),
         "reo_set_matrix_f64": (i32, [vp, vp, i64, i64, i64]),
         "reo_set_matrix_i64": (i32, [vp, vp, i64, i64, i64]),
         "reo_set_matrix_dev_f64": (i32, [vp, vp, i64, i64, i64]),
@@ -243,6 +245,22 @@ class Context:
         cb = ALLREDUCE_FN(_cb)
         self._keep.append(cb)
         check(self._L.reo_set_allreduce(self._h, cb, None))
+
+    def set_allgather(self, fn) -> None:
+        """fn(send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream: int) -> None: gather `bytes_per_rank` bytes of
+        every shard's `send` into `recv + shard * bytes_per_rank` on every shard, ordered on the HIP stream `stream`
+        (the cheaper form of the table exchange, see include/reo_hip.h)."""
+        def _cb(send, recv, nbytes, stream, _user):
+            try:
+                fn(int(send), int(recv), int(nbytes), int(stream or 0))
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLGATHER_FN(_cb)
+        self._keep.append(cb)
+        check(self._L.reo_set_allgather(self._h, cb, None))
 
     # -- hot path -------------------------------------------------------------
     def build_pairs(self, k: int = 0) -> None:

@@ -199,11 +199,25 @@ static int32_t exchange_table(reo_ctx *c)
 {
     c->table_complete = c->world <= 1;
     if (c->world <= 1 && !c->comm) return REO_OK;  // (a communicator of one rank still makes its call: the path stays testable on one GPU)
-    const int64_t count = static_cast<int64_t>(c->G) * kPlanes * c->Wp;
-    int32_t rc = comm_allreduce_table(c, count);  // comm.hip: REO_OK when it did the exchange, 1 when no communicator is attached
-    if (rc < 0) return rc;
-    if (rc == 1) {
+    int32_t rc;
+    if (c->comm || c->ag) {
+        // gather form: pack the forward words of this shard's units, all-gather the packs, unpack the others' words and
+        // derive their mirror words here (kernels.hip, x_pack / x_expand_fwd / x_expand_mirror)
+        const int64_t bytes = exchange_unit_words(c) * exchange_units_per_rank(c) * static_cast<int64_t>(sizeof(uint32_t));
+        if ((rc = c->xsend.ensure(static_cast<size_t>(bytes / 4))) || (rc = c->xrecv.ensure(static_cast<size_t>(bytes / 4) * c->world))) return rc;
+        tic(c, 6);  // the exchange stage: pack + collective + unpack
+        if ((rc = launch_pack_units(c))) return rc;
+        if (c->comm) {
+            if ((rc = comm_allgather(c, c->xsend.p, c->xrecv.p, bytes)) < 0) return rc;
+        } else {
+            rc = c->ag(c->xsend.p, c->xrecv.p, bytes, c->stream, c->ag_user);  // stream-ordered, no host sync here
+            if (rc) { set_error("all-gather hook failed with %d", rc); return REO_ECOMM; }
+        }
+        if ((rc = launch_expand_units(c))) return rc;
+        toc(c);
+    } else {
         if (!c->ar) return REO_OK;  // no exchange configured: the partial table can still be inspected (reo_get_codes)
+        const int64_t count = static_cast<int64_t>(c->G) * kPlanes * c->Wp;
         tic(c, 6);
         rc = c->ar(c->table.p, count, c->stream, c->ar_user);  // stream-ordered, no host sync here
         toc(c);
@@ -218,7 +232,7 @@ static int32_t need_complete_table(reo_ctx *c)
     if (c->built_k < 0) { set_error("no class table: call reo_build_pairs first"); return REO_EINVAL; }
     if (!c->table_complete) {
         set_error("shard %d of %d holds only its own part of the class table: attach a communicator (reo_comm_init_rank) or an "
-                  "all-reduce hook (reo_set_allreduce) before reo_build_pairs", c->rank, c->world);
+                  "exchange hook (reo_set_allgather, reo_set_allreduce) before reo_build_pairs", c->rank, c->world);
         return REO_ECOMM;
     }
     return REO_OK;
@@ -286,7 +300,7 @@ void reo_destroy(reo_ctx *c)
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
+    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -308,6 +322,13 @@ int32_t reo_set_allreduce(reo_ctx *c, reo_allreduce_fn fn, void *user)
 {
     if (!c) { set_error("null context"); return REO_EINVAL; }
     c->ar = fn; c->ar_user = user;
+    return REO_OK;
+}
+
+int32_t reo_set_allgather(reo_ctx *c, reo_allgather_fn fn, void *user)
+{
+    if (!c) { set_error("null context"); return REO_EINVAL; }
+    c->ag = fn; c->ag_user = user;
     return REO_OK;
 }
 

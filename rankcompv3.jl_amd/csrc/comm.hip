@@ -3,9 +3,13 @@
 // Threads.@threads only, :368,402); what is exchanged here is this build's own intermediate, the class table.
 //
 // Protocol: the pair tiles of the G x G triangle are dealt to the shards (launch_k1, `unit % world`); every shard
-// writes the table words of its tiles (forward and mirror bits) into a zeroed table, so the shards' tables have
-// disjoint bits and ONE integer sum (ncclSum over uint32) per class table assembles it on every shard --
-// 4 bits per ordered pair, 205 MB at 20 000 genes.  The iteration passes then run with no collective at all.
+// writes the table words of its tiles (forward and mirror bits) into a zeroed table.  One process per GPU
+// (reo_comm_init_rank): every shard packs the forward words of its own units (upper triangle: 107 MB in all at 20 000
+// genes), ONE ncclAllGather per class table hands every pack to every shard, and each shard unpacks the others' words
+// and derives their mirror words itself (api.hip, exchange_table; kernels.hip, x_pack / x_expand_*) -- a quarter of the
+// bytes that an in-place sum of the whole 205 MB table moves.  One process, all GPUs (reo_create_multi): the tables,
+// whose bits are disjoint, are summed onto the leader with one ncclReduce.  The iteration passes then run with no
+// collective at all.
 #include <rccl/rccl.h>
 
 #include <cstring>
@@ -24,14 +28,11 @@ namespace reo {
         }                                                                                     \
     } while (0)
 
-int32_t comm_allreduce_table(reo_ctx *c, int64_t count)
+int32_t comm_allgather(reo_ctx *c, const void *send, void *recv, int64_t bytes_per_rank)
 {
     if (!c->comm) return 1;
-    tic(c, 6);
-    const ncclResult_t r = ncclAllReduce(c->table.p, c->table.p, static_cast<size_t>(count), ncclUint32, ncclSum,
-                                         static_cast<ncclComm_t>(c->comm), c->stream);
-    toc(c);
-    if (r != ncclSuccess) { set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); return REO_ECOMM; }
+    const ncclResult_t r = ncclAllGather(send, recv, static_cast<size_t>(bytes_per_rank), ncclUint8, static_cast<ncclComm_t>(c->comm), c->stream);
+    if (r != ncclSuccess) { set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return REO_ECOMM; }
     return REO_OK;
 }
 

@@ -2202,6 +2202,90 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
     }
 }
 
+// ---------------------------------------------------------------------------
+// Exchange of the class table between shards, gather form (api.hip, exchange_table).  A work unit of the pair kernel
+// = kUnitH i-tiles (1024 gene rows) x one panel of W = 32 Wc gene columns; its FORWARD words are the rectangle rows x
+// (words of the panel) of the table, its MIRROR words (the same pairs seen from the other gene, :386) the transposed
+// rectangle with the low / high planes swapped.  A shard packs the forward rectangles of its own units as they stand
+// in its table; after the all-gather every shard ORs the others' rectangles into its table (x_expand_fwd), then the
+// transposes (x_expand_mirror).  Rectangles of different units are disjoint, and so are transposed rectangles; a
+// rectangle can overlap a transposed one next to the diagonal, which is why the two steps are separate launches and
+// everything is OR-ed (bits that arrive twice -- a sender's own mirror bits inside one of its rectangles -- are the
+// same bits).  Pack layout of a unit: [1024 rows][4 planes][Wc words]; rows and words past the table are zeros.
+struct XArgs {
+    uint32_t *table;
+    const uint32_t *units;  // every unit of the build: panel << 16 | i-range; owner = index % world
+    int G, Wp, Wc, total, world, rank, maxu;
+};
+constexpr int kUnitRows = kUnitH * kTileI;
+
+__global__ __launch_bounds__(256) void x_pack(XArgs a, uint32_t *__restrict__ send)
+{
+    const int m = blockIdx.y, gu = a.rank + m * a.world;
+    const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * a.Wc;
+    const size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= uw) return;
+    uint32_t v = 0;
+    if (gu < a.total) {
+        const uint32_t um = a.units[gu];
+        const int p = static_cast<int>(um >> 16), r = static_cast<int>(um & 0xFFFFu);
+        const int w = static_cast<int>(e % a.Wc), pl = static_cast<int>((e / a.Wc) % kPlanes), rr = static_cast<int>(e / (static_cast<size_t>(a.Wc) * kPlanes));
+        const int row = r * kUnitRows + rr, cw = p * a.Wc + w;
+        if (row < a.G && cw < a.Wp) v = a.table[(static_cast<size_t>(row) * kPlanes + pl) * a.Wp + cw];
+    }
+    send[static_cast<size_t>(m) * uw + e] = v;
+}
+
+__global__ __launch_bounds__(256) void x_expand_fwd(XArgs a, const uint32_t *__restrict__ recv)
+{
+    const int s = blockIdx.y / a.maxu, m = blockIdx.y % a.maxu, gu = s + m * a.world;
+    if (s == a.rank || gu >= a.total) return;
+    const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * a.Wc;
+    const size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= uw) return;
+    const uint32_t v = recv[(static_cast<size_t>(s) * a.maxu + m) * uw + e];
+    if (!v) return;
+    const uint32_t um = a.units[gu];
+    const int p = static_cast<int>(um >> 16), r = static_cast<int>(um & 0xFFFFu);
+    const int w = static_cast<int>(e % a.Wc), pl = static_cast<int>((e / a.Wc) % kPlanes), rr = static_cast<int>(e / (static_cast<size_t>(a.Wc) * kPlanes));
+    const int row = r * kUnitRows + rr, cw = p * a.Wc + w;
+    if (row < a.G && cw < a.Wp) a.table[(static_cast<size_t>(row) * kPlanes + pl) * a.Wp + cw] |= v;
+}
+
+// One workgroup per (unit, column word jb of the panel, plane); each wave transposes pairs of 32 x 32 bit blocks: lane l
+// holds the word of source row 32 ib + (l & 31), ib = 2 pair + (l >> 5); the ballot of bit c over the wave is, for output
+// row 32 jb + c, the two words that cover source rows 64 pair .. 64 pair + 63 -- kept by lane c and OR-ed into the table.
+__global__ __launch_bounds__(256) void x_expand_mirror(XArgs a, const uint32_t *__restrict__ recv)
+{
+    const int s = blockIdx.z / a.maxu, m = blockIdx.z % a.maxu, gu = s + m * a.world;
+    if (s == a.rank || gu >= a.total) return;
+    const int jb = blockIdx.x, pl = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * a.Wc;
+    const uint32_t *src = recv + (static_cast<size_t>(s) * a.maxu + m) * uw;
+    const uint32_t um = a.units[gu];
+    const int p = static_cast<int>(um >> 16), r = static_cast<int>(um & 0xFFFFu);
+    const int j = (p * a.Wc + jb) * 32 + (lane & 31);  // the output row of lanes 0..31
+    for (int pair = wave; pair < kUnitRows / 64; pair += 4) {
+        const int rr = 64 * pair + lane;  // source row inside the unit
+        const uint32_t word = src[(static_cast<size_t>(rr) * kPlanes + pl) * a.Wc + jb];
+        if (!__ballot(word != 0)) continue;  // wave-uniform: nothing in these 64 x 32 bits
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const unsigned long long b = __ballot((word >> c) & 1u);
+            mine = lane == c ? b : mine;
+        }
+        const int ow = (r * kUnitRows) / 32 + 2 * pair;  // two consecutive words of the output row
+        if (lane < 32 && j < a.G && mine != 0 && ow + 1 < a.Wp) {
+            uint2 *o = reinterpret_cast<uint2 *>(a.table + (static_cast<size_t>(j) * kPlanes + (pl ^ 1)) * a.Wp + ow);  // L <-> H
+            uint2 t = *o;
+            t.x |= static_cast<uint32_t>(mine); t.y |= static_cast<uint32_t>(mine >> 32);
+            *o = t;
+        }
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
@@ -2262,12 +2346,14 @@ int32_t launch_k1(reo_ctx *c, int k)
     const int Q = chunk_bytes * 4 <= (2u << 20) ? 4 : (chunk_bytes * 2 <= (2u << 20) ? 2 : 1);
     const int NP = (NJ + Q - 1) / Q;
     std::vector<uint32_t> units;
+    c->units_all_host.clear();
     int64_t owned = 0, total = 0;
     uint32_t gu = 0;
     for (int p = 0; p < NP; ++p) {
         const int ni = std::min(NIT, (CJ / kTileI) * Q * (p + 1));  // i-tiles that reach this panel's columns
         for (int r = 0; r * kUnitH < ni; ++r, ++gu) {
             const bool mine = c->world == 1 || static_cast<int>(gu % c->world) == c->rank;
+            c->units_all_host.push_back(static_cast<uint32_t>(p) << 16 | static_cast<uint32_t>(r));
             if (mine) units.push_back(static_cast<uint32_t>(p) << 16 | static_cast<uint32_t>(r));
             for (int t = r * kUnitH; t < std::min(ni, (r + 1) * kUnitH); ++t)
                 for (int jc = p * Q; jc < std::min(NJ, (p + 1) * Q); ++jc) {
@@ -2309,6 +2395,53 @@ int32_t launch_k1(reo_ctx *c, int k)
     default: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems, wide); break;
     }
     toc(c);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+
+int64_t exchange_unit_words(const reo_ctx *c) { return static_cast<int64_t>(kUnitRows) * kPlanes * (c->k1_q * c->k1_cj / 32); }
+int32_t exchange_units_per_rank(const reo_ctx *c)
+{
+    const int total = static_cast<int>(c->units_all_host.size()), world = std::max(c->world, 1);
+    return std::max(1, (total + world - 1) / world);
+}
+
+static int32_t exchange_args(reo_ctx *c, XArgs &a)
+{
+    int32_t rc;
+    const size_t total = c->units_all_host.size();
+    if ((rc = c->units_all.ensure(std::max<size_t>(total, 1)))) return rc;
+    if (total) {
+        REO_HIP_CHECK(hipMemcpyAsync(c->units_all.p, c->units_all_host.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // (the vector may be rebuilt by the next launch_k1 while the copy is in flight)
+    }
+    a.table = c->table.p; a.units = c->units_all.p;
+    a.G = static_cast<int>(c->G); a.Wp = c->Wp; a.Wc = c->k1_q * c->k1_cj / 32;
+    a.total = static_cast<int>(total); a.world = std::max(c->world, 1); a.rank = c->rank; a.maxu = exchange_units_per_rank(c);
+    return REO_OK;
+}
+
+int32_t launch_pack_units(reo_ctx *c)
+{
+    XArgs a;
+    int32_t rc = exchange_args(c, a);
+    if (rc) return rc;
+    const size_t uw = static_cast<size_t>(exchange_unit_words(c));
+    x_pack<<<dim3(static_cast<unsigned>((uw + 255) / 256), a.maxu), 256, 0, c->stream>>>(a, c->xsend.p);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t launch_expand_units(reo_ctx *c)
+{
+    XArgs a;
+    int32_t rc = exchange_args(c, a);
+    if (rc) return rc;
+    if (a.world < 2) return REO_OK;  // (a communicator of one rank: its own pack came back)
+    const size_t uw = static_cast<size_t>(exchange_unit_words(c));
+    x_expand_fwd<<<dim3(static_cast<unsigned>((uw + 255) / 256), a.maxu * a.world), 256, 0, c->stream>>>(a, c->xrecv.p);
+    x_expand_mirror<<<dim3(a.Wc, kPlanes, a.maxu * a.world), 256, 0, c->stream>>>(a, c->xrecv.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

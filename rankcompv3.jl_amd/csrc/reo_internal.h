@@ -131,6 +131,8 @@ struct reo_ctx {
     int rank = 0, world = 1;
     reo_allreduce_fn ar = nullptr;
     void *ar_user = nullptr;
+    reo_allgather_fn ag = nullptr;
+    void *ag_user = nullptr;
 
     // problem
     int64_t G = 0, S = 0, ld = 0;
@@ -175,6 +177,10 @@ struct reo_ctx {
     int last_k1_shared = 0;             // reo_get_info: how the last class table was built
     int64_t tiles_owned = 0, tiles_total = 0;
     int k1_cj = 0, k1_q = 0;  // K1 geometry of the last build: genes j per workgroup, j-chunks per panel
+    // gather form of the exchange (kernels.hip, x_pack / x_expand_*): every work unit of the last build (panel << 16 | i-range,
+    // owner = index % world), pack and gather buffers
+    std::vector<uint32_t> units_all_host;
+    reo::DevBuf<uint32_t> units_all, xsend, xrecv;
 
     // iteration state
     reo::DevBuf<uint32_t> refbits[2];   // [Wp]
@@ -225,6 +231,10 @@ int32_t run_transform(reo_ctx *c);
 
 // kernels.hip
 int32_t launch_k1(reo_ctx *c, int k);
+int64_t exchange_unit_words(const reo_ctx *c);   // uint32 per packed work unit
+int32_t exchange_units_per_rank(const reo_ctx *c);
+int32_t launch_pack_units(reo_ctx *c);           // this shard's units -> c->xsend
+int32_t launch_expand_units(reo_ctx *c);         // c->xrecv (every shard's pack) -> the table: the others' words and their mirrors
 int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq);
 int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
@@ -237,7 +247,7 @@ int32_t light_window();
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
 
 // comm.hip: in-library RCCL.  Returns REO_OK after enqueueing the sum on c->stream, 1 when no communicator is attached
-int32_t comm_allreduce_table(reo_ctx *c, int64_t count);
+int32_t comm_allgather(reo_ctx *c, const void *send, void *recv, int64_t bytes_per_rank);
 void comm_release(reo_ctx *c);
 int32_t multi_build_pairs(reo_ctx *lead, int32_t k, int32_t (*build_local)(reo_ctx *, int32_t));
 

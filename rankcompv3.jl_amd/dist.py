@@ -16,6 +16,13 @@ class _RawDev:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
+class _RawDevBytes:
+    """The same for a run of bytes."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
 def allreduce_hook(device=None, group=None, via_host: bool = False):
     """fn(ptr, count, stream): sum int32[count] at `ptr` across the process group, in place, ordered
     on the library's HIP stream.  `device` is a torch cuda device for device pointers: the collective
@@ -53,6 +60,23 @@ def allreduce_hook(device=None, group=None, via_host: bool = False):
                 ext.synchronize()
             else:
                 dist.all_reduce(t, group=group)  # enqueued; `ext` waits for it, the host does not
+
+    return fn
+
+
+def allgather_hook(device, group=None):
+    """fn(send_ptr, recv_ptr, bytes_per_rank, stream): all-gather of the shards' packed table words through
+    torch.distributed (RCCL), enqueued on the library's HIP stream."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(send: int, recv: int, nbytes: int, stream: int = 0) -> None:
+        world = dist.get_world_size(group)
+        ext = torch.cuda.ExternalStream(stream, device=device) if stream else torch.cuda.current_stream(device)
+        with torch.cuda.stream(ext):
+            src = torch.as_tensor(_RawDevBytes(send, nbytes), device=device)
+            dst = torch.as_tensor(_RawDevBytes(recv, nbytes * world), device=device)
+            dist.all_gather_into_tensor(dst, src, group=group)
 
     return fn
 

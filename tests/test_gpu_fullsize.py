@@ -44,7 +44,7 @@ def test_config3_whole_table_and_loop_against_oracle(pkg, oracle, family, n_iter
 
 
 def _two_shard_run(pkg, X, gid, seed, pval_reo, ref0, n_iter, n_conv):
-    """Two contexts (shards 0/2 and 1/2) on one GPU joined by a host-side hook; returns what each shard computed."""
+    """Two contexts (shards 0/2 and 1/2) on one GPU joined by a host-side all-gather hook; returns what each shard computed."""
     import torch
     world = 2
     barrier = threading.Barrier(world)
@@ -54,14 +54,14 @@ def _two_shard_run(pkg, X, gid, seed, pval_reo, ref0, n_iter, n_conv):
 
     def run(rank):
         try:
-            def hook(ptr, count, stream):
+            def gather(send, recv, nbytes, stream):  # reo_set_allgather: what the in-library RCCL path does
                 torch.cuda.ExternalStream(stream, device=dev).synchronize()
-                slots[rank] = torch.as_tensor(pkg.dist._RawDev(ptr, count), device=dev)
+                slots[rank] = torch.as_tensor(pkg.dist._RawDevBytes(send, nbytes), device=dev)
+                mine = torch.as_tensor(pkg.dist._RawDevBytes(recv, nbytes * world), device=dev)
                 barrier.wait()
-                if rank == 0:
-                    slots[0].add_(slots[1])
-                    slots[1].copy_(slots[0])
-                    torch.cuda.synchronize()
+                for r in range(world):
+                    mine[r * nbytes:(r + 1) * nbytes].copy_(slots[r])
+                torch.cuda.synchronize()
                 barrier.wait()
 
             with pkg.Context(device=0, seed=seed) as ctx:
@@ -69,7 +69,7 @@ def _two_shard_run(pkg, X, gid, seed, pval_reo, ref0, n_iter, n_conv):
                 ctx.set_groups(gid, 2)
                 ctx.compute_thresholds(pval_reo)
                 ctx.set_shard(rank, world)
-                ctx.set_allreduce(hook)
+                ctx.set_allgather(gather)
                 ctx.build_pairs(0)
                 info = ctx.info()
                 cont = ctx.tally(ref0)
