@@ -7,8 +7,11 @@ cut into tiles of TILE_I rows x CHUNK_J columns; a unit = UNIT_H consecutive
 row tiles x Q column chunks of one panel; units are numbered panel-major and
 unit u belongs to shard u % world.  Every shard builds the class-table bits of
 its own tiles (forward and mirror) into a zeroed table; the shards' bits are
-disjoint, so ONE integer all-reduce (sum) of the table gives every shard the
-whole table, and tallies / iteration passes then run unsharded
+disjoint, so ONE exchange gives every shard the whole table -- an in-place sum
+of the table, or (what the library's RCCL path does: x_pack / x_expand_* in
+kernels.hip, mirrored by pack_units / expand_units below) an all-gather of the
+forward rectangles of every shard's own units, the mirror words being derived
+on arrival -- and tallies / iteration passes then run unsharded
 (src/RankCompV3.jl:403).
 """
 from __future__ import annotations
@@ -123,3 +126,50 @@ def codes_from_planes(planes: np.ndarray) -> np.ndarray:
     code = (3 * ic + it).astype(np.uint8)
     np.fill_diagonal(code, 255)
     return code
+
+
+def unit_list(G: int, slots: int, has_ties: bool):
+    """Every work unit of the build in launch_k1's order: (panel p, i-range r); unit u belongs to shard u % world.  A
+    unit's forward words are the rectangle rows [1024 r, 1024 r + 1024) x columns [W p, W p + W), W = Q * CJ."""
+    Gp, CJ, Q = geometry(G, slots, has_ties)
+    NJ, NIT = (Gp + CJ - 1) // CJ, Gp // TILE_I
+    NP = (NJ + Q - 1) // Q
+    units = []
+    for p in range(NP):
+        ni = min(NIT, (CJ // TILE_I) * Q * (p + 1))
+        units += [(p, r) for r in range((ni + UNIT_H - 1) // UNIT_H)]
+    return units, Q * CJ
+
+
+def pack_units(planes: np.ndarray, G: int, slots: int, has_ties: bool, rank: int, world: int) -> np.ndarray:
+    """x_pack: the forward rectangles of this shard's units as they stand in its (partial) table `planes` [G, 4, G],
+    one after the other, zero-padded to whole rectangles and to ceil(units / world) units."""
+    units, W = unit_list(G, slots, has_ties)
+    H = UNIT_H * TILE_I
+    maxu = max(1, (len(units) + world - 1) // world)
+    out = np.zeros((maxu, H, 4, W), dtype=planes.dtype)
+    for m in range(maxu):
+        gu = rank + m * world
+        if gu >= len(units):
+            continue
+        p, r = units[gu]
+        blk = planes[r * H:(r + 1) * H, :, p * W:(p + 1) * W]
+        out[m, :blk.shape[0], :, :blk.shape[2]] = blk
+    return out
+
+
+def expand_units(planes: np.ndarray, recv: np.ndarray, G: int, slots: int, has_ties: bool, rank: int, world: int) -> None:
+    """x_expand_fwd + x_expand_mirror: OR the other shards' rectangles (recv[s] = shard s's pack) into `planes`, then their
+    transposes with the low / high planes swapped (the pair seen from the other gene, src/RankCompV3.jl:386)."""
+    units, W = unit_list(G, slots, has_ties)
+    H = UNIT_H * TILE_I
+    swap = [1, 0, 3, 2]
+    todo = [(s, m, units[s + m * world]) for s in range(world) if s != rank for m in range(recv.shape[1]) if s + m * world < len(units)]
+    for s, m, (p, r) in todo:
+        rows, cols = slice(r * H, min((r + 1) * H, G)), slice(p * W, min((p + 1) * W, G))
+        planes[rows, :, cols] |= recv[s, m, :rows.stop - rows.start, :, :cols.stop - cols.start]
+    for s, m, (p, r) in todo:
+        rows, cols = slice(r * H, min((r + 1) * H, G)), slice(p * W, min((p + 1) * W, G))
+        blk = recv[s, m, :rows.stop - rows.start, :, :cols.stop - cols.start]
+        for pl in range(4):
+            planes[cols, swap[pl], rows] |= blk[:, pl, :].T

@@ -74,6 +74,15 @@ def _worker(rank, world, port, G, S, seed, out):
         assert planes.max() == 1                                  # the shards' bits were disjoint
         whole = sh.codes_from_planes(planes)
         assert np.array_equal(whole, code)
+        # the cheaper exchange, what the library's RCCL path does: all-gather of the shards' own forward rectangles,
+        # mirror words derived on arrival (x_pack / x_expand_fwd / x_expand_mirror)
+        import torch
+        part = np.ascontiguousarray(sh.class_planes(code, mask))
+        pack = torch.from_numpy(sh.pack_units(part, G, slots, True, rank, world))
+        recv = [torch.empty_like(pack) for _ in range(world)]
+        dist.all_gather(recv, pack)
+        sh.expand_units(part, np.stack([r.numpy() for r in recv]), G, slots, True, rank, world)
+        assert part.max() == 1 and np.array_equal(sh.codes_from_planes(part), code)
         # ... after which tallies and the loop of src/RankCompV3.jl:396-425 run unsharded on every rank
         ref0 = pkg.synth.ref_mask(G, 200, seed)
         assert np.array_equal(sh.derive_tallies(sh.raw_counters(whole, ref0), ref0), oracle.tally(code, ref0))
