@@ -137,6 +137,13 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
 // marks padding items, which sort behind every gene.
 // flags: 0 non-finite input, 1 some tie, 4 some sample needs more than 31 key bits (the caller then
 // redoes the whole transform with the segmented sort).
+// the histogram form of the per-sample ranking (t_sample): integer input only, at most this many varying key bits
+template <class T> constexpr bool kCountingPath = false;
+template <> constexpr bool kCountingPath<int64_t> = true;
+constexpr unsigned kCountBits = 15;
+constexpr int kCountPer = (1 << kCountBits) / 1024;  // bins per thread in the prefix sums
+constexpr size_t kCountWords = (size_t(1) << kCountBits) + (size_t(1) << (kCountBits - 5));  // the histogram, skewed by one word in 32
+
 template <class T, int IPT>
 __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
                                                  const int32_t *__restrict__ slots, int G, int Gp, int S,
@@ -186,6 +193,64 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         return;
     }
     const uint32_t mask = (1u << nbits) - 1u;
+    if (kCountingPath<T> && nbits <= kCountBits) {
+        // Integer data whose varying key bits number at most 15 (ranks, small counts): ties are equalities, so a band is
+        // a key value, and positions follow from a histogram -- first position of the band = number of smaller keys,
+        // position inside the band = order of arrival at the histogram (any order inside a band gives the same counts:
+        // a tied partner only has to lie inside the band).  No sort: about a tenth of the radix path's time.
+        // (bin b lives at word b + b / 32: a thread that walks its 32 consecutive bins in the prefix sums then meets a
+        //  different bank than its neighbours -- unskewed, all 64 lanes of a wave hit one bank)
+        uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+        auto at = [](uint32_t b) { return b + (b >> 5); };
+        const int nbin = 1 << nbits;
+        for (int b = t; b < nbin; b += 1024) hist[at(b)] = 0;
+        __syncthreads();
+        uint32_t key[IPT], arrival[IPT];
+#pragma unroll
+        for (int e = 0; e < IPT; ++e) {
+            const int i = e * 1024 + t;
+            key[e] = 0; arrival[e] = 0;
+            if (i < G) {
+                key[e] = static_cast<uint32_t>((kKeep ? kk[e] : Codec<T>::enc(col[i])) >> begin_bit) & mask;
+                arrival[e] = atomicAdd(&hist[at(key[e])], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive prefix sums of the bins, in place: thread t owns bins [t per, t per + per)
+        const int per = nbin >= 1024 ? nbin / 1024 : 1;
+        uint32_t cnt[kCountPer], tot = 0;
+#pragma unroll
+        for (int u = 0; u < kCountPer; ++u) {
+            cnt[u] = (u < per && t * per + u < nbin) ? hist[at(t * per + u)] : 0u;
+            tot += cnt[u];
+        }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += up; }
+        uint32_t *wtot = hist + kCountWords;  // 16 words behind the histogram (part of the dynamic allocation)
+        if ((t & 63) == 63) wtot[t >> 6] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot;
+        for (int w = 0; w < (t >> 6); ++w) run += wtot[w];
+#pragma unroll
+        for (int u = 0; u < kCountPer; ++u)
+            if (u < per && t * per + u < nbin) { hist[at(t * per + u)] = run; run += cnt[u]; }
+        __syncthreads();
+        bool tied = false;
+        uint16_t *prow = pos + static_cast<size_t>(slot) * Gp, *lrow = lo + static_cast<size_t>(slot) * Gp, *hrow = hi + static_cast<size_t>(slot) * Gp;
+#pragma unroll
+        for (int e = 0; e < IPT; ++e) {
+            const int i = e * 1024 + t;
+            if (i >= G) continue;
+            const uint32_t l = hist[at(key[e])], h = static_cast<int>(key[e]) + 1 < nbin ? hist[at(key[e] + 1)] : static_cast<uint32_t>(G);
+            tied |= h - l > 1u;
+            prow[i] = static_cast<uint16_t>(l + arrival[e]);  // (rows of padded genes were zeroed by the caller)
+            lrow[i] = static_cast<uint16_t>(l);
+            hrow[i] = static_cast<uint16_t>(h);
+        }
+        if (tied && *anytie == 0) atomicOr(anytie, 1);
+        return;
+    }
     uint32_t k[IPT];
     uint16_t v[IPT];
 #pragma unroll
@@ -301,7 +366,8 @@ template <class T, int IPT>
 int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
 {
     using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
-    const size_t lds = std::max(sizeof(typename sorter::storage_type), static_cast<size_t>(IPT <= 24 ? 6 : 4) * c->Gp);
+    const size_t lds = std::max({sizeof(typename sorter::storage_type), static_cast<size_t>(IPT <= 24 ? 6 : 4) * c->Gp,
+                                 kCountingPath<T> ? sizeof(uint32_t) * kCountWords + 64 : size_t(0)});
     // every time: the attribute belongs to the (function, device) pair and a process may use several devices
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
