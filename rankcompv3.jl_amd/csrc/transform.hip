@@ -321,8 +321,8 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     }
 }
 
-// 16-bit rows -> bit planes over 32-sample blocks.  One thread per (gene, block): reads the gene's 32 numbers of
-// each of the three rows (coalesced over genes) and writes
+// 16-bit rows -> bit planes over 32-sample blocks.  One thread per (pair of genes, block): reads the genes' 32 numbers
+// of each of the three rows (coalesced over genes) and writes
 //   P  [nblk][4][Gp] uint4 : planes 4q..4q+3 of pos of gene g in block b at (b * 4 + q) * Gp + g   (lane operand)
 //   AL [nblk][Gp][4] uint4 : the 16 plane words of lo of gene g in block b at (b * Gp + g) * 4 ..   (tile operand)
 //   AH likewise for hi.
@@ -333,28 +333,44 @@ __global__ __launch_bounds__(256) void t_slice(const uint16_t *__restrict__ pos,
                                                const uint16_t *__restrict__ hi, int Gp, uint4 *__restrict__ P,
                                                uint4 *__restrict__ AL, uint4 *__restrict__ AH)
 {
-    const int g = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    const size_t row0 = static_cast<size_t>(b) * 32 * Gp + g;
-    uint32_t w[16];
+    // two adjacent genes per thread: their 32 x (16 + 16) bits of a block are one 32 x 32 bit matrix, transposed in
+    // registers by five rounds of masked swaps (480 operations for both genes; picking the bits one by one was 2 x 1024)
+    const int g = (blockIdx.x * 256 + threadIdx.x) * 2, b = blockIdx.y;
+    const size_t row0 = (static_cast<size_t>(b) * 32 * Gp + g) / 2;  // in pairs of 16-bit numbers
+    uint32_t w[32];
     auto planes = [&](const uint16_t *__restrict__ src) {
+        const uint32_t *src2 = reinterpret_cast<const uint32_t *>(src);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) w[k] = 0;
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const uint32_t v = src[row0 + static_cast<size_t>(s) * Gp];
+        for (int s = 0; s < 32; ++s) w[s] = src2[row0 + static_cast<size_t>(s) * (Gp / 2)];  // gene g in the low half, g + 1 in the high half
+        uint32_t m = 0x0000FFFFu;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) w[k] |= ((v >> k) & 1u) << s;
+        for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
+#pragma unroll
+            for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+                const uint32_t t = ((w[k] >> j) ^ w[k + j]) & m;
+                w[k] ^= t << j;
+                w[k + j] ^= t;
+            }
         }
+        // now w[k] = plane k of gene g (bit s = sample s), w[16 + k] = plane k of gene g + 1
     };
     planes(pos);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) P[(static_cast<size_t>(b) * 4 + q) * Gp + g] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+    for (int q = 0; q < 4; ++q) {
+        uint4 *o = P + (static_cast<size_t>(b) * 4 + q) * Gp + g;
+        o[0] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+        o[1] = uint4{w[16 + 4 * q], w[16 + 4 * q + 1], w[16 + 4 * q + 2], w[16 + 4 * q + 3]};
+    }
     auto skewed = [&](uint4 *__restrict__ dst) {
         uint4 *o = dst + (static_cast<size_t>(b) * Gp + g) * 4;
-        o[0] = uint4{w[1], w[2], w[3], w[4]};
-        o[1] = uint4{w[5], w[6], w[7], w[8]};
-        o[2] = uint4{w[9], w[10], w[11], w[12]};
-        o[3] = uint4{w[13], w[14], w[15], w[0]};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t *v = w + 16 * h;
+            o[4 * h + 0] = uint4{v[1], v[2], v[3], v[4]};
+            o[4 * h + 1] = uint4{v[5], v[6], v[7], v[8]};
+            o[4 * h + 2] = uint4{v[9], v[10], v[11], v[12]};
+            o[4 * h + 3] = uint4{v[13], v[14], v[15], v[0]};
+        }
     };
     planes(lo);
     skewed(AL);
@@ -430,7 +446,7 @@ int32_t transform_impl(reo_ctx *c)
     REO_HIP_CHECK(hipMemsetAsync(c->t_hi16.p, 0, n * sizeof(uint16_t), st));
     const T *X = static_cast<const T *>(c->dX);
     auto finish = [&](int has_ties) -> int32_t {
-        t_slice<<<dim3(Gp / 256, nblk), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p);
+        t_slice<<<dim3(Gp / 512, nblk), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p);
         REO_HIP_CHECK(hipGetLastError());
         c->has_ties = has_ties;
         c->transformed = true;
