@@ -1932,6 +1932,15 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     if (live) a.result[i] = p;
     const int m = live ? bh_rank(p, G, a.padj_deg) : G + 1;
     STAMP(a, 22);
+    {   // the histogram first: these atomics are performed at the memory side (they must be coherent across the XCDs) and
+        // the launch cannot end before the last of them has been -- about 4 us when they were the kernel's last
+        // instructions; issued here, the rest of the kernel runs in their shadow
+        int32_t *hist = a.hist + static_cast<size_t>(pbuf) * a.hist_stride;
+        const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
+        if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&hist[0], __popcll(first)); }
+        else if (m <= G) atomicAdd(&hist[m - 1], 1);
+        if (lane == 0 && finite) atomicAdd(&lc->sig[blockIdx.x & (kSpread - 1)][0], __popcll(finite));
+    }
     {   // every slot of the row is written (the mask step reads whole rows), transposed through LDS so that each wave
         // stores whole cache lines: rows written as scattered 4-byte pieces came back slowly in the next launch
         __shared__ int32_t row[256];
@@ -1959,11 +1968,6 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
         lds_barrier();
         if (threadIdx.x == 0) cl[blockIdx.x] = min(s_c, kListCap + 1);
     }
-    int32_t *hist = a.hist + static_cast<size_t>(pbuf) * a.hist_stride;
-    const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
-    if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&hist[0], __popcll(first)); }
-    else if (m <= G) atomicAdd(&hist[m - 1], 1);
-    if (lane == 0 && finite) atomicAdd(&lc->sig[blockIdx.x & (kSpread - 1)][0], __popcll(finite));
     STAMP(a, 23);
 }
 
