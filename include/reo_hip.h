@@ -210,7 +210,9 @@ int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);
  * 11 padded sample slots, 12 the last class table came from the shared
  * per-group counts (more than two groups: the one-vs-rest comparisons count
  * every group once and keep the counts in HBM; REO_SHARE_GROUP_COUNTS=0 in the
- * environment recounts per comparison), 13 bytes held by those counts. */
+ * environment recounts per comparison), 13 bytes held by those counts, 14 the last transform ranked every sample
+ * inside one workgroup, 15 the iteration passes keep their rank histogram per XCD (the self-test of reo_create passed;
+ * REO_XCC_LOCAL=0 switches it off). */
 int32_t reo_get_info(reo_ctx *ctx, int64_t *info, int32_t n);
 
 #ifdef __cplusplus

@@ -161,7 +161,7 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         (rc = c->state.ensure(1)) ||
         (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * (kSortChunk + kSortChunk / 32))) ||
         (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))) ||
-        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(2 * ((G + 32767) / 32768 * 32768))) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->clist.ensure(2 * kListStride)) || (rc = c->scal.ensure(64)))
+        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(2 * kHistParts * ((G + 32767) / 32768 * 32768))) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->clist.ensure(2 * kListStride)) || (rc = c->scal.ensure(64)))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
@@ -278,6 +278,17 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (const char *e = getenv("REO_LIGHT_MIN_G")) c->light_min_g = std::max(64, atoi(e));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return REO_EHIP; }
+    // The light passes keep their BH-rank histogram as one partial per XCD, updated by atomics that stay in that XCD's L2.
+    // That rests on two properties of the part, checked here once (a 20 us kernel): the XCC id register tells workgroups
+    // of different XCDs apart, and such atomics from different workgroups of one XCD do not lose updates.  If the check
+    // fails (or REO_XCC_LOCAL=0) the atomics are made coherent across the device instead -- slower, same results.
+    int ok = 0;
+    const char *xe = getenv("REO_XCC_LOCAL");
+    if (!(xe && xe[0] == '0')) {
+        const int32_t rc = xcc_selftest(c, &ok);
+        if (rc) { reo_destroy(c); return rc; }
+    }
+    c->xcc_local = ok;
     *out = c;
     return REO_OK;
 }
@@ -669,11 +680,11 @@ int32_t reo_get_timings(reo_ctx *c, double *ms, int32_t n)
 int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
 {
     if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
-    const int64_t v[15] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
+    const int64_t v[16] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
                            c->tiles_owned, c->tiles_total, kTileI, c->k1_cj, c->k1_q, kUnitH,
                            c->goff32.empty() ? 0 : c->goff32.back(), c->last_k1_shared,
-                           static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t)), c->transform_in_lds};
-    for (int i = 0; i < n && i < 15; ++i) info[i] = v[i];
+                           static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t)), c->transform_in_lds, c->xcc_local};
+    for (int i = 0; i < n && i < 16; ++i) info[i] = v[i];
     return REO_OK;
 }
 

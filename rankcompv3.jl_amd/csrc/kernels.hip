@@ -808,6 +808,7 @@ struct IterArgs {
     int32_t *mrank;              // [Gp]        light passes: m_i
     int replay;                  // 1: recompute the outputs of the last executed pass from its tallies, change no state
     int k2_idx;                  // index of this k2_tally launch (for the stage timers)
+    int xcc_local;               // light passes: the histogram atomics may stay in the XCD's L2 (reo_create's self-test passed)
     int32_t *clist; int band;    // light passes: genes near the BH cut listed by kl_rank ([2][kListStride]); half width of "near" in ranks
     int window, light_min_g;     // light passes: ranks on either side of a quantile that its window is made to hold; smallest G that uses them
     unsigned long long *stamps;  // diagnostic builds (-DREO_STAMPS): s_memrealtime marks of workgroup 0, else unused
@@ -1607,6 +1608,25 @@ constexpr int kHeadPre = 20;  // rows of 256 genes per wave whose BH ranks are r
 // hold 0 (rank 0 is always inside the cut: new bit 0 = old bit).
 __device__ __forceinline__ int mrank_slot(int i) { return (i & ~255) + 4 * (i & 63) + ((i >> 6) & 3); }
 
+// the XCD this wave runs on (0..7)
+__device__ __forceinline__ unsigned xcc_id()
+{
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x & (kHistParts - 1);
+}
+
+// reo_create's check of what the per-XCD histograms rest on: every wave adds 1 to 64 counters of its XCD's partial, 16
+// times, with atomics that need not be coherent beyond the XCD's L2, and notes its XCD.  Afterwards every partial must
+// hold exactly 16 x (waves that named it) in each counter.
+__global__ __launch_bounds__(256) void k_xcc_selftest(int32_t *part, int32_t *waves_of)
+{
+    const unsigned x = xcc_id();
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < 16; ++k) __hip_atomic_fetch_add(&part[x * 64 + lane], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) atomicAdd(&waves_of[x], 1);
+}
+
 // lane l's four words of row R of mrank (COH: coherent 8-byte loads, for the persistent kernel)
 template <bool COH>
 __device__ __forceinline__ int4 load_rank_row(const int32_t *mrank, int R, int lane)
@@ -1684,6 +1704,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     LightRec r;
     int bfail = 0, sig = 0;
     int hv[4][8];
+    int4 hx[kHistParts][2][2];
     int4 mv[kHeadPre];
     int2 le[kListPre];
     int lcnt[kListPre];
@@ -1692,13 +1713,20 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     double win[4];
     const int nrow = (G + 255) >> 8;
     if (b > 0) {
-        const int32_t *hist = a.hist + static_cast<size_t>(pb) * a.hist_stride;
+        // the histogram of the BH ranks is kept as one partial histogram per XCD (kl_rank); the first two tiles of each
+        // (4096 bins: enough unless more genes than that have a finite rank) are requested now and summed below
+        const int32_t *hist = a.hist + static_cast<size_t>(pb) * kHistParts * a.hist_stride;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int4 *hp = reinterpret_cast<const int4 *>(hist + (e * 256 + threadIdx.x) * 8);
-            const int4 h0 = hp[0], h1 = hp[1];
-            hv[e][0] = h0.x; hv[e][1] = h0.y; hv[e][2] = h0.z; hv[e][3] = h0.w; hv[e][4] = h1.x; hv[e][5] = h1.y; hv[e][6] = h1.z; hv[e][7] = h1.w;
-        }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hv[e][u] = 0;
+#pragma unroll
+        for (int x = 0; x < kHistParts; ++x)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + (e * 256 + threadIdx.x) * 8);
+                hx[x][e][0] = hp[0]; hx[x][e][1] = hp[1];
+            }
 #pragma unroll
         for (int q = 0; q < kHeadPre; ++q) {
             const int R = wave + 4 * q;
@@ -1746,12 +1774,32 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
             inref = i < G && a.refbytes[r.t & 1][i] != 0;
             lds_barrier();
         }
-    } else if (r.active && bfail) {
+    } else if (r.active && (bfail || sig > 8192)) {  // (more finite ranks than the histogram tiles read here resolve: sorting path too)
         r.active = 0; r.need_full = 1;  // pass r.t lost a quantile window: the sorting path redoes it (its tallies are in place)
     } else if (r.active) {
         // ---- the mask step of pass r.t (:413-424)
         const int t = r.t, cur = t & 1, nxt = cur ^ 1;
-        const int kstar = sig <= 8192 ? bh_cut4(hv, G) : bh_cut<false>(a.hist + static_cast<size_t>(pb) * a.hist_stride, G, sig);
+        {
+            const int32_t *hist = a.hist + static_cast<size_t>(pb) * kHistParts * a.hist_stride;
+#pragma unroll
+            for (int x = 0; x < kHistParts; ++x)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    hv[e][0] += hx[x][e][0].x; hv[e][1] += hx[x][e][0].y; hv[e][2] += hx[x][e][0].z; hv[e][3] += hx[x][e][0].w;
+                    hv[e][4] += hx[x][e][1].x; hv[e][5] += hx[x][e][1].y; hv[e][6] += hx[x][e][1].z; hv[e][7] += hx[x][e][1].w;
+                }
+            if (sig > 4096) {  // (workgroup-uniform) the other two tiles, now
+#pragma unroll 1
+                for (int x = 0; x < kHistParts; ++x)
+#pragma unroll
+                    for (int e = 2; e < 4; ++e) {
+                        const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + (e * 256 + threadIdx.x) * 8);
+                        const int4 h0 = hp[0], h1 = hp[1];
+                        hv[e][0] += h0.x; hv[e][1] += h0.y; hv[e][2] += h0.z; hv[e][3] += h0.w; hv[e][4] += h1.x; hv[e][5] += h1.y; hv[e][6] += h1.z; hv[e][7] += h1.w;
+                    }
+            }
+        }
+        const int kstar = bh_cut4(hv, G);
         if (!TAIL) STAMP(a, 1);
         if (threadIdx.x == 0) { s_n = 0; s_nn = 0; s_fb = 0; }
         lds_barrier();
@@ -1853,7 +1901,8 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         v = out[1];
         if (!TAIL) STAMP(a, 4);
         a.result[11 * static_cast<size_t>(G) + i] = v;
-        a.hist[static_cast<size_t>(pbuf) * a.hist_stride + i] = 0;  // this launch parity's histogram: last read two launches ago
+#pragma unroll
+        for (int x = 0; x < kHistParts; ++x) a.hist[(static_cast<size_t>(pbuf) * kHistParts + x) * a.hist_stride + i] = 0;  // this launch parity's histograms: last read two launches ago
         belowA = v < wa_lo; inA = !belowA && v <= wa_hi;
         belowB = v < wb_lo; inB = !belowB && v <= wb_hi;
         inner = v > wa_hi && v < wb_lo;
@@ -1935,10 +1984,20 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     {   // the histogram first: these atomics are performed at the memory side (they must be coherent across the XCDs) and
         // the launch cannot end before the last of them has been -- about 4 us when they were the kernel's last
         // instructions; issued here, the rest of the kernel runs in their shadow
-        int32_t *hist = a.hist + static_cast<size_t>(pbuf) * a.hist_stride;
+        // one partial histogram per XCD, updated with atomics that need not be coherent beyond the XCD's own L2 (only
+        // workgroups running on this XCD touch this partial): an atomic that has to be coherent across the XCDs is
+        // performed at the memory side, and 3 500 of those kept the launch alive for 4.5 us
         const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
-        if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&hist[0], __popcll(first)); }
-        else if (m <= G) atomicAdd(&hist[m - 1], 1);
+        const bool lead1 = m == 1 && lane == __ffsll(static_cast<long long>(first)) - 1;  // the hot bin: one add per wave
+        if (a.xcc_local) {
+            int32_t *hist = a.hist + (static_cast<size_t>(pbuf) * kHistParts + xcc_id()) * a.hist_stride;
+            if (lead1) __hip_atomic_fetch_add(&hist[0], __popcll(first), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (m >= 2 && m <= G) __hip_atomic_fetch_add(&hist[m - 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {  // (self-test failed or switched off: device-coherent atomics into partial 0)
+            int32_t *hist = a.hist + static_cast<size_t>(pbuf) * kHistParts * a.hist_stride;
+            if (lead1) atomicAdd(&hist[0], __popcll(first));
+            else if (m >= 2 && m <= G) atomicAdd(&hist[m - 1], 1);
+        }
         if (lane == 0 && finite) atomicAdd(&lc->sig[blockIdx.x & (kSpread - 1)][0], __popcll(finite));
     }
     {   // every slot of the row is written (the mask step reads whole rows), transposed through LDS so that each wave
@@ -2504,9 +2563,9 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     a.sorted_p = c->sorted_p.p; a.rank_s = c->rank_s.p; a.rank_a = c->rank_a.p;
     a.part = c->part.p; a.blockmin = c->blockmin.p; a.scal = c->scal.p;
     a.trace = c->trace.p; a.modes = nullptr;
-    a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / 2); a.mrank = c->mrank.p;
+    a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / (2 * kHistParts)); a.mrank = c->mrank.p;
     a.replay = replay; a.k2_idx = 0;
-    a.clist = c->clist.p; a.band = c->light_band;
+    a.clist = c->clist.p; a.band = c->light_band; a.xcc_local = c->xcc_local;
     a.window = c->light_window; a.light_min_g = c->light_min_g;
     a.stamps = reinterpret_cast<unsigned long long *>(c->scal.p + 32);
     return a;
@@ -2567,6 +2626,28 @@ int32_t launch_light_batch(reo_ctx *c, int nlight)
     if (nlight < 2) kl_head<true, false><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, nlight);
     else kl_head<true, true><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, nlight);
     REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t xcc_selftest(reo_ctx *c, int *ok)
+{
+    *ok = 0;
+    DevBuf<int32_t> buf;
+    int32_t rc = buf.ensure(kHistParts * 64 + kHistParts);
+    if (rc) return rc;
+    REO_HIP_CHECK(hipMemsetAsync(buf.p, 0, buf.n * sizeof(int32_t), c->stream));
+    k_xcc_selftest<<<1024, 256, 0, c->stream>>>(buf.p, buf.p + kHistParts * 64);
+    std::vector<int32_t> h(buf.n);
+    REO_HIP_CHECK(hipMemcpyAsync(h.data(), buf.p, buf.n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int64_t waves = 0;
+    bool good = true;
+    for (int x = 0; x < kHistParts; ++x) {
+        const int32_t w = h[kHistParts * 64 + x];
+        waves += w;
+        for (int l = 0; l < 64; ++l) good = good && h[x * 64 + l] == 16 * w;
+    }
+    *ok = good && waves == 1024 * 4 ? 1 : 0;
     return REO_OK;
 }
 

@@ -59,6 +59,7 @@ struct LightRec {
 // are performed one after the other (about 12 ns each): 316 waves adding to one word kept kl_rank alive for 3 us after
 // its last instruction.  Sums that need no return value are therefore spread over kSpread cache lines (by workgroup)
 // and added up by their readers.
+constexpr int kHistParts = 8;   // partial histograms of the BH ranks, one per XCD (kernels.hip, kl_rank)
 constexpr int kSpread = 8;
 constexpr int kListCap = 16;   // genes near the BH cut that one workgroup of kl_rank can list
 constexpr int kListStride = 256 + 256 * kListCap * 2;  // int32 per parity: counts by workgroup, then (word, gene) pairs
@@ -205,6 +206,7 @@ struct reo_ctx {
     reo::DevBuf<reo::LightState> lstate;  // [1] batch log of the two-launch light passes
     reo::DevBuf<int32_t> clist;         // [2][256 + 256 * kListCap * 2] genes near the BH cut, by workgroup (kernels.hip, kl_rank)
     int light_band = 32;                // REO_LIGHT_BAND (tests)
+    int xcc_local = 0;                  // the per-XCD histogram atomics may stay in the XCD's L2 (checked once per context: kernels.hip, xcc_selftest)
     int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
     int light_mode = 1;                 // 0 sorting passes only, 1 light passes as two launches each, 2 as one persistent launch (REO_LIGHT)
     reo::DevBuf<int32_t> hist, mrank;   // [2][G padded to whole 32768-bin rounds], [Gp] light passes: histogram of the BH ranks (by launch parity), the ranks
@@ -242,6 +244,7 @@ int32_t launch_tally(reo_ctx *c, int nref);
 int32_t launch_full_pass(reo_ctx *c, bool replay);
 int32_t launch_light_persistent(reo_ctx *c);
 int32_t launch_light_batch(reo_ctx *c, int nlight);
+int32_t xcc_selftest(reo_ctx *c, int *ok);
 int32_t light_min_genes();
 int32_t light_window();
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);

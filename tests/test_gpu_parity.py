@@ -883,8 +883,9 @@ def test_in_library_rccl_and_multi_context_from_python(pkg, oracle):
     _check_result(res0, exp)
 
 
-@pytest.mark.parametrize("window,light,band", [("3", "1", "32"), ("1", "1", "32"), ("12", "1", "2"), ("12", "1", "0"), ("3", "2", "32"), ("1", "2", "32")])
-def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monkeypatch, window, light, band):
+@pytest.mark.parametrize("window,light,band,xcc", [("3", "1", "32", "1"), ("1", "1", "32", "1"), ("12", "1", "2", "1"), ("12", "1", "0", "0"),
+                                                   ("3", "1", "32", "0"), ("3", "2", "32", "1"), ("1", "2", "32", "1")])
+def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monkeypatch, window, light, band, xcc):
     """The light iteration passes (quantile windows + BH cut from the histogram of step-up ranks) on many small random
     problems: REO_LIGHT_MIN_G lets small gene counts use them, and a window of 1-3 ranks makes windows lose their order
     statistic now and then, so the fall-back to the sorting path and the hand-over of the tally state between the two
@@ -894,6 +895,7 @@ def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monke
     monkeypatch.setenv("REO_LIGHT_MIN_G", "64")
     monkeypatch.setenv("REO_LIGHT_WINDOW", window)
     monkeypatch.setenv("REO_LIGHT", light)
+    monkeypatch.setenv("REO_XCC_LOCAL", xcc)   # 1: rank histogram per XCD with atomics that stay in its L2 (if the self-test passes); 0: device-coherent atomics
     monkeypatch.setenv("REO_LIGHT_BAND", band)  # half width of the list of genes near the BH cut: 0 and 2 make the cut leave it
     rng = np.random.default_rng(4242 + int(window) * 7 + int(light))
     light_batches = 0
@@ -908,7 +910,7 @@ def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monke
         ref0 = pkg.synth.ref_mask(G, max(3, G // 3), cs["seed"])
         n_iter, n_conv = int(rng.integers(6, 14)), int(rng.choice([0, 0, 1]))
         pval_deg, padj_deg = float(rng.choice([1.0, 1.0, 0.2])), float(rng.choice([0.05, 0.3, 0.9]))
-        tag = (window, light, band, case_no, cs["kind"], G, cs["S"], cs["ng"], n_iter, n_conv, pval_deg, padj_deg)
+        tag = (window, light, band, xcc, case_no, cs["kind"], G, cs["S"], cs["ng"], n_iter, n_conv, pval_deg, padj_deg)
         run = pkg.run_identify_degs(X, labels, list(range(G)), cs["pval_reo"], pval_deg, padj_deg, ref0, n_iter, n_conv,
                                     seed=cs["seed"], device=0, profile=True)
         Xf = np.asarray(X, dtype=np.float64)
@@ -924,6 +926,8 @@ def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monke
         if run.timings["k2_launches"] < sum(c["iters_run"] for c in run.comparisons) + 2 * len(run.comparisons):
             light_batches += 1
     assert light_batches > 0
+    if xcc == "1" and light == "1":
+        assert run.info["xcc_local_histograms"] == 1  # (the self-test of reo_create passes on an MI355X)
 
 
 @pytest.mark.parametrize("family,ngroups", [("t1", 2), ("t0", 2), ("float", 2), ("t1", 3)])
