@@ -1616,6 +1616,14 @@ __device__ __forceinline__ unsigned xcc_id()
     return x & (kHistParts - 1);
 }
 
+// add to one of the kSpread parts of a counter that its readers sum: by XCD with an atomic that stays in the XCD's L2 when
+// that has been checked (reo_create), else by workgroup with a device-coherent atomic
+__device__ __forceinline__ void spread_add(int32_t (*parts)[32], int v, bool xcc_local)
+{
+    if (xcc_local) __hip_atomic_fetch_add(&parts[xcc_id()][0], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAdd(&parts[blockIdx.x & (kSpread - 1)][0], v);
+}
+
 // reo_create's check of what the per-XCD histograms rest on: every wave adds 1 to 64 counters of its XCD's partial, 16
 // times, with atomics that need not be coherent beyond the XCD's L2, and notes its XCD.  Afterwards every partial must
 // hold exactly 16 x (waves that named it) in each counter.
@@ -1930,8 +1938,8 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     lds_barrier();
     if (threadIdx.x == 0) {
         const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
-        if (ba) atomicAdd(&lc->below_a[blockIdx.x & (kSpread - 1)][0], ba);
-        if (bb) atomicAdd(&lc->below_b[blockIdx.x & (kSpread - 1)][0], bb);
+        if (ba) spread_add(lc->below_a, ba, a.xcc_local);
+        if (bb) spread_add(lc->below_b, bb, a.xcc_local);
     }
     if (!TAIL) STAMP(a, 7);
 }
@@ -1998,7 +2006,7 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
             if (lead1) atomicAdd(&hist[0], __popcll(first));
             else if (m >= 2 && m <= G) atomicAdd(&hist[m - 1], 1);
         }
-        if (lane == 0 && finite) atomicAdd(&lc->sig[blockIdx.x & (kSpread - 1)][0], __popcll(finite));
+        if (lane == 0 && finite) spread_add(lc->sig, __popcll(finite), a.xcc_local);
     }
     {   // every slot of the row is written (the mask step reads whole rows), transposed through LDS so that each wave
         // stores whole cache lines: rows written as scattered 4-byte pieces came back slowly in the next launch
