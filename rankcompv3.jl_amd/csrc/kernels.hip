@@ -59,6 +59,14 @@ __device__ __forceinline__ void stc(T *p, T v)
     else *p = v;
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding global
+// load and STORE of the wave (s_waitcnt vmcnt(0): a write round trip of a microsecond or two in these latency-bound
+// kernels); this waits for the LDS traffic alone.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Binomial(n_eq, 1/2) draw standing in for n_eq calls of rand(Bool) in
 // is_greater (:72-73): one bit of a counter-based stream keyed by
 // (seed, i, j, group) per tied sample.
@@ -762,6 +770,51 @@ __device__ __forceinline__ void delta_counts(const uint32_t *__restrict__ table,
     }
 }
 
+// delta_counts for a workgroup of 256 threads that owns genes 256 b .. 256 b + 255 (thread = gene) and a list of at most
+// kDeltaMax entries in LDS.  A pass of the light path changes about twenty reference genes; four loads per entry in every
+// thread are 320 load instructions per CU and a round trip per eight entries.  Here the 8 words x 4 planes that hold the
+// workgroup's bits of a changed row are fetched once -- every entry's at the same time, one round trip, 32 n / 256 loads per
+// thread -- into LDS ([entry][word] as uint4 of the four planes), and each thread then reads one uint4 per entry.  The
+// eight sums are kept in packed 8-bit fields, separately for entering and leaving genes: A = cL | cH << 16,
+// B = tL | tH << 8, A * B = LL | LH << 8 | HL << 16 | HH << 24.  Whole workgroup (one barrier); buf: kDeltaMax * 8 uint4.
+__device__ __forceinline__ void delta_counts_block(const uint32_t *__restrict__ table, int Wp, const uint32_t *list, int n, int (&d)[kRaw], uint4 *buf)
+{
+    static_assert(kDeltaMax <= 255 && kDeltaMax * 32 <= 256 * 16, "8-bit fields; at most 16 fetches per thread");
+    const int items = n * 32;
+    uint32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int id = threadIdx.x + 256 * k;
+        v[k] = 0;
+        if (id < items) {
+            const uint32_t ent = list[id >> 5];
+            v[k] = table[(static_cast<size_t>(ent >> 1) * kPlanes + ((id >> 3) & 3)) * Wp + blockIdx.x * 8 + (id & 7)];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int id = threadIdx.x + 256 * k;
+        if (id < items) reinterpret_cast<uint32_t *>(buf)[((id >> 5) * 8 + (id & 7)) * 4 + ((id >> 3) & 3)] = v[k];
+    }
+    lds_barrier();
+    const int wi = threadIdx.x >> 5, sh = threadIdx.x & 31;
+    uint32_t accA[2] = {0, 0}, accB[2] = {0, 0}, accX[2] = {0, 0};  // [0] leaving, [1] entering
+#pragma unroll 4
+    for (int e = 0; e < n; ++e) {
+        const uint4 w = buf[e * 8 + wi];
+        // pair (i, j) seen from gene i: cL(i,j) = cH(j,i), cH(i,j) = cL(j,i), likewise for the treat side
+        const uint32_t A = ((w.y >> sh) & 1u) | (((w.x >> sh) & 1u) << 16);
+        const uint32_t B = ((w.w >> sh) & 1u) | (((w.z >> sh) & 1u) << 8);
+        const int s = list[e] & 1u;  // (uniform)
+        accA[s] += A; accB[s] += B; accX[s] += A * B;
+    }
+    auto f = [](uint32_t x, int at) { return static_cast<int>((x >> at) & 0xFFu); };
+    d[0] = f(accA[1], 0) - f(accA[0], 0);  d[1] = f(accA[1], 16) - f(accA[0], 16);
+    d[2] = f(accB[1], 0) - f(accB[0], 0);  d[3] = f(accB[1], 8) - f(accB[0], 8);
+    d[4] = f(accX[1], 0) - f(accX[0], 0);  d[5] = f(accX[1], 8) - f(accX[0], 8);
+    d[6] = f(accX[1], 16) - f(accX[0], 16); d[7] = f(accX[1], 24) - f(accX[0], 24);
+}
+
 __device__ __forceinline__ void delta_gene(const uint32_t *__restrict__ table, int Wp, const uint32_t *__restrict__ list,
                                            int n, int32_t *__restrict__ raw, int i)
 {
@@ -953,14 +1006,6 @@ __global__ __launch_bounds__(256) void k3_derive(IterArgs a)
     for (int q = 0; q < 9; ++q) result[(2 + q) * Gs + i] = static_cast<double>(c[q]);
     result[11 * Gs + i] = o[1]; result[12 * Gs + i] = o[2];
     result[13 * Gs + i] = o[3]; result[14 * Gs + i] = o[4];
-}
-
-// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding global
-// load and STORE of the wave (s_waitcnt vmcnt(0): a write round trip of a microsecond or two in these latency-bound
-// kernels); this waits for the LDS traffic alone.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // Sum over the 256 threads of a workgroup, the same bits in every thread and every workgroup: an
@@ -1702,6 +1747,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ uint32_t dl[kDeltaMax];
     __shared__ int s_n, s_nn, s_fb;
+    __shared__ uint4 dbuf[kDeltaMax * 8];
     __shared__ double red[256];
     __shared__ int wcnt[4][2];
     warm_kernargs<sizeof(IterArgs) + 16>();
@@ -1889,16 +1935,18 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     const double wa_lo = win[0], wa_hi = win[1], wb_lo = win[2], wb_hi = win[3];
     double v = 0.0;
     bool inner = false, inA = false, inB = false, belowA = false, belowB = false;
-    if (i < G) {
-        if (n) {
-            int d[kRaw];
-            delta_counts<false, 8>(a.table, a.Wp, dl, n, i, d);
-            if (!TAIL) STAMP(a, 3);
+    if (n) {  // (workgroup-uniform)
+        int d[kRaw];
+        delta_counts_block(a.table, a.Wp, dl, n, d, dbuf);
+        if (!TAIL) STAMP(a, 3);
+        if (i < G) {
             r0.x += d[0]; r0.y += d[1]; r0.z += d[2]; r0.w += d[3];
             r1.x += d[4]; r1.y += d[5]; r1.z += d[6]; r1.w += d[7];
             int4 *o = reinterpret_cast<int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
             o[0] = r0; o[1] = r1;
         }
+    }
+    if (i < G) {
         int32_t c[9];
         const int total = r.nref - (inref ? 1 : 0);  // the diagonal is never set (:363,385)
         c[0] = r1.x; c[2] = r1.y; c[6] = r1.z; c[8] = r1.w;
@@ -1958,7 +2006,7 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     const bool live = i < G;
     LightSlot *sl = &ls->slot[b];
     LightCnt *lc = &sl->lc;
-    const int active = sl->rec.active;
+    const int active = sl->rec.active, rec_t = sl->rec.t, rec_kstar = sl->rec.kstar;
     const int cnt_a = lc->cnt_a, cnt_b = lc->cnt_b;
     int below_a = 0, below_b = 0;
 #pragma unroll
@@ -1968,6 +2016,9 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     if (static_cast<int>(threadIdx.x) < (G + 255) / 256) { pn = a.part[3 * threadIdx.x]; pm = a.part[3 * threadIdx.x + 1]; pq = a.part[3 * threadIdx.x + 2]; }
     const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
     const double d1 = live ? a.result[11 * static_cast<size_t>(G) + i] : 0.0;
+    // this gene's mask bit, both parities (which one counts is in the record, not known yet): asked for here because a load
+    // issued behind the stores further down would wait for them to be acknowledged
+    const uint8_t ob_e = live ? a.refbytes[0][i] : 0, ob_o = live ? a.refbytes[1][i] : 0;
     if (!active) return;
     STAMP(a, 20);
     __shared__ double red[256];
@@ -2011,19 +2062,19 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     {   // every slot of the row is written (the mask step reads whole rows), transposed through LDS so that each wave
         // stores whole cache lines: rows written as scattered 4-byte pieces came back slowly in the next launch
         __shared__ int32_t row[256];
-        const uint32_t oldbit = live && a.refbytes[sl->rec.t & 1][i] != 0 ? 0x80000000u : 0u;
+        const uint32_t oldbit = ((rec_t & 1) ? ob_o : ob_e) != 0 ? 0x80000000u : 0u;
         row[4 * lane + wave] = live ? static_cast<int32_t>(static_cast<uint32_t>(p <= a.pval_deg ? m : G + 2) | oldbit) : 0;
         lds_barrier();
         a.mrank[blockIdx.x * 256 + threadIdx.x] = row[threadIdx.x];
     }
-    if (sl->rec.kstar >= 0) {
+    if (rec_kstar >= 0) {
         // the genes whose mask bit can change at the next mask step if its cut lands within `band` ranks of the last one:
         // ranks inside the band, and bits that are wrong for every cut in it.  By workgroup, no global atomics.
         __shared__ int s_c;
         if (threadIdx.x == 0) s_c = 0;
         lds_barrier();
-        const int kp = sl->rec.kstar, rk = p <= a.pval_deg ? m : G + 2;
-        const bool ob = a.refbytes[sl->rec.t & 1][live ? i : 0] != 0;
+        const int kp = rec_kstar, rk = p <= a.pval_deg ? m : G + 2;
+        const bool ob = ((rec_t & 1) ? ob_o : ob_e) != 0;
         const bool want = live && ((rk > kp - a.band && rk <= kp + a.band) || (rk > kp + a.band && !ob) || (rk <= kp - a.band && ob));
         const unsigned long long cm = __ballot(want);
         int pos = 0;
