@@ -405,9 +405,15 @@ int32_t reo_compute_thresholds(reo_ctx *c, double pval_reo)
     std::vector<int32_t> cnt(c->ngroups, 0);
     for (int32_t g : c->group_id) cnt[g]++;
     c->thr.assign(2 * c->ngroups, 0);
+    std::vector<std::pair<int32_t, int32_t>> seen;  // (n, threshold) of this call: group sizes repeat (two balanced groups: one n, four uses)
+    auto threshold_of = [&](int32_t n) {
+        for (const auto &s : seen) if (s.first == n) return s.second;
+        seen.emplace_back(n, major_reo_lower_count(n, pval_reo));
+        return seen.back().second;
+    };
     for (int k = 0; k < c->ngroups; ++k) {  // threshold = f.(hcat(gsi1,gsi2)'), :362
-        c->thr[2 * k] = major_reo_lower_count(cnt[k], pval_reo);
-        c->thr[2 * k + 1] = major_reo_lower_count(S - cnt[k], pval_reo);
+        c->thr[2 * k] = threshold_of(cnt[k]);
+        c->thr[2 * k + 1] = threshold_of(S - cnt[k]);
         if (c->thr[2 * k] < 0 || c->thr[2 * k + 1] < 0) {
             set_error("no count in 0..n/2 has a two-sided binomial p above %g (the reference's findfirst returns nothing)", pval_reo);
             return REO_EINVAL;
