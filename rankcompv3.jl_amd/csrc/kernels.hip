@@ -1048,10 +1048,30 @@ __device__ __forceinline__ void block_sum2_256(double v, double w, double *red, 
 // compare-exchange with the partner's element: keep the smaller value if keep_min, else the larger.
 // Equal values need no tie-break here: any consistent order among them still makes the ranks
 // permutations, and every quantity derived from them (sorted values, BH, trimmed std) is identical.
+// Value of lane (l ^ J): quad permutes (DPP, no LDS traffic) for J = 1, 2; ds_swizzle (no address register) for
+// J = 4, 8, 16; ds_bpermute for 32.  __shfl_xor always takes the last route (two dependent LDS round trips per double);
+// the 21 stages of the sort below were 2.2 us of kl_rank that way.
+template <int J>
+__device__ __forceinline__ int lane_xor_b32(int v)
+{
+    if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (J < 32) return __builtin_amdgcn_ds_swizzle(v, (J << 10) | 0x1F);          // bit mode: and 0x1F, or 0, xor J
+    else return __shfl_xor(v, J, 64);
+}
+template <int J>
+__device__ __forceinline__ double lane_xor(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = lane_xor_b32<J>(static_cast<int>(b)), hi = lane_xor_b32<J>(static_cast<int>(b >> 32));
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
 __device__ __forceinline__ void cmpx(double &v, uint32_t &i, double pv, uint32_t pi, bool keep_min)
 {
-    const bool take = keep_min ? (pv < v) : (pv > v);
-    if (take) { v = pv; i = pi; }
+    const bool take = ((pv < v) & keep_min) | ((pv > v) & !keep_min);  // (bitwise: no divergent branches)
+    v = take ? pv : v;
+    i = take ? pi : i;
 }
 
 // Bitonic sort of one kSortChunk-gene chunk, one element per thread: exchange distances 1..32 go through wave
@@ -1069,16 +1089,25 @@ __global__ __launch_bounds__(kSortChunk) void k3_sort_chunks(IterArgs a)
     for (int k = 2; k <= kSortChunk; k <<= 1) {
         const bool up = (t & k) == 0;
         for (int j = k >> 1; j >= 64; j >>= 1) {  // partner in another wave
-            __syncthreads();
+            lds_barrier();
             sv[t] = v; si[t] = static_cast<uint16_t>(id);
-            __syncthreads();
+            lds_barrier();
             cmpx(v, id, sv[t ^ j], si[t ^ j], ((t & j) == 0) == up);
         }
-        for (int j = (k >> 1) < 32 ? (k >> 1) : 32; j >= 1; j >>= 1) {  // inside the wave
-            const double pv = __shfl_xor(v, j, 64);
-            const uint32_t pi = __shfl_xor(id, j, 64);
-            cmpx(v, id, pv, pi, ((t & j) == 0) == up);
-        }
+        // inside the wave: quad permutes / swizzles (lane_xor), starting at distance min(k / 2, 32)
+        const int j0 = (k >> 1) < 32 ? (k >> 1) : 32;  // workgroup-uniform
+        auto stage = [&](auto J) {
+            constexpr int jj = decltype(J)::value;
+            const double pv = lane_xor<jj>(v);
+            const uint32_t pi = static_cast<uint32_t>(lane_xor_b32<jj>(static_cast<int>(id)));
+            cmpx(v, id, pv, pi, ((t & jj) == 0) == up);
+        };
+        if (j0 >= 32) stage(std::integral_constant<int, 32>{});
+        if (j0 >= 16) stage(std::integral_constant<int, 16>{});
+        if (j0 >= 8) stage(std::integral_constant<int, 8>{});
+        if (j0 >= 4) stage(std::integral_constant<int, 4>{});
+        if (j0 >= 2) stage(std::integral_constant<int, 2>{});
+        stage(std::integral_constant<int, 1>{});
     }
     a.chunk_v[base + t] = v; a.chunk_i[base + t] = static_cast<uint16_t>(id);
     // every 32nd element once more, packed: k3_merge_rank stages these into LDS with contiguous loads
@@ -1396,25 +1425,6 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
 // Only the pass that ends the loop needs padj values and the other output columns: they are recomputed from its
 // tallies by the sorting path (replay).  Two launches per pass (kl_head, kl_rank) instead of seven, or one persistent
 // launch (kl_persist); none of them searches or sorts G values.
-
-// Value of lane (l ^ J): quad permutes (DPP, no LDS traffic) for J = 1, 2; ds_swizzle (no address register) for
-// J = 4, 8, 16; ds_bpermute for 32.  __shfl_xor always takes the last route (two dependent LDS round trips per double);
-// the 21 stages of the sort below were 2.2 us of kl_rank that way.
-template <int J>
-__device__ __forceinline__ int lane_xor_b32(int v)
-{
-    if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
-    else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    else if constexpr (J < 32) return __builtin_amdgcn_ds_swizzle(v, (J << 10) | 0x1F);          // bit mode: and 0x1F, or 0, xor J
-    else return __shfl_xor(v, J, 64);
-}
-template <int J>
-__device__ __forceinline__ double lane_xor(double x)
-{
-    const long long b = __double_as_longlong(x);
-    const int lo = lane_xor_b32<J>(static_cast<int>(b)), hi = lane_xor_b32<J>(static_cast<int>(b >> 32));
-    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
-}
 
 // Bitonic sort of the 64 doubles a wave holds (one per lane), ascending by lane: 21 compare-exchange stages, no barrier.
 template <int K, int J>
