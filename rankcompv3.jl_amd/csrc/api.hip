@@ -593,8 +593,9 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (getenv("REO_DEBUG_PASSES"))
-            fprintf(stderr, "batch: %d sorting + %d light launches, passes %d -> %d, need_full %d, done %d, last_full %d\n", nfull, nlight,
-                    passes, c->host_state->passes, c->host_state->need_full, c->host_state->done, c->host_state->last_full);
+            fprintf(stderr, "batch: %d sorting + %d light launches, passes %d -> %d, need_full %d, done %d, last_full %d, changed genes in front of the next pass %d\n", nfull, nlight,
+                    passes, c->host_state->passes, c->host_state->need_full, c->host_state->done, c->host_state->last_full,
+                    c->host_state->delta_cnt[c->host_state->passes & 1]);
         if (c->host_state->fault) {
             set_error("the persistent iteration kernel gave up at a grid barrier (a workgroup did not arrive within its bound); "
                       "REO_LIGHT=1 runs the same passes as separate launches");
