@@ -570,8 +570,9 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // the sorting path -- needed for the first pass, whenever the reference set changed by more genes than a tally
     // update takes, and when a quantile window lost its order statistic -- and the light path.  A batch = two
     // sorting passes, or a run of light passes; small problems sort every pass.
-    const bool small = G < c->light_min_g || c->light_mode == 0;
-    int passes = 0, seen_need_full = 1, light_batches = 0;
+    bool small = G < c->light_min_g || c->light_mode == 0;
+    c->it_no_light = false;
+    int passes = 0, seen_need_full = 1, light_batches = 0, idle_light = 0;  // idle_light: light batches in a row that completed no pass
     while (n_iter > 0) {  // :400
         const int remaining = n_iter - passes;
         // the state read after the last batch says which kind of pass is due: sorting launches are enqueued only then
@@ -600,6 +601,13 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
             set_error("the persistent iteration kernel gave up at a grid barrier (a workgroup did not arrive within its bound); "
                       "REO_LIGHT=1 runs the same passes as separate launches");
             return REO_EHIP;
+        }
+        if (nlight > 0) idle_light = c->host_state->passes == passes ? idle_light + 1 : 0;
+        if (idle_light >= 2 && !small) {
+            // two light batches in a row completed no pass (each ended by handing its first pass to the sorting path, which
+            // leaves need_full set): sorting passes for the rest of the call
+            small = true;
+            c->it_no_light = true;
         }
         passes = c->host_state->passes;
         seen_need_full = c->host_state->need_full;

@@ -1602,7 +1602,9 @@ __device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand,
 // The BH cut from the first four 2048-bin tiles of the histogram, already in registers (hv[e]: bins (e * 256 + thread) * 8
 // ...+7): bh_cut for a histogram whose finite ranks number at most 8192.  Bins past the bound may hold counts; they
 // cannot qualify (H never exceeds the number of finite ranks), so no masking is needed.
-__device__ __forceinline__ int bh_cut4(const int (&hv)[4][8], int G)
+// tile0, carry: the four tiles are tiles tile0 .. tile0 + 3 of the histogram and `carry` ranks lie in the tiles before them
+// (updated to include these four); a trailing barrier lets the call be repeated.
+__device__ __forceinline__ int bh_cut4(const int (&hv)[4][8], int G, int tile0, int &carry_io)
 {
     __shared__ __attribute__((aligned(16))) int wsum[4][4];
     __shared__ int wbest[4];
@@ -1622,21 +1624,24 @@ __device__ __forceinline__ int bh_cut4(const int (&hv)[4][8], int G)
 #pragma unroll
         for (int e = 0; e < 4; ++e) wsum[e][wave] = inc[e];
     lds_barrier();
-    int best = 0, carry = 0;
+    int best = 0, carry = carry_io;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int4 ws = *reinterpret_cast<const int4 *>(wsum[e]);
         int run = carry + inc[e] - s[e] + (wave > 0 ? ws.x : 0) + (wave > 1 ? ws.y : 0) + (wave > 2 ? ws.z : 0);
-        const int r0 = (e * 256 + threadIdx.x) * 8 + 1;
+        const int r0 = ((tile0 + e) * 256 + threadIdx.x) * 8 + 1;
 #pragma unroll
         for (int u = 0; u < 8; ++u) { run += hv[e][u]; if (r0 + u <= G && run >= r0 + u) best = max(best, r0 + u); }
         carry += ws.x + ws.y + ws.z + ws.w;
     }
+    carry_io = carry;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(best, o, 64); best = u > best ? u : best; }
     if (lane == 0) wbest[wave] = best;
     lds_barrier();
-    return max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
+    const int k = max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
+    lds_barrier();  // wsum / wbest may be rewritten by the next call
+    return k;
 }
 
 // Touch every 64-byte line of the kernel's argument block at once.  The compiler loads arguments where they are first
@@ -1838,7 +1843,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
             inref = i < G && a.refbytes[r.t & 1][i] != 0;
             lds_barrier();
         }
-    } else if (r.active && (bfail || sig > 8192)) {  // (more finite ranks than the histogram tiles read here resolve: sorting path too)
+    } else if (r.active && bfail) {
         r.active = 0; r.need_full = 1;  // pass r.t lost a quantile window: the sorting path redoes it (its tallies are in place)
     } else if (r.active) {
         // ---- the mask step of pass r.t (:413-424)
@@ -1863,7 +1868,29 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
                     }
             }
         }
-        const int kstar = bh_cut4(hv, G);
+        int carry = 0;
+        int kstar = bh_cut4(hv, G, 0, carry);
+        if (sig > 8192) {  // (workgroup-uniform; rare: more than 8192 genes inside or near the cut) the tiles after the first four, four at a time
+            const int32_t *hist = a.hist + static_cast<size_t>(pb) * kHistParts * a.hist_stride;
+            const int ntile = (min(G, sig) + 2047) / 2048;
+#pragma unroll 1
+            for (int tile0 = 4; tile0 < ntile; tile0 += 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hv[e][u] = 0;
+#pragma unroll 1
+                for (int x = 0; x < kHistParts; ++x)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if ((tile0 + e) * 2048 >= a.hist_stride) continue;  // (past the histogram: no such ranks)
+                        const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + ((tile0 + e) * 256 + threadIdx.x) * 8);
+                        const int4 h0 = hp[0], h1 = hp[1];
+                        hv[e][0] += h0.x; hv[e][1] += h0.y; hv[e][2] += h0.z; hv[e][3] += h0.w; hv[e][4] += h1.x; hv[e][5] += h1.y; hv[e][6] += h1.z; hv[e][7] += h1.w;
+                    }
+                kstar = max(kstar, bh_cut4(hv, G, tile0, carry));
+            }
+        }
         if (!TAIL) STAMP(a, 1);
         if (threadIdx.x == 0) { s_n = 0; s_nn = 0; s_fb = 0; }
         lds_barrier();
@@ -2289,7 +2316,8 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
         for (int q = 0; q < kSpread; ++q) sig += ldc<true>(&lc->sig[q][0]);
         STAMP(a, 5);
         const int t = r.t, nxt = par ^ 1;
-        const int kstar = sig <= 8192 ? bh_cut4(hv, G) : bh_cut<true>(hist, G, sig);
+        int carry0 = 0;
+        const int kstar = sig <= 8192 ? bh_cut4(hv, G, 0, carry0) : bh_cut<true>(hist, G, sig);
         STAMP(a, 6);
         if (threadIdx.x == 0) { s_n = 0; s_nn = 0; }
         lds_barrier();
@@ -2635,7 +2663,9 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / (2 * kHistParts)); a.mrank = c->mrank.p;
     a.replay = replay; a.k2_idx = 0;
     a.clist = c->clist.p; a.band = c->light_band; a.xcc_local = c->xcc_local;
-    a.window = c->light_window; a.light_min_g = c->light_min_g;
+    // (no light passes -- switched off, or given up by the running call: the sorting path then leaves need_full set, else its
+    //  launches would wait for light passes that nobody enqueues)
+    a.window = c->light_window; a.light_min_g = (c->it_no_light || c->light_mode == 0) ? 0x7FFFFFFF : c->light_min_g;
     a.stamps = reinterpret_cast<unsigned long long *>(c->scal.p + 32);
     return a;
 }

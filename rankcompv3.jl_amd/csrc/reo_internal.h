@@ -214,6 +214,7 @@ struct reo_ctx {
     double it_pval_deg = 1.0, it_padj_deg = 0.05;
     int it_n_iter = 0, it_n_conv = 0, it_a0 = 0, it_b0 = 0;
     int k2_idx = 0;                     // K2 launches of the running call
+    bool it_no_light = false;           // the running call has given up on light passes (two light batches in a row completed no pass)
     reo::IterState *host_state = nullptr;  // pinned
 
     // timing

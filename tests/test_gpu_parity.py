@@ -930,6 +930,28 @@ def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monke
         assert run.info["xcc_local_histograms"] == 1  # (the self-test of reo_create passes on an MI355X)
 
 
+def test_sorting_passes_only_and_large_cuts_at_a_size_that_uses_light_passes(pkg, monkeypatch):
+    """REO_LIGHT=0 (sorting passes only) on a problem large enough for light passes -- the sorting path must then keep
+    asking for itself (a call once waited for ever for light passes that nobody enqueued) -- and cut-offs that put
+    thousands of genes inside or near the BH cut (histogram tiles beyond the first four): the same results as the default."""
+    G, S, seed = 20000, 64, 0x5EED0093
+    X = pkg.synth.t1_counts(G, S, seed)
+    group = pkg.synth.groups(S)
+    ref0 = pkg.synth.ref_mask(G, 3000, seed)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REO_LIGHT", mode)
+        with pkg.Context(device=0, seed=seed) as ctx:
+            gid, lev = pkg.encode_groups(group)
+            ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01); ctx.build_pairs(0)
+            out[mode] = [ctx.identify_degs(ref0, 1.0, padj, 16, 0) for padj in (0.05, 0.9)]
+    for (r1, i1, t1), (r0, i0, t0) in zip(out["1"], out["0"]):
+        assert i1 == i0 == 16 and t1 == t0
+        assert np.array_equal(r1[:, 2:11], r0[:, 2:11])
+        ok = np.isfinite(r0).all(axis=1)
+        assert np.allclose(r1[ok][:, :2], r0[ok][:, :2], rtol=0, atol=P_ATOL)
+
+
 @pytest.mark.parametrize("family,ngroups", [("t1", 2), ("t0", 2), ("float", 2), ("t1", 3)])
 def test_more_than_65535_samples(pkg, oracle, family, ngroups):
     """Single-cell mode without pseudo-bulking (src/RankCompV3.jl:608-616 with n_pseudo = 0) can hand over more samples
