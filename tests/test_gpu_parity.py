@@ -310,8 +310,8 @@ def test_full_size_one_vs_rest_codes_on_sampled_blocks(pkg, oracle):
                 assert np.array_equal(got, exp), (k, i0, j0)
 
 
-@pytest.mark.parametrize("exchange,world", [("sum", 2), ("gather", 2), ("gather", 3), ("gather", 8)])
-def test_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle, exchange, world):
+@pytest.mark.parametrize("exchange,world,family", [("sum", 2, "t1"), ("gather", 2, "t1"), ("gather", 3, "t1"), ("gather", 8, "t1"), ("gather", 3, "t0")])
+def test_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle, exchange, world, family):
     """G-sharding: `world` contexts (shards r / world) on one GPU, their exchange hooks joined by a thread barrier.
     Before the exchange owned pairs carry the oracle's codes and the others are empty; after the one exchange of the
     class table -- "sum": in-place sum of the whole table (reo_set_allreduce); "gather": all-gather of the shards' own
@@ -321,7 +321,8 @@ def test_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle, exchange, wo
     import threading
     import torch
     G, S, seed = 2300, 24, 0x5EED0005
-    X = pkg.synth.t1_counts(G, S, seed)
+    ties = family == "t1"   # (tie-free data: work units four times as wide as the padded table)
+    X = (pkg.synth.t1_counts if ties else pkg.synth.t0_ranks)(G, S, seed)
     group = pkg.synth.groups(S)
     gid, lev = pkg.encode_groups(group)
     ref0 = pkg.synth.ref_mask(G, 200, seed)
@@ -364,7 +365,7 @@ def test_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle, exchange, wo
                 ctx.build_pairs(0)          # no exchange configured yet: the shard's own part of the table
                 info = ctx.info()
                 got = ctx.get_codes(0, G, 0, G)
-                mask = pkg.sharding.owned_pair_mask(G, info["sample_slots"], True, rank, world)
+                mask = pkg.sharding.owned_pair_mask(G, info["sample_slots"], ties, rank, world)
                 off = ~np.eye(G, dtype=bool)
                 assert np.array_equal(got[mask], code[mask])
                 assert (got[off & ~mask] == 4).all()
@@ -392,7 +393,7 @@ def test_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle, exchange, wo
         t.join(timeout=300)
     assert not errors, errors
     owned = [results[r][0]["tiles_owned"] for r in range(world)]
-    assert sum(owned) == results[0][0]["tiles_total"] and (min(owned) > 0 or world == 8)  # (five work units: three of eight shards own none)
+    assert sum(owned) == results[0][0]["tiles_total"] and (min(owned) > 0 or world == 8 or not ties)  # (five work units, three with tie-free data: some shards own none)
     for r in range(world):
         info, cont, (res, iters, trace) = results[r]
         assert np.array_equal(cont, oracle.tally(code, ref0))
