@@ -124,7 +124,7 @@ def main() -> None:
         if world > 1 or force_comm:
             if args.debug_gloo_one_gpu:
                 ctx.set_shard(rank, world)
-                ctx.set_allreduce(pkg.dist.allreduce_hook(dev, via_host=True))
+                ctx.set_allgather(pkg.dist.allgather_hook(dev, via_host=True))  # the protocol of the RCCL path, carried by gloo
             else:  # in-library RCCL: rank 0 makes the id, torch.distributed only carries its 128 bytes
                 with _StdoutToStderr():
                     box = [pkg._ffi.comm_unique_id() if rank == 0 else None]

@@ -64,9 +64,10 @@ def allreduce_hook(device=None, group=None, via_host: bool = False):
     return fn
 
 
-def allgather_hook(device, group=None):
+def allgather_hook(device, group=None, via_host: bool = False):
     """fn(send_ptr, recv_ptr, bytes_per_rank, stream): all-gather of the shards' packed table words through
-    torch.distributed (RCCL), enqueued on the library's HIP stream."""
+    torch.distributed (RCCL), enqueued on the library's HIP stream.  via_host=True stages the buffers through the host so
+    that a gloo group can carry them (several ranks on one GPU, where RCCL refuses to run)."""
     import torch
     import torch.distributed as dist
 
@@ -76,7 +77,14 @@ def allgather_hook(device, group=None):
         with torch.cuda.stream(ext):
             src = torch.as_tensor(_RawDevBytes(send, nbytes), device=device)
             dst = torch.as_tensor(_RawDevBytes(recv, nbytes * world), device=device)
-            dist.all_gather_into_tensor(dst, src, group=group)
+            if via_host:
+                ext.synchronize()
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, src.cpu(), group=group)
+                dst.copy_(torch.cat(parts))
+                ext.synchronize()
+            else:
+                dist.all_gather_into_tensor(dst, src, group=group)
 
     return fn
 
