@@ -43,6 +43,28 @@ def test_pair_masks_cover_every_pair_once(pkg):
     assert all(np.array_equal(m, m.T) for m in masks) and all(m.any() for m in masks)
 
 
+@pytest.mark.parametrize("G,ties,world", [(1400, True, 3), (2300, False, 3), (2300, True, 8), (3100, True, 2)])
+def test_gather_exchange_mirror_assembles_the_table(pkg, G, ties, world):
+    """pack_units / expand_units (the numpy mirror of x_pack / x_expand_fwd / x_expand_mirror): every shard packs the forward
+    rectangles of its own work units, all packs go to everybody, and every shard ends with the complete table -- uneven
+    unit counts, more shards than units, units wider than the table."""
+    sh = pkg.sharding
+    rng = np.random.default_rng(G + world)
+    code = rng.integers(0, 9, size=(G, G)).astype(np.uint8)
+    iu = np.triu_indices(G, 1)
+    code[iu[1], iu[0]] = (2 - code[iu] // 3) * 3 + (2 - code[iu] % 3)   # the pair seen from the other gene: low <-> high on both sides
+    np.fill_diagonal(code, 255)
+    slots = 64
+    whole = sh.class_planes(code)
+    parts = [np.ascontiguousarray(sh.class_planes(code, sh.owned_pair_mask(G, slots, ties, r, world))) for r in range(world)]
+    assert sum(int(p.sum()) for p in parts) == int(whole.sum())
+    packs = np.stack([sh.pack_units(parts[r], G, slots, ties, r, world) for r in range(world)])
+    for r in range(world):
+        t = parts[r].copy()
+        sh.expand_units(t, packs, G, slots, ties, r, world)
+        assert np.array_equal(t, whole), (r, world)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
