@@ -8,7 +8,10 @@
 //   K2  k2_tally    class table x reference mask -> per-gene tallies   (:403)
 //       (delta form: the same launch updates the counters from the rows of the genes whose mask bit changed)
 //   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask, loop control (:404-425,225-259): the
-//                   sorting path; kl_* the light passes (no sort: quantile windows + BH cut by histogram)
+//                   sorting path; kl_head + kl_rank the light passes, two launches each (no sort: quantile
+//                   windows + BH cut from per-XCD histograms + a list of the genes near the cut); kl_persist the same
+//                   as one persistent launch (opt-in)
+//       x_pack / x_expand_*  exchange of the class table between shards: all-gather of forward words
 //
 // All file:line citations are relative to /root/reference.
 //
