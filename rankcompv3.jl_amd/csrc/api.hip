@@ -270,6 +270,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (!c) { set_error("out of host memory"); return REO_ENOMEM; }
     c->device = device;
     c->seed = seed;
+    if (const char *e = getenv("REO_K1_WAVE")) c->k1_wave = (e[0] != '0');
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
     if (const char *e = getenv("REO_LIGHT_BAND")) c->light_band = std::max(0, atoi(e));
     if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);

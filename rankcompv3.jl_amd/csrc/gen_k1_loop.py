@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled gfx950 pair-count loops of K1 (k1_loop_gen.inc).
+
+    python3 gen_k1_loop.py > k1_loop_gen.inc        (the Makefile does this; the .inc is committed as well)
+
+One loop = one inline-asm statement that counts, for ONE wave and one range of 32-sample blocks,
+    n(i, j) = #{s : pos_j(s) < edge_i(s)}     for the 32 gene rows i of a tile and the wave's 64 * RJ genes j
+bit-sliced as in kernels.hip (count_pass): per row and block NB v_bitop3_b32 per chain (borrow of edge_i - pos_j,
+plane by plane) and one v_bcnt_u32_b32.  What the hand schedule does that the compiler's did not (ISA of round 2):
+  * no wait states between the plane steps (the compiler padded every asm statement with s_nop 0);
+  * the tile operand (edge planes of the 32 rows, wave-uniform) is read from LDS one row AHEAD, quad by quad as the
+    registers of the running row are consumed, with counted s_waitcnt lgkmcnt(N) -- no LDS latency in the row loop;
+  * the tile operand reaches LDS by LDS-DMA (global_load_lds_dwordx4) one block ahead, into a 2-slot ring that belongs
+    to the wave alone: no barrier anywhere, every wave is an independent work item;
+  * the lane operand (pos planes of the wave's genes, 60-64 VGPRs) of the NEXT block is requested during the LAST row of
+    the running block, each register quad as soon as its last reader has issued;
+  * counted s_waitcnt vmcnt(N) throughout (the generator keeps the queues and asserts the loop invariant).
+
+Register file of a loop (tie-free, RJ = 4): acc 64 (two 16-bit counts per register: rows 2h, 2h+1), pos planes 64,
+row operand 16 + 4 (the quad that holds plane 0 is double-buffered), chains 4, addresses 4.
+With ties (RJ = 2, edges lo and hi): acc 64 (gt and ge), pos planes 32, row operands 2 x 20, chains 4.
+
+Data layout (kernels.hip header): P uint4 [nblk][4][Gp] (plane quad q of gene g in block b at (b*4+q)*Gp + g);
+AL / AH uint4 [nblk][Gp][4], plane k in word (k + 15) % 16.
+"""
+import sys
+
+RI = 32
+
+
+def a_word(k):
+    return (k + 15) & 15
+
+
+class Loop:
+    def __init__(self, nb, ties, name, lshl_add=True):
+        self.nb, self.ties, self.name = nb, ties, name
+        self.rj = 2 if ties else 4
+        self.lines = []
+        self.lq = []   # outstanding LDS reads, oldest first (tags)
+        self.vq = []   # outstanding vector-memory operations, oldest first (tags)
+        self.lshl_add = lshl_add
+        self.label_n = 0
+        # ---- VGPRs owned by the statement (physical) ----
+        self.ACC = 8                       # v[8:71]: four tuples of 16, pinned outputs
+        self.P = 72                        # pos planes: gene r, plane k at P + 16 r + k   (bank = k % 4)
+        nedge = 2 if ties else 1
+        self.A = [72 + 16 * self.rj + 20 * e for e in range(nedge)]   # row operand words 0..15, +16..19 second copy of quad 3
+        top = 72 + 16 * self.rj + 20 * nedge
+        self.L = top                       # 4 chain registers
+        self.VLDS = top + 4                # LDS byte address of the slot being read
+        self.VA2 = top + 5                 # lane * 16 + 1024 (second half of a DMA'd block)
+        self.vtop = top + 6
+        assert self.vtop <= 168 - 4, self.vtop
+        # bank rule (measured, tools/microbench_bank.hip): a v_bitop3_b32 whose three sources sit in ONE bank issues
+        # at half rate.  pos plane k is in bank k % 4, edge plane k in bank (A + k + 3) % 4: never the same.
+        for a in self.A:
+            assert a % 2 == 0 and (a + 3) % 4 != 0
+        # ---- SGPRs owned by the statement ----
+        s = 36
+        self.SB = [s + 2 * q for q in range(4)]; s += 8      # pos quad bases of the next block to load
+        self.SA = [s, s + 2][:nedge]; s += 4                 # edge block to DMA next (lo, hi)
+        self.S_M0 = s; self.S_REM = s + 1; self.S_LEFT = s + 2; self.S_SLOT = s + 3; self.S_T = s + 4; self.S_T2 = s + 5
+        self.S_PS4 = s + 6; s += 7
+        self.stop = s
+        # planes -> row operand quads
+        self.pq = (nb + 3) // 4            # pos quads per gene
+        self.aq = sorted({a_word(k) // 4 for k in range(nb)})
+        self.first_use = {q: min(k for k in range(nb) if a_word(k) // 4 == q) for q in self.aq}
+        self.last_use = {q: max(k for k in range(nb) if a_word(k) // 4 == q) for q in self.aq}
+        self.slot_bytes = 2048 * nedge
+
+    # ---------------------------------------------------------------- emit helpers
+    def e(self, s):
+        self.lines.append(s)
+
+    def lds_read(self, tag, dst, off):
+        self.e(f"ds_read_b128 v[{dst}:{dst + 3}], v{self.VLDS} offset:{off}")
+        self.lq.append(tag)
+
+    def lds_need(self, tags):
+        """wait until every read in `tags` has returned (reads return in order)"""
+        idx = max((self.lq.index(t) for t in tags if t in self.lq), default=-1)
+        if idx < 0:
+            return
+        n = len(self.lq) - 1 - idx
+        assert n <= 15
+        self.e(f"s_waitcnt lgkmcnt({n})")
+        self.lq = self.lq[idx + 1:]
+
+    def vm_need(self, tags):
+        idx = max((self.vq.index(t) for t in tags if t in self.vq), default=-1)
+        if idx < 0:
+            return
+        n = len(self.vq) - 1 - idx
+        assert n <= 63
+        self.e(f"s_waitcnt vmcnt({n})")
+        self.vq = self.vq[idx + 1:]
+
+    def areg(self, e, k, row):
+        """register of plane k of edge e in row `row`"""
+        w = a_word(k)
+        if w // 4 == 3 and (row & 1):
+            return self.A[e] + 16 + (w & 3)
+        return self.A[e] + w
+
+    def aquad_reg(self, e, q, row):
+        return self.A[e] + 16 if (q == 3 and (row & 1)) else self.A[e] + 4 * q
+
+    def read_row_quad(self, row, q):
+        """request quad q of the row operand(s) of row `row` (row 32 = row 0 of the next block, other slot)"""
+        for e in range(len(self.A)):
+            self.lds_read(("a", row & 1 if q == 3 else 0, e, q), self.aquad_reg(e, q, row), 2048 * e + (row % RI) * 64 + q * 16)
+
+    def need_row_quad(self, row, q):
+        self.lds_need([("a", row & 1 if q == 3 else 0, e, q) for e in range(len(self.A))])
+
+    def dma_block(self):
+        """LDS-DMA of the next edge block(s) into the slot s_slot, then advance (clamped at the last block)"""
+        for e in range(len(self.A)):
+            sa = self.SA[e]
+            if e == 0:
+                self.e(f"s_mov_b32 m0, s{self.S_SLOT}")
+            else:
+                self.e(f"s_add_u32 m0, s{self.S_SLOT}, {2048 * e}")
+            self.e("s_nop 0")
+            self.e(f"global_load_lds_dwordx4 %[aoff], s[{sa}:{sa + 1}]")
+            self.vq.append(("dma", e, 0))
+            self.e(f"s_add_u32 m0, s{self.S_SLOT}, {2048 * e + 1024}")
+            self.e("s_nop 0")
+            self.e(f"global_load_lds_dwordx4 v{self.VA2}, s[{sa}:{sa + 1}]")
+            self.vq.append(("dma", e, 1))
+        # advance the source by one block unless it is the last one; toggle the slot
+        self.e(f"s_cmp_gt_u32 s{self.S_LEFT}, 1")
+        self.e(f"s_cselect_b32 s{self.S_T}, %[astride], 0")
+        self.e(f"s_cselect_b32 s{self.S_T2}, 1, 0")
+        for e in range(len(self.A)):
+            sa = self.SA[e]
+            self.e(f"s_add_u32 s{sa}, s{sa}, s{self.S_T}")
+            self.e(f"s_addc_u32 s{sa + 1}, s{sa + 1}, 0")
+        self.e(f"s_sub_u32 s{self.S_LEFT}, s{self.S_LEFT}, s{self.S_T2}")
+        self.e(f"s_xor_b32 s{self.S_SLOT}, s{self.S_SLOT}, {self.slot_bytes}")
+
+    def load_pos_quad(self, q):
+        n = min(4, self.nb - 4 * q)
+        op = {4: "global_load_dwordx4", 3: "global_load_dwordx3", 2: "global_load_dwordx2", 1: "global_load_dword"}[n]
+        for r in range(self.rj):
+            d = self.P + 16 * r + 4 * q
+            dst = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
+            self.e(f"{op} {dst}, %[poff], s[{self.SB[q]}:{self.SB[q] + 1}] offset:{1024 * r}")
+            self.vq.append(("p", q, r))
+
+    def advance_pos(self):
+        for q in range(self.pq):
+            self.e(f"s_add_u32 s{self.SB[q]}, s{self.SB[q]}, s{self.S_PS4}")
+            self.e(f"s_addc_u32 s{self.SB[q] + 1}, s{self.SB[q] + 1}, 0")
+
+    def chains(self, k, row):
+        """one plane step of the four chains"""
+        if self.ties:   # chains: (gene 0, lo) (gene 1, lo) (gene 0, hi) (gene 1, hi)
+            ch = [(0, 0), (1, 0), (0, 1), (1, 1)]
+        else:
+            ch = [(r, 0) for r in range(4)]
+        for c, (r, e) in enumerate(ch):
+            p = self.P + 16 * r + k
+            a = self.areg(e, k, row)
+            l = self.L + c
+            if k == 0:
+                self.e(f"v_bitop3_b32 v{l}, v{p}, v{a}, v{p} bitop3:0x0c")
+            else:
+                self.e(f"v_bitop3_b32 v{l}, v{p}, v{a}, v{l} bitop3:0x8e")
+
+    def popcounts(self, row):
+        h = row >> 1
+        accs = [self.ACC + 16 * c + h for c in range(4)]   # tie-free: gene c; ties: gt[0], gt[1], ge[0], ge[1]
+        if row & 1:
+            for c in range(4):
+                self.e(f"v_bcnt_u32_b32 v{self.L + c}, v{self.L + c}, 0")
+            for c in range(4):
+                self.e(f"v_lshl_add_u32 v{accs[c]}, v{self.L + c}, 16, v{accs[c]}")
+        else:
+            for c in range(4):
+                self.e(f"v_bcnt_u32_b32 v{accs[c]}, v{self.L + c}, v{accs[c]}")
+
+    def skip_if_last(self):
+        self.label_n += 1
+        lab = f".Lk1skip_{self.name}_{self.label_n}_%="
+        self.e(f"s_cmp_eq_u32 s{self.S_REM}, 1")
+        self.e(f"s_cbranch_scc1 {lab}")
+        return lab
+
+    # ---------------------------------------------------------------- the loop
+    def row(self, i):
+        nb = self.nb
+        last = i == RI - 1
+        nxt = i + 1
+        if last:
+            # the next row is row 0 of the next block: its operand must have landed in the other slot
+            self.vm_need([t for t in self.vq if t[0] == "dma"])
+            self.e(f"v_xor_b32 v{self.VLDS}, {self.slot_bytes}, v{self.VLDS}")
+        for k in range(nb):
+            q = a_word(k) // 4
+            if k == self.first_use[q] or (q == 3 and k == 0):
+                self.need_row_quad(i, q)
+            if i == 0 and k % 4 == 0:
+                self.vm_need([("p", k // 4, r) for r in range(self.rj)])
+            self.chains(k, i)
+            # requests for the next row, as the registers of this row become free
+            if k == 0 and 3 in self.aq:
+                self.read_row_quad(nxt, 3)      # (second copy of quad 3: free since row i - 1)
+            if q != 3 and k == self.last_use[q]:
+                self.read_row_quad(nxt, q)
+            if last and (k % 4 == 3 or k == nb - 1):
+                lab = self.skip_if_last()
+                self.load_pos_quad(k // 4)
+                self.e(lab + ":")
+        self.popcounts(i)
+
+    def generate(self):
+        nedge = len(self.A)
+        e = self.e
+        e(f"s_mov_b32 s{self.S_M0}, m0")
+        for q in range(self.pq):
+            if q == 0:
+                e(f"s_mov_b64 s[{self.SB[0]}:{self.SB[0] + 1}], %[pbase]")
+            else:
+                e(f"s_add_u32 s{self.SB[q]}, s{self.SB[q - 1]}, %[pstride]")
+                e(f"s_addc_u32 s{self.SB[q] + 1}, s{self.SB[q - 1] + 1}, 0")
+        e(f"s_lshl_b32 s{self.S_PS4}, %[pstride], 2")
+        e(f"s_mov_b64 s[{self.SA[0]}:{self.SA[0] + 1}], %[albase]")
+        if nedge > 1:
+            e(f"s_mov_b64 s[{self.SA[1]}:{self.SA[1] + 1}], %[ahbase]")
+        e(f"s_mov_b32 s{self.S_REM}, %[nblk]")
+        e(f"s_mov_b32 s{self.S_LEFT}, %[nblk]")
+        e(f"s_mov_b32 s{self.S_SLOT}, %[ldsbase]")
+        e(f"v_mov_b32 v{self.VLDS}, %[ldsbase]")
+        e(f"v_add_u32 v{self.VA2}, 1024, %[aoff]")
+        for r in range(64):
+            e(f"v_mov_b32 v{self.ACC + r}, 0")
+        self.dma_block()
+        for q in range(self.pq):
+            self.load_pos_quad(q)
+        self.advance_pos()
+        self.dma_block()
+        # first row operand: block 0 has to be in LDS
+        self.vm_need([t for t in self.vq if t[0] == "dma"][:2 * nedge])
+        for q in ([3] if 3 in self.aq else []) + [q for q in self.aq if q != 3]:
+            self.read_row_quad(0, q)
+        top_l, top_v = list(self.lq), list(self.vq)
+        e(f".Lk1loop_{self.name}_%=:")
+        for i in range(RI):
+            self.row(i)
+        # end of the block: the slot just read is free -- DMA of the block after the next one; pos bases move on
+        lab = self.skip_if_last()
+        self.dma_block()
+        self.advance_pos()
+        e(lab + ":")
+        # loop invariant of the queues (a last block issues nothing and leaves the loop)
+        assert self.lq == top_l, (self.lq, top_l)
+        assert self.vq == top_v, (self.vq, top_v)
+        e(f"s_sub_u32 s{self.S_REM}, s{self.S_REM}, 1")
+        e(f"s_cmp_lg_u32 s{self.S_REM}, 0")
+        e(f"s_cbranch_scc1 .Lk1loop_{self.name}_%=")
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e(f"s_mov_b32 m0, s{self.S_M0}")
+
+    def cxx(self):
+        nedge = len(self.A)
+        out = []
+        out.append(f"// {self.name}: NB = {self.nb}, {'with ties (RJ = 2, edges lo and hi)' if self.ties else 'tie-free (RJ = 4)'};"
+                   f" {len(self.lines)} instructions, VGPRs v8..v{self.vtop - 1}")
+        out.append(f"__device__ __forceinline__ void {self.name}(u32x16 &acc0, u32x16 &acc1, u32x16 &acc2, u32x16 &acc3,")
+        out.append("    const void *pbase, uint32_t pstride, const void *albase, const void *ahbase, uint32_t astride, uint32_t nblk,")
+        out.append("    uint32_t poff, uint32_t aoff, uint32_t ldsbase)")
+        out.append("{")
+        out.append("    asm volatile(")
+        for l in self.lines:
+            out.append(f'        "{l}\\n\\t"')
+        out.append(f'        : "=&{{v[{self.ACC}:{self.ACC + 15}]}}"(acc0), "=&{{v[{self.ACC + 16}:{self.ACC + 31}]}}"(acc1), '
+                   f'"=&{{v[{self.ACC + 32}:{self.ACC + 47}]}}"(acc2), "=&{{v[{self.ACC + 48}:{self.ACC + 63}]}}"(acc3)')
+        ins = '[pbase] "s"(pbase), [pstride] "s"(pstride), [albase] "s"(albase), '
+        if nedge > 1:
+            ins += '[ahbase] "s"(ahbase), '
+        ins += '[astride] "s"(astride), [nblk] "s"(nblk), [poff] "v"(poff), [aoff] "v"(aoff), [ldsbase] "s"(ldsbase)'
+        out.append("        : " + ins)
+        clob = [f'"v{r}"' for r in range(self.P, self.vtop)] + [f'"s{r}"' for r in range(36, self.stop)] + ['"vcc"', '"scc"', '"memory"']
+        out.append("        : " + ", ".join(clob) + ");")
+        out.append("}")
+        return "\n".join(out)
+
+
+VARIANTS = [(12, False), (15, False), (16, False), (12, True), (15, True), (16, True)]
+
+
+def main():
+    print("// GENERATED by gen_k1_loop.py -- do not edit; see that file for the schedule.")
+    print("typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));")
+    for nb, ties in VARIANTS:
+        lp = Loop(nb, ties, f"k1_loop_nb{nb}_{'ties' if ties else 'free'}")
+        lp.generate()
+        print()
+        print(lp.cxx())
+
+
+if __name__ == "__main__":
+    main()

@@ -410,6 +410,81 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k1_pairs(K1Args a)  // wav
 
 
 // ---------------------------------------------------------------------------
+// K1, wave form (round 3; the default for two groups): ONE WAVE PER WORKGROUP, one work item = (tile of 32 gene rows i,
+// 64 RJ consecutive genes j, one side).  The count loop is one generated, hand-scheduled asm statement
+// (gen_k1_loop.py -> k1_loop_gen.inc): the wave stages its own tile operand by LDS-DMA into a private 2-slot ring and
+// reads it back one row ahead, so there is no barrier, no idle wave held by one, and no wait for LDS or (beyond the
+// first block) for the lane operand inside the row loop.  Work order as in tile_of_block: workgroup b belongs to XCD
+// slot b & 7, each slot walks whole units -- side-major, then i-tile-major, wave chunks fastest -- so the unit's pos
+// panel of one side stays in that XCD's L2.  Items left of the diagonal or in the padding exit at once.
+#include "k1_loop_gen.inc"
+
+template <int RJ>
+__device__ __forceinline__ bool wave_item(const K1Args &a, int &i0, int &jw, int &side)
+{
+    const int slot = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int QW = a.Q * 4;                 // wave chunks (64 RJ genes) per panel
+    const int per_side = kUnitH * QW, per_unit = 2 * per_side;
+    const int u = (q / per_unit) * 8 + slot;
+    if (u >= a.n_units) return false;
+    const uint32_t um = a.unit_map[u];
+    const int wq = q % per_unit;
+    side = wq / per_side;
+    const int rem = wq % per_side;
+    i0 = (static_cast<int>(um & 0xFFFFu) * kUnitH + rem / QW) * kTileI;
+    jw = (static_cast<int>(um >> 16) * QW + rem % QW) * (64 * RJ);
+    if (i0 >= a.G || jw >= a.Gp) return false;
+    return !wave_idle<RJ>(jw, i0, a.G);
+}
+
+template <int NB, bool TIES>
+__device__ __forceinline__ void k1_loop(u32x16 &c0, u32x16 &c1, u32x16 &c2, u32x16 &c3, const void *pb, uint32_t ps, const void *al,
+                                        const void *ah, uint32_t as, uint32_t nblk, uint32_t poff, uint32_t aoff, uint32_t lds)
+{
+    if (TIES) {
+        if (NB == 12) k1_loop_nb12_ties(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
+        else if (NB == 15) k1_loop_nb15_ties(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
+        else k1_loop_nb16_ties(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
+    } else {
+        if (NB == 12) k1_loop_nb12_free(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
+        else if (NB == 15) k1_loop_nb15_free(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
+        else k1_loop_nb16_free(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
+    }
+}
+
+template <int NB, bool TIES>
+__global__ __launch_bounds__(64, 3) void k1w_pairs(K1Args a)
+{
+    constexpr int RI = kTileI, RJ = TIES ? kRJTies : kRJ;
+    __shared__ uint4 ring[TIES ? 512 : 256];  // two slots of one block's tile operand (lo [+ hi]): 2 x 2 KB [x 2]
+    int i0v, jwv, sidev;
+    if (!wave_item<RJ>(a, i0v, jwv, sidev)) return;
+    const int i0 = __builtin_amdgcn_readfirstlane(i0v), jw = __builtin_amdgcn_readfirstlane(jwv);
+    const int side = __builtin_amdgcn_readfirstlane(sidev);
+    const int lane = threadIdx.x, jl = jw + lane, bi = i0 >> 6;
+    const int bb = side ? a.tb : a.cb, be = side ? a.te : a.ce;
+    uint32_t gt[RJ][RI / 2], ge[TIES ? RJ : 1][RI / 2];
+    u32x16 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (be > bb) {
+        const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * 4 * a.Gp * 16;
+        const char *al = reinterpret_cast<const char *>(a.AL) + (static_cast<size_t>(bb) * a.Gp + i0) * 64;
+        const char *ah = reinterpret_cast<const char *>(a.AH) + (static_cast<size_t>(bb) * a.Gp + i0) * 64;
+        const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
+        k1_loop<NB, TIES>(c0, c1, c2, c3, pb, static_cast<uint32_t>(a.Gp) * 16u, al, ah, static_cast<uint32_t>(a.Gp) * 64u,
+                          static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
+    }
+#pragma unroll
+    for (int h = 0; h < RI / 2; ++h) {
+        if (TIES) { gt[0][h] = c0[h]; gt[1][h] = c1[h]; ge[0][h] = c2[h]; ge[1][h] = c3[h]; }
+        else { gt[0][h] = c0[h]; gt[1 % RJ][h] = c1[h]; gt[2 % RJ][h] = c2[h]; gt[3 % RJ][h] = c3[h]; }
+    }
+    const int g = side ? a.gt : a.gc;
+    const int m = side ? a.m2 : a.m1, n = side ? a.nt : a.nc;
+    emit_side<RI, RJ>(a, i0, jl, bi, lane, side ? 2 : 0, m, n - m,
+                      [&](int r, int ii) { return count_with_coins<RJ, TIES>(gt, ge, a.seed, i0, jl, r, ii, g); });
+}
+
+// ---------------------------------------------------------------------------
 // Wide form of the pair loop for more than 65 535 samples (single-cell mode without pseudo-bulking, :608-616): one
 // 32-bit count per register.  Tie-free: 2 genes per lane, two gene rows per step (chains (p0,a_i) (p1,a_i) (p0,a_i+1)
 // (p1,a_i+1)); with ties: 1 gene per lane, chains (p0,lo_i) (p0,hi_i) (p0,lo_i+1) (p0,hi_i+1).  The tile operand is
@@ -2478,6 +2553,10 @@ static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool
     } else if (multi) {
         if (c->has_ties) k1_pairs<NB, true, true><<<grid, 256, 0, c->stream>>>(a);
         else k1_pairs<NB, false, true><<<grid, 256, 0, c->stream>>>(a);
+    } else if (c->k1_wave) {  // one wave per workgroup, generated count loop (two groups)
+        const unsigned gridw = grid * 4u * 2u;  // 4 wave chunks per workgroup tile, 2 sides
+        if (c->has_ties) k1w_pairs<NB, true><<<gridw, 64, 0, c->stream>>>(a);
+        else k1w_pairs<NB, false><<<gridw, 64, 0, c->stream>>>(a);
     } else {
         if (c->has_ties) k1_pairs<NB, true, false><<<grid, 256, 0, c->stream>>>(a);
         else k1_pairs<NB, false, false><<<grid, 256, 0, c->stream>>>(a);
