@@ -307,7 +307,7 @@ void reo_destroy(reo_ctx *c)
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
     c->table.release();
     c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
-    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release();
+    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release(); c->k1_items.release();
     c->t_pos16.release(); c->t_lo16.release(); c->t_hi16.release(); c->gcounts.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();

@@ -33,14 +33,16 @@ def a_word(k):
 
 
 class Loop:
-    def __init__(self, nb, ties, name, lshl_add=True):
-        self.nb, self.ties, self.name = nb, ties, name
+    def __init__(self, nb, ties, name, lshl_add=True, opts=()):
+        # opts: timing experiments only (tools/k1w_probe.hip) -- never set for the library's loops
+        self.nb, self.ties, self.name, self.opts = nb, ties, name, set(opts)
         self.rj = 2 if ties else 4
         self.lines = []
         self.lq = []   # outstanding LDS reads, oldest first (tags)
         self.vq = []   # outstanding vector-memory operations, oldest first (tags)
         self.lshl_add = lshl_add
         self.label_n = 0
+        self.in_loop = False
         # ---- VGPRs owned by the statement (physical) ----
         self.ACC = 8                       # v[8:71]: four tuples of 16, pinned outputs
         self.P = 72                        # pos planes: gene r, plane k at P + 16 r + k   (bank = k % 4)
@@ -75,7 +77,8 @@ class Loop:
         self.lines.append(s)
 
     def lds_read(self, tag, dst, off):
-        self.e(f"ds_read_b128 v[{dst}:{dst + 3}], v{self.VLDS} offset:{off}")
+        if "nolds" not in self.opts:
+            self.e(f"ds_read_b128 v[{dst}:{dst + 3}], v{self.VLDS} offset:{off}")
         self.lq.append(tag)
 
     def lds_need(self, tags):
@@ -85,7 +88,8 @@ class Loop:
             return
         n = len(self.lq) - 1 - idx
         assert n <= 15
-        self.e(f"s_waitcnt lgkmcnt({n})")
+        if not ({"nolds", "nowait_lds"} & self.opts):
+            self.e(f"s_waitcnt lgkmcnt({n})")
         self.lq = self.lq[idx + 1:]
 
     def vm_need(self, tags):
@@ -94,7 +98,8 @@ class Loop:
             return
         n = len(self.vq) - 1 - idx
         assert n <= 63
-        self.e(f"s_waitcnt vmcnt({n})")
+        if "nowait_vm" not in self.opts or all(t[0] == "dma" for t in tags):
+            self.e(f"s_waitcnt vmcnt({n})")
         self.vq = self.vq[idx + 1:]
 
     def areg(self, e, k, row):
@@ -147,6 +152,9 @@ class Loop:
         for r in range(self.rj):
             d = self.P + 16 * r + 4 * q
             dst = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
+            if "noreload" in self.opts and self.in_loop:
+                self.vq.append(("p", q, r))
+                continue
             self.e(f"{op} {dst}, %[poff], s[{self.SB[q]}:{self.SB[q] + 1}] offset:{1024 * r}")
             self.vq.append(("p", q, r))
 
@@ -172,12 +180,17 @@ class Loop:
 
     def popcounts(self, row):
         h = row >> 1
+        if "nopop" in self.opts:
+            return
         accs = [self.ACC + 16 * c + h for c in range(4)]   # tie-free: gene c; ties: gt[0], gt[1], ge[0], ge[1]
         if row & 1:
             for c in range(4):
                 self.e(f"v_bcnt_u32_b32 v{self.L + c}, v{self.L + c}, 0")
             for c in range(4):
-                self.e(f"v_lshl_add_u32 v{accs[c]}, v{self.L + c}, 16, v{accs[c]}")
+                if "lshl" not in self.opts:   # high half += count, low half kept (SDWA: one full-rate op)
+                    self.e(f"v_add_u32_sdwa v{accs[c]}, v{self.L + c}, v{accs[c]} dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_1")
+                else:
+                    self.e(f"v_lshl_add_u32 v{accs[c]}, v{self.L + c}, 16, v{accs[c]}")
         else:
             for c in range(4):
                 self.e(f"v_bcnt_u32_b32 v{accs[c]}, v{self.L + c}, v{accs[c]}")
@@ -247,6 +260,7 @@ class Loop:
         for q in ([3] if 3 in self.aq else []) + [q for q in self.aq if q != 3]:
             self.read_row_quad(0, q)
         top_l, top_v = list(self.lq), list(self.vq)
+        self.in_loop = True
         e(f".Lk1loop_{self.name}_%=:")
         for i in range(RI):
             self.row(i)
@@ -289,7 +303,7 @@ class Loop:
         return "\n".join(out)
 
 
-VARIANTS = [(12, False), (15, False), (16, False), (12, True), (15, True), (16, True)]
+VARIANTS = [(12, False), (15, False), (16, False)]   # (tie-rich data: two passes of the same loop, edges lo then hi)
 
 
 def main():

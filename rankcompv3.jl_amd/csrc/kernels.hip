@@ -30,6 +30,7 @@
 // Wave = 64 lanes everywhere; no warp-32 idiom is used.
 #include <algorithm>
 #include <cstddef>
+#include <cstring>
 
 #include "reo_internal.h"
 
@@ -245,6 +246,7 @@ struct K1Args {
     int n_units, Q;      // units owned by this shard; j-chunks per panel
     const int32_t *goff; // MULTI: group offsets in blocks (ngroups + 1)
     int ngroups;
+    const uint32_t *items;  // wave form: side << 31 | wave chunk << 16 | i-tile, one per workgroup
 };
 
 // true when every gene j of the wave (64 RJ consecutive genes from jw) is padding (>= G) or lies in a 64-gene
@@ -414,74 +416,69 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 3) void k1_pairs(K1Args a)  // wav
 // 64 RJ consecutive genes j, one side).  The count loop is one generated, hand-scheduled asm statement
 // (gen_k1_loop.py -> k1_loop_gen.inc): the wave stages its own tile operand by LDS-DMA into a private 2-slot ring and
 // reads it back one row ahead, so there is no barrier, no idle wave held by one, and no wait for LDS or (beyond the
-// first block) for the lane operand inside the row loop.  Work order as in tile_of_block: workgroup b belongs to XCD
-// slot b & 7, each slot walks whole units -- side-major, then i-tile-major, wave chunks fastest -- so the unit's pos
-// panel of one side stays in that XCD's L2.  Items left of the diagonal or in the padding exit at once.
+// first block) for the lane operand inside the row loop.  The items are an explicit list made by the host (launch_k1:
+// unit by unit, side-major, then i-tile-major, wave chunks fastest; only items that hold a real pair).  Workgroups go to
+// the 8 XCDs round-robin, so every XCD gets every 8th item of that order: the same number of items each (walking whole
+// units per XCD, as the workgroup form does, left the XCD with the most diagonal-free units 22 % more work than the
+// average -- tools/k1w_probe.hip), and all of them inside one unit's pos panel at any time.
 #include "k1_loop_gen.inc"
 
-template <int RJ>
-__device__ __forceinline__ bool wave_item(const K1Args &a, int &i0, int &jw, int &side)
+template <int NB>
+__device__ __forceinline__ void k1_loop(u32x16 &c0, u32x16 &c1, u32x16 &c2, u32x16 &c3, const void *pb, uint32_t ps, const void *ab,
+                                        uint32_t as, uint32_t nblk, uint32_t poff, uint32_t aoff, uint32_t lds)
 {
-    const int slot = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int QW = a.Q * 4;                 // wave chunks (64 RJ genes) per panel
-    const int per_side = kUnitH * QW, per_unit = 2 * per_side;
-    const int u = (q / per_unit) * 8 + slot;
-    if (u >= a.n_units) return false;
-    const uint32_t um = a.unit_map[u];
-    const int wq = q % per_unit;
-    side = wq / per_side;
-    const int rem = wq % per_side;
-    i0 = (static_cast<int>(um & 0xFFFFu) * kUnitH + rem / QW) * kTileI;
-    jw = (static_cast<int>(um >> 16) * QW + rem % QW) * (64 * RJ);
-    if (i0 >= a.G || jw >= a.Gp) return false;
-    return !wave_idle<RJ>(jw, i0, a.G);
+    if (NB == 12) k1_loop_nb12_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+    else if (NB == 15) k1_loop_nb15_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+    else k1_loop_nb16_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
 }
 
-template <int NB, bool TIES>
-__device__ __forceinline__ void k1_loop(u32x16 &c0, u32x16 &c1, u32x16 &c2, u32x16 &c3, const void *pb, uint32_t ps, const void *al,
-                                        const void *ah, uint32_t as, uint32_t nblk, uint32_t poff, uint32_t aoff, uint32_t lds)
-{
-    if (TIES) {
-        if (NB == 12) k1_loop_nb12_ties(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
-        else if (NB == 15) k1_loop_nb15_ties(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
-        else k1_loop_nb16_ties(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
-    } else {
-        if (NB == 12) k1_loop_nb12_free(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
-        else if (NB == 15) k1_loop_nb15_free(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
-        else k1_loop_nb16_free(c0, c1, c2, c3, pb, ps, al, ah, as, nblk, poff, aoff, lds);
-    }
-}
-
+// Tie-rich data (two band edges per pair): the SAME loop runs twice per item, against the lo planes (n_gt) and then
+// against the hi planes (n_ge); the first pass's 64 count registers wait in the wave's private segment (16 stores and
+// loads per item).  Two chains per pair inside one loop would halve the genes per lane, i.e. double the LDS reads per
+// bit op -- the round-2 form, whose LDS pipe was busy 45 % of the cycles.
 template <int NB, bool TIES>
 __global__ __launch_bounds__(64, 3) void k1w_pairs(K1Args a)
 {
-    constexpr int RI = kTileI, RJ = TIES ? kRJTies : kRJ;
-    __shared__ uint4 ring[TIES ? 512 : 256];  // two slots of one block's tile operand (lo [+ hi]): 2 x 2 KB [x 2]
-    int i0v, jwv, sidev;
-    if (!wave_item<RJ>(a, i0v, jwv, sidev)) return;
-    const int i0 = __builtin_amdgcn_readfirstlane(i0v), jw = __builtin_amdgcn_readfirstlane(jwv);
-    const int side = __builtin_amdgcn_readfirstlane(sidev);
+    constexpr int RI = kTileI, RJ = kRJ, NE = TIES ? 2 : 1;
+    __shared__ uint4 ring[256];  // two slots of one block's tile operand: 2 x 2 KB
+    const uint32_t item = a.items[blockIdx.x];  // side << 31 | wave chunk << 16 | i-tile
+    const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(item & 0xFFFFu) * RI);
+    const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((item >> 16) & 0x7FFFu) * (64 * RJ));
+    const int side = __builtin_amdgcn_readfirstlane(static_cast<int>(item >> 31));
     const int lane = threadIdx.x, jl = jw + lane, bi = i0 >> 6;
     const int bb = side ? a.tb : a.cb, be = side ? a.te : a.ce;
-    uint32_t gt[RJ][RI / 2], ge[TIES ? RJ : 1][RI / 2];
-    u32x16 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    uint32_t cnt[NE][RJ][RI / 2];  // [0]: n_gt, [1]: n_ge -- packed, rows 2h and 2h+1
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int r = 0; r < RJ; ++r)
+#pragma unroll
+            for (int h = 0; h < RI / 2; ++h) cnt[e][r][h] = 0;
     if (be > bb) {
         const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * 4 * a.Gp * 16;
-        const char *al = reinterpret_cast<const char *>(a.AL) + (static_cast<size_t>(bb) * a.Gp + i0) * 64;
-        const char *ah = reinterpret_cast<const char *>(a.AH) + (static_cast<size_t>(bb) * a.Gp + i0) * 64;
+        const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * 64;
         const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
-        k1_loop<NB, TIES>(c0, c1, c2, c3, pb, static_cast<uint32_t>(a.Gp) * 16u, al, ah, static_cast<uint32_t>(a.Gp) * 64u,
-                          static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
-    }
+#pragma clang loop unroll(disable)
+        for (int e = 0; e < NE; ++e) {  // (one copy of the loop's code, not two)
+            const char *ab = reinterpret_cast<const char *>(e ? a.AH : a.AL) + aoff;
+            u32x16 c0, c1, c2, c3;
+            k1_loop<NB>(c0, c1, c2, c3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * 64u,
+                        static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
 #pragma unroll
-    for (int h = 0; h < RI / 2; ++h) {
-        if (TIES) { gt[0][h] = c0[h]; gt[1][h] = c1[h]; ge[0][h] = c2[h]; ge[1][h] = c3[h]; }
-        else { gt[0][h] = c0[h]; gt[1 % RJ][h] = c1[h]; gt[2 % RJ][h] = c2[h]; gt[3 % RJ][h] = c3[h]; }
+            for (int h = 0; h < RI / 2; ++h) { cnt[e][0][h] = c0[h]; cnt[e][1][h] = c1[h]; cnt[e][2][h] = c2[h]; cnt[e][3][h] = c3[h]; }
+        }
     }
     const int g = side ? a.gt : a.gc;
     const int m = side ? a.m2 : a.m1, n = side ? a.nt : a.nc;
     emit_side<RI, RJ>(a, i0, jl, bi, lane, side ? 2 : 0, m, n - m,
-                      [&](int r, int ii) { return count_with_coins<RJ, TIES>(gt, ge, a.seed, i0, jl, r, ii, g); });
+                      [&](int r, int ii) {
+                          int nre = static_cast<int>(unpack16(cnt[0][r], ii));
+                          if (TIES) {  // tie coins (:72-77)
+                              const uint32_t neq = unpack16(cnt[NE - 1][r], ii) - static_cast<uint32_t>(nre);
+                              if (neq) nre += tie_wins(a.seed, i0 + ii, jl + 64 * r, g, neq);
+                          }
+                          return nre;
+                      });
 }
 
 // ---------------------------------------------------------------------------
@@ -2554,7 +2551,8 @@ static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool
         if (c->has_ties) k1_pairs<NB, true, true><<<grid, 256, 0, c->stream>>>(a);
         else k1_pairs<NB, false, true><<<grid, 256, 0, c->stream>>>(a);
     } else if (c->k1_wave) {  // one wave per workgroup, generated count loop (two groups)
-        const unsigned gridw = grid * 4u * 2u;  // 4 wave chunks per workgroup tile, 2 sides
+        const unsigned gridw = static_cast<unsigned>(c->k1_items_n);
+        if (gridw == 0) return;
         if (c->has_ties) k1w_pairs<NB, true><<<gridw, 64, 0, c->stream>>>(a);
         else k1w_pairs<NB, false><<<gridw, 64, 0, c->stream>>>(a);
     } else {
@@ -2581,7 +2579,8 @@ int32_t launch_k1(reo_ctx *c, int k)
     // work units: panel p = Q consecutive j-chunks, cut into i-ranges of kUnitH tiles.  Q keeps the
     // panel's pos planes (Q x 256 RJ genes x nblk blocks x 64 B) within about 2 MiB of the 4 MiB L2 of an XCD.
     const bool wide = c->S > 65535;  // a count may not fit 16 bits: the unpacked form of the pair loop
-    const int RJ = wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ);  // genes j per lane
+    const bool wave = c->k1_wave && !multi && !wide;  // the wave form (two groups): kRJ genes per lane for both families
+    const int RJ = wave ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));  // genes j per lane
     const int CJ = kTileJ * RJ;
     const int NJ = (c->Gp + CJ - 1) / CJ, NIT = c->Gp / kTileI;
     const size_t chunk_bytes = static_cast<size_t>(CJ) * (c->goff32[c->ngroups] / 32) * 64;
@@ -2615,6 +2614,36 @@ int32_t launch_k1(reo_ctx *c, int k)
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `units` is a local: the copy must have read it before any return below
     }
     a.unit_map = c->unit_map.p;
+    a.items = nullptr;
+    if (wave) {
+        // item list of the wave form: the owned units in order, side-major, i-tile-major, wave chunks fastest; kept
+        // until the geometry changes
+        const int CW = 64 * RJ, QW = Q * (CJ / CW);
+        const uint64_t key[4] = {static_cast<uint64_t>(c->G) << 32 | static_cast<uint32_t>(c->Gp), static_cast<uint64_t>(RJ) << 32 | static_cast<uint32_t>(Q),
+                                 static_cast<uint64_t>(c->world) << 32 | static_cast<uint32_t>(c->rank), units.size()};
+        if (!c->k1_items.p || std::memcmp(key, c->k1_items_key, sizeof key) != 0) {
+            std::vector<uint32_t> items;
+            items.reserve(units.size() * 2 * kUnitH * QW);
+            const int G = static_cast<int>(c->G);
+            for (uint32_t um : units)
+                for (uint32_t side = 0; side < 2; ++side)
+                    for (int t = 0; t < kUnitH; ++t)
+                        for (int w = 0; w < QW; ++w) {
+                            const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + t, cw = static_cast<int>(um >> 16) * QW + w;
+                            const int i0 = it * kTileI, jw = cw * CW;
+                            if (i0 >= G || jw >= G || ((jw + CW - 1) >> 6) < (i0 >> 6)) continue;  // no pair i < j < G in it
+                            items.push_back(side << 31 | static_cast<uint32_t>(cw) << 16 | static_cast<uint32_t>(it));
+                        }
+            if ((rc = c->k1_items.ensure(std::max<size_t>(items.size(), 1)))) return rc;
+            if (!items.empty()) {
+                REO_HIP_CHECK(hipMemcpyAsync(c->k1_items.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `items` is a local
+            }
+            c->k1_items_n = items.size();
+            std::memcpy(c->k1_items_key, key, sizeof key);
+        }
+        a.items = c->k1_items.p;
+    }
     REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
     if (units.empty()) return REO_OK;
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);

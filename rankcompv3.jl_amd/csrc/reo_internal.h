@@ -161,6 +161,9 @@ struct reo_ctx {
     reo::DevBuf<unsigned char> t_temp;
     reo::DevBuf<int32_t> t_order, t_flags, t_slots;
     reo::DevBuf<uint32_t> unit_map;  // K1 work units: panel << 16 | i-range
+    reo::DevBuf<uint32_t> k1_items;  // wave form of K1: one work item per workgroup (side << 31 | wave chunk << 16 | i-tile)
+    size_t k1_items_n = 0;
+    uint64_t k1_items_key[4] = {0, 0, 0, 0};  // geometry the list was made for
     bool transformed = false;
     int has_ties = 0;
     int transform_in_lds = 0;  // the last transform sorted each sample inside one workgroup's LDS (transform.hip)

@@ -20,17 +20,32 @@ import numpy as np
 
 TILE_I = 32     # kTileI
 TILE_J = 256    # kTileJ
-RJ = 4          # kRJ (genes per lane in the tie-free kernel)
-RJ_TIES = 2     # kRJTies (genes per lane in the tie-rich kernel)
+RJ = 4          # kRJ (genes per lane in the wave form of the pair kernel, and in the tie-free workgroup form)
+RJ_TIES = 2     # kRJTies (genes per lane in the tie-rich workgroup form)
+RJ_WIDE = 2     # kRJWide / kRJWideTies: the wide forms (more than 65 535 samples)
+RJ_WIDE_TIES = 1
 UNIT_H = 32     # kUnitH
 GENE_PAD = 1024 # kGenePad
 SLOT_PAD = 32   # sample slots per block of the bit planes
 
 
-def geometry(G: int, sample_slots: int, has_ties: bool):
+FORM = "wave"   # which pair kernel launch_k1 selects: "wave" (two groups, S <= 65535: the default), "wg" (the workgroup
+                # form: more than two groups, or REO_K1_WAVE=0), "wide" (S > 65535)
+
+
+def genes_per_lane(has_ties: bool, form: str | None = None) -> int:
+    form = form or FORM
+    if form == "wave":
+        return RJ
+    if form == "wide":
+        return RJ_WIDE_TIES if has_ties else RJ_WIDE
+    return RJ_TIES if has_ties else RJ
+
+
+def geometry(G: int, sample_slots: int, has_ties: bool, form: str | None = None):
     """(Gp, CJ, Q) exactly as launch_k1 derives them."""
     Gp = (G + GENE_PAD - 1) // GENE_PAD * GENE_PAD
-    CJ = TILE_J * (RJ_TIES if has_ties else RJ)
+    CJ = TILE_J * genes_per_lane(has_ties, form)
     chunk_bytes = CJ * sample_slots * 2
     Q = 4 if chunk_bytes * 4 <= (2 << 20) else (2 if chunk_bytes * 2 <= (2 << 20) else 1)
     return Gp, CJ, Q
@@ -41,10 +56,10 @@ def sample_slots(group_sizes) -> int:
     return int(sum((int(n) + SLOT_PAD - 1) // SLOT_PAD * SLOT_PAD for n in group_sizes))
 
 
-def tile_owner(G: int, slots: int, has_ties: bool, world: int) -> np.ndarray:
+def tile_owner(G: int, slots: int, has_ties: bool, world: int, form: str | None = None) -> np.ndarray:
     """owner[it, jc] = shard that computes pair tile (rows 32*it.., columns CJ*jc..), or -1 if the
     tile lies strictly below the diagonal (it is the mirror of another tile)."""
-    Gp, CJ, Q = geometry(G, slots, has_ties)
+    Gp, CJ, Q = geometry(G, slots, has_ties, form)
     NJ, NIT = (Gp + CJ - 1) // CJ, Gp // TILE_I
     NP = (NJ + Q - 1) // Q
     owner = np.full((NIT, NJ), -1, dtype=np.int32)
@@ -63,11 +78,11 @@ def tile_owner(G: int, slots: int, has_ties: bool, world: int) -> np.ndarray:
     return owner
 
 
-def owned_pair_mask(G: int, slots: int, has_ties: bool, rank: int, world: int) -> np.ndarray:
+def owned_pair_mask(G: int, slots: int, has_ties: bool, rank: int, world: int, form: str | None = None) -> np.ndarray:
     """mask[i, j] (i != j) = True iff the unordered pair {i, j} is computed by shard `rank`
     (the shard then holds both the (i,j) bits and the mirrored (j,i) bits)."""
-    Gp, CJ, Q = geometry(G, slots, has_ties)
-    owner = tile_owner(G, slots, has_ties, world)
+    Gp, CJ, Q = geometry(G, slots, has_ties, form)
+    owner = tile_owner(G, slots, has_ties, world, form)
     i = np.arange(G)
     lo, hi = np.minimum(i[:, None], i[None, :]), np.maximum(i[:, None], i[None, :])
     m = owner[lo // TILE_I, hi // CJ] == rank
