@@ -11,7 +11,7 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.search(r"::((?:k\d?_|k3_|t_)\w+)", name)
+    m = re.search(r"::((?:k\d?w?_|k3_|t_)\w+)", name)
     if m:
         return m.group(1)
     if "segmented_radix_sort" in name:

@@ -77,7 +77,7 @@ class Loop:
         self.lines.append(s)
 
     def lds_read(self, tag, dst, off):
-        if "nolds" not in self.opts:
+        if "nolds" not in self.opts or not self.in_loop:   # (the probe keeps the prologue's reads: same data in the registers)
             self.e(f"ds_read_b128 v[{dst}:{dst + 3}], v{self.VLDS} offset:{off}")
         self.lq.append(tag)
 
@@ -88,7 +88,7 @@ class Loop:
             return
         n = len(self.lq) - 1 - idx
         assert n <= 15
-        if not ({"nolds", "nowait_lds"} & self.opts):
+        if not ({"nolds", "nowait_lds"} & self.opts) or not self.in_loop:
             self.e(f"s_waitcnt lgkmcnt({n})")
         self.lq = self.lq[idx + 1:]
 
@@ -119,6 +119,9 @@ class Loop:
 
     def need_row_quad(self, row, q):
         self.lds_need([("a", row & 1 if q == 3 else 0, e, q) for e in range(len(self.A))])
+
+    def need_row_quads(self, row, qs):
+        self.lds_need([("a", row & 1 if q == 3 else 0, e, q) for q in qs if q in self.aq for e in range(len(self.A))])
 
     def dma_block(self):
         """LDS-DMA of the next edge block(s) into the slot s_slot, then advance (clamped at the last block)"""
@@ -213,8 +216,13 @@ class Loop:
             self.e(f"v_xor_b32 v{self.VLDS}, {self.slot_bytes}, v{self.VLDS}")
         for k in range(nb):
             q = a_word(k) // 4
-            if k == self.first_use[q] or (q == 3 and k == 0):
-                self.need_row_quad(i, q)
+            if "wait4" in self.opts:
+                if k == self.first_use[q] or (q == 3 and k == 0):
+                    self.need_row_quad(i, q)
+            elif k == 0:        # two waits per row (an s_waitcnt costs the wave an issue slot even when it has nothing to
+                self.need_row_quads(i, [3, 0])   # wait for): quads 3 and 0 at the row start, the others before plane 5
+            elif k == 5:
+                self.need_row_quads(i, [q for q in self.aq if q not in (3, 0)])
             if i == 0 and k % 4 == 0:
                 self.vm_need([("p", k // 4, r) for r in range(self.rj)])
             self.chains(k, i)

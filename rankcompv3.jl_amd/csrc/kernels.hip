@@ -30,6 +30,8 @@
 // Wave = 64 lanes everywhere; no warp-32 idiom is used.
 #include <algorithm>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "reo_internal.h"
@@ -247,6 +249,7 @@ struct K1Args {
     const int32_t *goff; // MULTI: group offsets in blocks (ngroups + 1)
     int ngroups;
     const uint32_t *items;  // wave form: side << 31 | wave chunk << 16 | i-tile, one per workgroup
+    unsigned long long *stamps;  // diagnostic (REO_K1_STAMPS=1): four s_memrealtime marks per item, else null
 };
 
 // true when every gene j of the wave (64 RJ consecutive genes from jw) is padding (>= G) or lies in a 64-gene
@@ -276,55 +279,59 @@ __device__ __forceinline__ void write_lane(uint32_t &v, uint32_t x, int l)
 // the mirror word of row j (:386: L and H swap) grows by one bit per row with an add-with-carry from the
 // same mask.  Only pairs i < j < G are real; everything else contributes zero bits.  The diagonal 64x64
 // blocks are written by several tiles and use atomicOr on the pre-zeroed table.
+template <int RI, typename F>
+__device__ __forceinline__ void emit_gene(const K1Args &a, int i0, int j, int bi, int lane, int pl, int hi_thr, int lo_thr, F val)
+{
+    const int bj = __builtin_amdgcn_readfirstlane(j >> 6);  // wave-uniform, and the compiler should know it
+    if ((bj << 6) >= a.Gp || bj < bi) return;
+    const int d = j - i0;                          // rows i0+ii with ii < d are above the diagonal
+    const bool near = (bj << 6) - i0 < RI;         // wave-uniform: some lane has d < 32
+    const unsigned long long lanes_ok = __ballot(j < a.G);
+    uint32_t wL = 0, wH = 0;
+    uint32_t fLlo = 0, fLhi = 0, fHlo = 0, fHhi = 0;  // lane ii: forward words of row i0+ii
+#pragma unroll
+    for (int ii = RI - 1; ii >= 0; --ii) {
+        const int n = val(ii);
+        const unsigned long long ok = near ? (__ballot(d > ii) & lanes_ok) : lanes_ok;
+        const unsigned long long mH = __ballot(n >= hi_thr) & ok;
+        const unsigned long long mL = __ballot(n <= lo_thr) & ok & ~mH;
+        shift_in(wH, mH);
+        shift_in(wL, mL);
+        write_lane(fHlo, static_cast<uint32_t>(mH), ii);
+        write_lane(fHhi, static_cast<uint32_t>(mH >> 32), ii);
+        write_lane(fLlo, static_cast<uint32_t>(mL), ii);
+        write_lane(fLhi, static_cast<uint32_t>(mL >> 32), ii);
+    }
+    const bool diag = (bj == bi);
+    if (lane < RI && i0 + lane < a.G) {
+        uint32_t *row = a.table + (static_cast<size_t>(i0 + lane) * kPlanes + pl) * a.Wp + 2 * bj;
+        if (!diag) {
+            *reinterpret_cast<uint2 *>(row) = uint2{fLlo, fLhi};
+            *reinterpret_cast<uint2 *>(row + a.Wp) = uint2{fHlo, fHhi};
+        } else {
+            if (fLlo) atomicOr(row, fLlo);
+            if (fLhi) atomicOr(row + 1, fLhi);
+            if (fHlo) atomicOr(row + a.Wp, fHlo);
+            if (fHhi) atomicOr(row + a.Wp + 1, fHhi);
+        }
+    }
+    if (j < a.G) {  // mirror: pair (j, i) is in state 2 - state(i, j)
+        uint32_t *row = a.table + (static_cast<size_t>(j) * kPlanes + pl) * a.Wp + (i0 >> 5);
+        if (!diag) {
+            row[0] = wH; row[a.Wp] = wL;
+        } else {
+            if (wH) atomicOr(row, wH);
+            if (wL) atomicOr(row + a.Wp, wL);
+        }
+    }
+}
+
 template <int RI, int RJ, typename F>
 __device__ __forceinline__ void emit_side(const K1Args &a, int i0, int jl, int bi, int lane, int pl, int hi_thr, int lo_thr, F val)
 {
 #pragma unroll
-    for (int r = 0; r < RJ; ++r) {
-        const int j = jl + 64 * r;
-        const int bj = __builtin_amdgcn_readfirstlane(j >> 6);  // wave-uniform, and the compiler should know it
-        if ((bj << 6) >= a.Gp || bj < bi) continue;
-        const int d = j - i0;                          // rows i0+ii with ii < d are above the diagonal
-        const bool near = (bj << 6) - i0 < RI;         // wave-uniform: some lane has d < 32
-        const unsigned long long lanes_ok = __ballot(j < a.G);
-        uint32_t wL = 0, wH = 0;
-        uint32_t fLlo = 0, fLhi = 0, fHlo = 0, fHhi = 0;  // lane ii: forward words of row i0+ii
-#pragma unroll
-        for (int ii = RI - 1; ii >= 0; --ii) {
-            const int n = val(r, ii);
-            const unsigned long long ok = near ? (__ballot(d > ii) & lanes_ok) : lanes_ok;
-            const unsigned long long mH = __ballot(n >= hi_thr) & ok;
-            const unsigned long long mL = __ballot(n <= lo_thr) & ok & ~mH;
-            shift_in(wH, mH);
-            shift_in(wL, mL);
-            write_lane(fHlo, static_cast<uint32_t>(mH), ii);
-            write_lane(fHhi, static_cast<uint32_t>(mH >> 32), ii);
-            write_lane(fLlo, static_cast<uint32_t>(mL), ii);
-            write_lane(fLhi, static_cast<uint32_t>(mL >> 32), ii);
-        }
-        const bool diag = (bj == bi);
-        if (lane < RI && i0 + lane < a.G) {
-            uint32_t *row = a.table + (static_cast<size_t>(i0 + lane) * kPlanes + pl) * a.Wp + 2 * bj;
-            if (!diag) {
-                *reinterpret_cast<uint2 *>(row) = uint2{fLlo, fLhi};
-                *reinterpret_cast<uint2 *>(row + a.Wp) = uint2{fHlo, fHhi};
-            } else {
-                if (fLlo) atomicOr(row, fLlo);
-                if (fLhi) atomicOr(row + 1, fLhi);
-                if (fHlo) atomicOr(row + a.Wp, fHlo);
-                if (fHhi) atomicOr(row + a.Wp + 1, fHhi);
-            }
-        }
-        if (j < a.G) {  // mirror: pair (j, i) is in state 2 - state(i, j)
-            uint32_t *row = a.table + (static_cast<size_t>(j) * kPlanes + pl) * a.Wp + (i0 >> 5);
-            if (!diag) {
-                row[0] = wH; row[a.Wp] = wL;
-            } else {
-                if (wH) atomicOr(row, wH);
-                if (wL) atomicOr(row + a.Wp, wL);
-            }
-        }
-    }
+    for (int r = 0; r < RJ; ++r)
+        emit_gene<RI>(a, i0, jl + 64 * r, bi, lane, pl, hi_thr, lo_thr, [&](int ii) { return val(r, ii); });
 }
 
 // block -> tile mapping shared by k1_pairs, k1_group_counts and k1_classify.  Work order (speed only, never
@@ -441,44 +448,60 @@ __global__ __launch_bounds__(64, 3) void k1w_pairs(K1Args a)
 {
     constexpr int RI = kTileI, RJ = kRJ, NE = TIES ? 2 : 1;
     __shared__ uint4 ring[256];  // two slots of one block's tile operand: 2 x 2 KB
+    const unsigned long long t_begin = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     const uint32_t item = a.items[blockIdx.x];  // side << 31 | wave chunk << 16 | i-tile
     const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(item & 0xFFFFu) * RI);
     const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((item >> 16) & 0x7FFFu) * (64 * RJ));
     const int side = __builtin_amdgcn_readfirstlane(static_cast<int>(item >> 31));
     const int lane = threadIdx.x, jl = jw + lane, bi = i0 >> 6;
     const int bb = side ? a.tb : a.cb, be = side ? a.te : a.ce;
-    uint32_t cnt[NE][RJ][RI / 2];  // [0]: n_gt, [1]: n_ge -- packed, rows 2h and 2h+1
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-        for (int r = 0; r < RJ; ++r)
-#pragma unroll
-            for (int h = 0; h < RI / 2; ++h) cnt[e][r][h] = 0;
+    u32x16 gt0 = 0, gt1 = 0, gt2 = 0, gt3 = 0;  // n_gt of the lane's four genes: packed, rows 2h and 2h+1
+    u32x16 ge[TIES ? RJ : 1];                   // n_ge (tie-rich data only)
+    unsigned long long t_loop = 0, t_emit = 0;
+    if (a.stamps) t_loop = __builtin_amdgcn_s_memrealtime();
     if (be > bb) {
         const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * 4 * a.Gp * 16;
         const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * 64;
         const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
 #pragma clang loop unroll(disable)
         for (int e = 0; e < NE; ++e) {  // (one copy of the loop's code, not two)
-            const char *ab = reinterpret_cast<const char *>(e ? a.AH : a.AL) + aoff;
+            const char *ab = reinterpret_cast<const char *>(e ? a.AL : (TIES ? a.AH : a.AL)) + aoff;  // ties: hi first, lo last
             u32x16 c0, c1, c2, c3;
             k1_loop<NB>(c0, c1, c2, c3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * 64u,
                         static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
-#pragma unroll
-            for (int h = 0; h < RI / 2; ++h) { cnt[e][0][h] = c0[h]; cnt[e][1][h] = c1[h]; cnt[e][2][h] = c2[h]; cnt[e][3][h] = c3[h]; }
+            if (TIES && e == 0) { ge[0] = c0; ge[1 % (TIES ? RJ : 1)] = c1; ge[2 % (TIES ? RJ : 1)] = c2; ge[3 % (TIES ? RJ : 1)] = c3; }
+            else { gt0 = c0; gt1 = c1; gt2 = c2; gt3 = c3; }
         }
+    } else if (TIES) {
+#pragma unroll
+        for (int r = 0; r < RJ; ++r) ge[r] = 0;
     }
+    if (a.stamps) t_emit = __builtin_amdgcn_s_memrealtime();
     const int g = side ? a.gt : a.gc;
     const int m = side ? a.m2 : a.m1, n = side ? a.nt : a.nc;
-    emit_side<RI, RJ>(a, i0, jl, bi, lane, side ? 2 : 0, m, n - m,
-                      [&](int r, int ii) {
-                          int nre = static_cast<int>(unpack16(cnt[0][r], ii));
-                          if (TIES) {  // tie coins (:72-77)
-                              const uint32_t neq = unpack16(cnt[NE - 1][r], ii) - static_cast<uint32_t>(nre);
-                              if (neq) nre += tie_wins(a.seed, i0 + ii, jl + 64 * r, g, neq);
-                          }
-                          return nre;
-                      });
+    // the four genes one after the other in a real loop (the count registers rotate): a quarter of the code of the
+    // unrolled form, which at 41 KB pushed the count loop out of the instruction cache whenever a wave classified
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < RJ; ++r) {
+        const u32x16 cur = gt0;
+        u32x16 cge = 0;
+        if (TIES) cge = ge[r];
+        emit_gene<RI>(a, i0, jl + 64 * r, bi, lane, side ? 2 : 0, m, n - m, [&](int ii) {
+            const uint32_t w = cur[ii >> 1];
+            int nre = static_cast<int>((ii & 1) ? (w >> 16) : (w & 0xFFFFu));
+            if (TIES) {  // tie coins (:72-77)
+                const uint32_t w2 = cge[ii >> 1];
+                const uint32_t neq = ((ii & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)) - static_cast<uint32_t>(nre);
+                if (neq) nre += tie_wins(a.seed, i0 + ii, jl + 64 * r, g, neq);
+            }
+            return nre;
+        });
+        gt0 = gt1; gt1 = gt2; gt2 = gt3;
+    }
+    if (a.stamps && lane == 0) {
+        unsigned long long *st = a.stamps + static_cast<size_t>(blockIdx.x) * 4;
+        st[0] = t_begin; st[1] = t_loop; st[2] = t_emit; st[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2614,7 +2637,7 @@ int32_t launch_k1(reo_ctx *c, int k)
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `units` is a local: the copy must have read it before any return below
     }
     a.unit_map = c->unit_map.p;
-    a.items = nullptr;
+    a.items = nullptr; a.stamps = nullptr;
     if (wave) {
         // item list of the wave form: the owned units in order, side-major, i-tile-major, wave chunks fastest; kept
         // until the geometry changes
@@ -2643,6 +2666,7 @@ int32_t launch_k1(reo_ctx *c, int k)
             std::memcpy(c->k1_items_key, key, sizeof key);
         }
         a.items = c->k1_items.p;
+        if (getenv("REO_K1_STAMPS")) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), std::max<size_t>(c->k1_items_n, 1) * 4 * sizeof(unsigned long long)));
     }
     REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
     if (units.empty()) return REO_OK;
@@ -2667,6 +2691,22 @@ int32_t launch_k1(reo_ctx *c, int k)
     }
     toc(c);
     REO_HIP_CHECK(hipGetLastError());
+    if (a.stamps) {  // diagnostic: where an item's time goes (100 MHz marks)
+        std::vector<unsigned long long> h(c->k1_items_n * 4);
+        REO_HIP_CHECK(hipMemcpyAsync(h.data(), a.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        double pro = 0, loop = 0, emit = 0;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t i = 0; i < c->k1_items_n; ++i) {
+            pro += static_cast<double>(h[4 * i + 1] - h[4 * i]); loop += static_cast<double>(h[4 * i + 2] - h[4 * i + 1]);
+            emit += static_cast<double>(h[4 * i + 3] - h[4 * i + 2]);
+            t0 = std::min(t0, h[4 * i]); t1 = std::max(t1, h[4 * i + 3]);
+        }
+        const double n = static_cast<double>(c->k1_items_n) * 100.0;  // marks per microsecond
+        fprintf(stderr, "[reo] K1 wave items %zu: prologue %.2f us, count loop %.2f us, classification %.2f us per item; first start to last end %.3f ms\n",
+                c->k1_items_n, pro / n, loop / n, emit / n, static_cast<double>(t1 - t0) / 1e5);
+        (void)hipFree(a.stamps);
+    }
     return REO_OK;
 }
 

@@ -3,8 +3,9 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "rankcompv3.jl_amd", "csrc"))
 from gen_k1_loop import Loop
 
-VARIANTS = [("base", ()), ("nowaitvm", ("nowait_vm",)), ("noreload", ("noreload",)), ("nowaitlds", ("nowait_lds",)),
-            ("nolds", ("nolds",)), ("nopop", ("nopop",)), ("lshl", ("lshl",)), ("valuonly", ("noreload", "nolds")), ("bitoponly", ("noreload", "nolds", "nopop"))]
+VARIANTS = [("base", ()), ("wait4", ("wait4",)), ("nowaitvm", ("nowait_vm",)), ("noreload", ("noreload",)), ("nowaitlds", ("nowait_lds",)),
+            ("nowait", ("nowait_lds", "nowait_vm")), ("nolds", ("nolds",)), ("nopop", ("nopop",)), ("lshl", ("lshl",)),
+            ("valuonly", ("noreload", "nolds")), ("bitoponly", ("noreload", "nolds", "nopop"))]
 print("typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));")
 for name, opts in VARIANTS:
     lp = Loop(15, False, "probe_" + name, opts=opts)
