@@ -14,7 +14,9 @@ borrow chains + v_bcnt_u32_b32); the tallies are integer popcounts and the per-g
 `scaling` is "strong": with N GPUs the same 20k x 1k problem is split over the ranks (pair tiles; one RCCL all-gather
 of the ranks' own class-table words inside reo_build_pairs, in-library: reo_comm_init_rank).
 
-python bench.py [--gpus N --steps K --warmup W]; for N > 1 launch with torch.distributed.run (one rank per GPU).
+python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no WORLD_SIZE in the environment the script launches
+itself under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) BEFORE anything touches the GPU, passes
+rank 0's JSON line through and exits with the launcher's status; under an external torch.distributed.run it is a rank.
 """
 from __future__ import annotations
 
@@ -74,6 +76,18 @@ def main() -> None:
     ap.add_argument("--debug-gloo-one-gpu", action="store_true",
                     help="debug only: every rank uses cuda:0 and the table exchange goes through gloo via the host")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing here has imported torch or made a HIP call, and
+        # the ranks are CHILD processes (never an exec of a process that has initialised the GPU).
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
@@ -186,7 +200,8 @@ def main() -> None:
         return {"bound": "valu", "achieved": rate / 1e12, "peak": peak / 1e12, "unit": "Tcmp/s", "frac": rate / peak,
                 "peak_definition": "256 CU x 4 SIMD x 2.4 GHz x 2048 comparisons per (2*bits+4)%s cycles, bits=%d" % (" x 2" if ties else "", plane_bits(G)),
                 "hbm_achieved_GBps": k1_bytes / (k1_ms * 1e-3) / 1e9, "hbm_frac": k1_bytes / (k1_ms * 1e-3) / HBM_PEAK,
-                "ms_per_launch": k1_ms, "traffic": None, "kernel": "k1_pairs<%d,%s,false>" % (plane_bits(G), "true" if ties else "false")}
+                "ms_per_launch": k1_ms, "traffic": None,
+                "kernel": ("k1w_pairs<%d,%s>" if os.environ.get("REO_K1_WAVE", "1") != "0" else "k1_pairs<%d,%s,false>") % (plane_bits(G), "true" if ties else "false")}
 
     k1 = k1_roofline(tm, info, bool(info["has_ties"]))
     k2_ms = tm["k2_full_ms"] / max(tm["k2_full_launches"], 1)   # whole-table scans only

@@ -2645,9 +2645,13 @@ int32_t launch_k1(reo_ctx *c, int k)
         const uint64_t key[4] = {static_cast<uint64_t>(c->G) << 32 | static_cast<uint32_t>(c->Gp), static_cast<uint64_t>(RJ) << 32 | static_cast<uint32_t>(Q),
                                  static_cast<uint64_t>(c->world) << 32 | static_cast<uint32_t>(c->rank), units.size()};
         if (!c->k1_items.p || std::memcmp(key, c->k1_items_key, sizeof key) != 0) {
-            std::vector<uint32_t> items;
-            items.reserve(units.size() * 2 * kUnitH * QW);
+            // Workgroup b runs on XCD b & 7.  An item goes to the list of XCD (wave chunk & 7), so an XCD's L2 keeps seeing
+            // the same few pos chunks of a panel (walking the order below dealt one item at a time, every XCD touched
+            // every chunk and the L2s missed twice as often); the lists are then levelled by moving the surplus of the
+            // long ones -- their last items -- to the short ones, and interleaved.
+            std::vector<uint32_t> lists[8];
             const int G = static_cast<int>(c->G);
+            size_t total_items = 0;
             for (uint32_t um : units)
                 for (uint32_t side = 0; side < 2; ++side)
                     for (int t = 0; t < kUnitH; ++t)
@@ -2655,8 +2659,20 @@ int32_t launch_k1(reo_ctx *c, int k)
                             const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + t, cw = static_cast<int>(um >> 16) * QW + w;
                             const int i0 = it * kTileI, jw = cw * CW;
                             if (i0 >= G || jw >= G || ((jw + CW - 1) >> 6) < (i0 >> 6)) continue;  // no pair i < j < G in it
-                            items.push_back(side << 31 | static_cast<uint32_t>(cw) << 16 | static_cast<uint32_t>(it));
+                            lists[cw & 7].push_back(side << 31 | static_cast<uint32_t>(cw) << 16 | static_cast<uint32_t>(it));
+                            ++total_items;
                         }
+            const size_t per = (total_items + 7) / 8;
+            std::vector<uint32_t> surplus;
+            for (auto &l : lists)
+                while (l.size() > per) { surplus.push_back(l.back()); l.pop_back(); }
+            for (auto &l : lists)
+                while (l.size() < per && !surplus.empty()) { l.push_back(surplus.back()); surplus.pop_back(); }
+            std::vector<uint32_t> items;
+            items.reserve(total_items);
+            for (size_t k = 0; k < per; ++k)
+                for (auto &l : lists)
+                    if (k < l.size()) items.push_back(l[k]);
             if ((rc = c->k1_items.ensure(std::max<size_t>(items.size(), 1)))) return rc;
             if (!items.empty()) {
                 REO_HIP_CHECK(hipMemcpyAsync(c->k1_items.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
