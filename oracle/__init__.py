@@ -187,5 +187,52 @@ def tuned_identify_degs(X, gid, ngroups, pval_reo, pval_deg, padj_deg, ref0, n_i
     return res, iters.value, [tuple(int(v) for v in t) for t in trace[: iters.value]]
 
 
+def _tuned_sigs():
+    L = lib()
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.tuned_build_table.restype = ctypes.c_int32
+    L.tuned_build_table.argtypes = [_f64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _i32p, ctypes.c_int32, ctypes.c_double, ctypes.c_uint64, u64p]
+    L.tuned_iterate.restype = ctypes.c_int32
+    L.tuned_iterate.argtypes = [u64p, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _u8p, ctypes.c_int32, ctypes.c_int32, _f64p,
+                                ctypes.POINTER(ctypes.c_int32), _i32p]
+    L.tuned_decode.restype = None
+    L.tuned_decode.argtypes = [u64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _u8p]
+    return L, u64p
+
+
+def tuned_build_table(X, gid, ngroups, pval_reo, seed):
+    """R2's class table of comparison 0 as bit planes [G][cL cH tL tH][ceil(G / 64)] uint64 (reo_tuned.c; two groups)."""
+    L, u64p = _tuned_sigs()
+    X, G, S = _colmajor(X)
+    gid = np.ascontiguousarray(gid, dtype=np.int32)
+    T = np.zeros((G, 4, (G + 63) // 64), dtype=np.uint64)
+    rc = L.tuned_build_table(_p(X, _f64p), G, S, G, _p(gid, _i32p), ngroups, pval_reo, seed, _p(T, u64p))
+    if rc:
+        raise RuntimeError(f"tuned_build_table rc={rc}")
+    return T
+
+
+def tuned_iterate(T, ref0, pval_deg, padj_deg, n_iter, n_conv):
+    """The iteration driver on a table of tuned_build_table: (result G x 15, passes, trace)."""
+    L, u64p = _tuned_sigs()
+    G = T.shape[0]
+    ref0 = np.ascontiguousarray(ref0, dtype=np.uint8)
+    res = np.zeros((G, 15), order="F")
+    iters = ctypes.c_int32(0)
+    trace = np.zeros((max(n_iter, 1), 2), dtype=np.int32)
+    rc = L.tuned_iterate(_p(T, u64p), G, pval_deg, padj_deg, _p(ref0, _u8p), n_iter, n_conv, _p(res, _f64p), ctypes.byref(iters), _p(trace, _i32p))
+    if rc:
+        raise RuntimeError(f"tuned_iterate rc={rc}")
+    return res, iters.value, [tuple(int(v) for v in t) for t in trace[: iters.value]]
+
+
+def tuned_decode(T, i0, i1, j0, j1):
+    """Class codes 0..8 (255 on the diagonal) of a block of a table of tuned_build_table."""
+    L, u64p = _tuned_sigs()
+    code = np.empty((i1 - i0, j1 - j0), dtype=np.uint8)
+    L.tuned_decode(_p(T, u64p), T.shape[0], i0, i1, j0, j1, _p(code, _u8p))
+    return code
+
+
 def num_threads():
     return int(lib().oracle_num_threads())

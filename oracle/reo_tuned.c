@@ -73,9 +73,10 @@ static void transpose64(uint64_t a[64])
         }
 }
 
-int32_t tuned_identify_degs(const double *X, int64_t G, int64_t S, int64_t ld, const int32_t *group_id, int32_t ngroups,
-                            double pval_reo, double pval_deg, double padj_deg, const uint8_t *ref0, int32_t n_iter,
-                            int32_t n_conv, uint64_t seed, double *result, int32_t *iters_run, int32_t *trace)
+/* The class table of comparison 0 as bit planes: T[G][cL cH tL tH][W] 64-bit words, W = ceil(G / 64) (caller-allocated,
+ * G * 4 * W words); :363-392. */
+int32_t tuned_build_table(const double *X, int64_t G, int64_t S, int64_t ld, const int32_t *group_id, int32_t ngroups,
+                          double pval_reo, uint64_t seed, uint64_t *T)
 {
     if (ngroups != 2 || G > 65535) return -2;
     int32_t n0 = 0;
@@ -87,8 +88,8 @@ int32_t tuned_identify_degs(const double *X, int64_t G, int64_t S, int64_t ld, c
     uint16_t *POS = (uint16_t *)aligned_alloc(64, (size_t)G * SP * 2), *LO = (uint16_t *)aligned_alloc(64, (size_t)G * SP * 2),
              *HI = (uint16_t *)aligned_alloc(64, (size_t)G * SP * 2);
     const int64_t W = (G + 63) / 64;
-    uint64_t *T = (uint64_t *)calloc((size_t)G * 4 * W, 8);  /* [G][cL cH tL tH][W] */
     if (!POS || !LO || !HI || !T) return -4;
+    memset(T, 0, (size_t)G * 4 * W * 8);
     for (size_t x = 0; x < (size_t)G * SP; ++x) { POS[x] = 0x7FFF; LO[x] = 0x8000; HI[x] = 0x8000; }  /* padding slots (biased): the largest position, the smallest edges */
     int any_tie = 0;
     const int dbg = getenv("REO_TUNED_DEBUG") != NULL;
@@ -155,6 +156,16 @@ int32_t tuned_identify_degs(const double *X, int64_t G, int64_t S, int64_t ld, c
             }
     free(POS); free(LO); free(HI);
     MARK("mirror");
+    return 0;
+}
+
+/* The iteration driver (:396-425) on a table made by tuned_build_table. */
+int32_t tuned_iterate(const uint64_t *T, int64_t G, double pval_deg, double padj_deg, const uint8_t *ref0, int32_t n_iter,
+                      int32_t n_conv, double *result, int32_t *iters_run, int32_t *trace)
+{
+    const int64_t W = (G + 63) / 64;
+    const int dbg = getenv("REO_TUNED_DEBUG") != NULL;
+    double t0 = omp_get_wtime();
     /* ---- iteration driver (:396-425) */
     uint8_t *ref = (uint8_t *)malloc((size_t)G), *inds = (uint8_t *)malloc((size_t)G);
     uint64_t *mask = (uint64_t *)malloc(sizeof(uint64_t) * W);
@@ -207,6 +218,36 @@ int32_t tuned_identify_degs(const double *X, int64_t G, int64_t S, int64_t ld, c
     }
     MARK("passes");
     if (iters_run) *iters_run = passes;
-    free(ref); free(inds); free(mask); free(cont); free(T);
+    free(ref); free(inds); free(mask); free(cont);
+    return rc;
+}
+
+/* class codes 0..8 (255 on the diagonal) of the block [i0, i1) x [j0, j1) of a table, row-major (like k_decode) */
+void tuned_decode(const uint64_t *T, int64_t G, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *code)
+{
+    const int64_t W = (G + 63) / 64;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = i0; i < i1; ++i) {
+        const uint64_t *r = T + (size_t)i * 4 * W;
+        for (int64_t j = j0; j < j1; ++j) {
+            const int64_t w = j >> 6; const int sh = (int)(j & 63);
+            const int l = (int)((r[w] >> sh) & 1), h = (int)((r[W + w] >> sh) & 1), tl = (int)((r[2 * W + w] >> sh) & 1), th = (int)((r[3 * W + w] >> sh) & 1);
+            const int ic = l ? 0 : (h ? 2 : 1), it = tl ? 0 : (th ? 2 : 1);
+            code[(size_t)(i - i0) * (size_t)(j1 - j0) + (size_t)(j - j0)] = i == j ? 255 : (uint8_t)(3 * ic + it);
+        }
+    }
+}
+
+int32_t tuned_identify_degs(const double *X, int64_t G, int64_t S, int64_t ld, const int32_t *group_id, int32_t ngroups,
+                            double pval_reo, double pval_deg, double padj_deg, const uint8_t *ref0, int32_t n_iter,
+                            int32_t n_conv, uint64_t seed, double *result, int32_t *iters_run, int32_t *trace)
+{
+    if (ngroups != 2 || G > 65535) return -2;
+    const int64_t W = (G + 63) / 64;
+    uint64_t *T = (uint64_t *)malloc((size_t)G * 4 * W * 8);
+    if (!T) return -4;
+    int32_t rc = tuned_build_table(X, G, S, ld, group_id, ngroups, pval_reo, seed, T);
+    if (!rc) rc = tuned_iterate(T, G, pval_deg, padj_deg, ref0, n_iter, n_conv, result, iters_run, trace);
+    free(T);
     return rc;
 }

@@ -300,8 +300,8 @@ void reo_destroy(reo_ctx *c)
     for (reo_ctx *p : c->peers) reo_destroy(p);
     c->peers.clear();
     (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);  // nothing of the communicator's is still queued when it goes
     comm_release(c);
-    (void)hipStreamSynchronize(c->stream);
     collect_timings(c);
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
@@ -353,10 +353,11 @@ static int32_t set_matrix_all(reo_ctx *c, const void *X, int64_t G, int64_t S, i
         reo_ctx *p = c->peers[d];
         if (!on_device) { rc = set_matrix(p, X, G, S, ld, dtype, false); continue; }
         if ((rc = use(p)) || (rc = p->dX_owned.ensure(static_cast<size_t>(G) * S * 8))) break;
-        for (int64_t s = 0; s < S && !rc; ++s)  // column by column: the source may have a leading dimension
-            if (hipMemcpyPeerAsync(p->dX_owned.p + s * G * 8, p->device, static_cast<const unsigned char *>(X) + s * ld * 8, c->device, G * 8, p->stream) != hipSuccess) {
-                set_error("peer copy of the matrix to device %d failed", p->device); rc = REO_EHIP;
-            }
+        // one 2-D copy (the source may have a leading dimension); unified addressing finds the source device
+        if (hipMemcpy2DAsync(p->dX_owned.p, static_cast<size_t>(G) * 8, X, static_cast<size_t>(ld) * 8, static_cast<size_t>(G) * 8, static_cast<size_t>(S),
+                             hipMemcpyDefault, p->stream) != hipSuccess) {
+            set_error("peer copy of the matrix to device %d failed", p->device); rc = REO_EHIP;
+        }
         if (!rc && hipStreamSynchronize(p->stream) != hipSuccess) { set_error("peer copy failed"); rc = REO_EHIP; }
         if (!rc) { invalidate(p); p->G = G; p->S = S; p->dtype = dtype; p->dX = p->dX_owned.p; p->ld = G; }
     }
@@ -464,9 +465,12 @@ int32_t reo_build_pairs(reo_ctx *c, int32_t k)
     if (c && !c->peers.empty()) {
         if ((rc = multi_build_pairs(c, k, build_local))) return rc;
     } else {
-        if ((rc = build_local(c, k))) return rc;
-        if ((rc = exchange_table(c))) return rc;
-        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c && c->comm_dead) { set_error("the communicator of this context was aborted after an earlier failure: attach a new one (reo_comm_init_rank)"); return REO_ECOMM; }
+        // a rank that fails here must not leave its peers waiting inside the collective: it aborts its communicator
+        // (a failing caller-supplied hook has to do the same with its own)
+        if ((rc = build_local(c, k))) { if (c && c->comm && c->world > 1) comm_abort(c); return rc; }
+        if ((rc = exchange_table(c))) { if (c->comm) comm_abort(c); return rc; }
+        if ((rc = comm_wait(c))) return rc;
     }
     c->t_ms[5] += 1.0;
     collect_timings(c);

@@ -173,6 +173,8 @@ struct reo_ctx {
     int built_k = -1;
     bool table_complete = false;        // world > 1: the shards' parts have been summed (api.hip, exchange_table)
     void *comm = nullptr;               // ncclComm_t of the in-library RCCL path (comm.hip), or null
+    bool comm_dead = false;             // the communicator was aborted after a failure: every later build answers REO_ECOMM
+    bool multi_one_device = false;      // reo_create_multi under REO_MULTI_ONE_DEVICE=1 (test seam: shards share one device, no RCCL)
     std::vector<reo_ctx *> peers;       // reo_create_multi: the contexts of devices 1.. owned by this (leader) context
     // one-vs-rest with > 2 groups: per-group pair counts shared by the comparisons (kernels.hip, k1_group_counts)
     reo::DevBuf<uint16_t> gcounts;      // [ngroups + 1][Gp/32][4][Gp][8]
@@ -257,6 +259,8 @@ int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d
 // comm.hip: in-library RCCL.  Returns REO_OK after enqueueing the sum on c->stream, 1 when no communicator is attached
 int32_t comm_allgather(reo_ctx *c, const void *send, void *recv, int64_t bytes_per_rank);
 void comm_release(reo_ctx *c);
+void comm_abort(reo_ctx *c);                     // abort the communicator, mark the context unusable for exchanges
+int32_t comm_wait(reo_ctx *c);                   // stream wait that watches the communicator (async errors, time limit)
 int32_t multi_build_pairs(reo_ctx *lead, int32_t k, int32_t (*build_local)(reo_ctx *, int32_t));
 
 // timing helpers (api.hip)

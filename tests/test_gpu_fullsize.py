@@ -2,8 +2,9 @@
 
 Config 3 (20 000 x 1 000): the WHOLE class table and the whole iteration loop (128 forced passes for the tie-free
 family, the converging run for the tie-rich one) against the oracle -- about a minute of oracle time on the GPU
-box's host cores.  Config 4 (30 000 x 4 000, the one-chunk-per-panel geometry): thresholds, sampled blocks of the
-class table against the oracle's counts, the tally identity, and two shards == unsharded.  Config 5 (sparse
+box's host cores.  Config 4 (30 000 x 4 000, the one-chunk-per-panel geometry), both data families: the WHOLE class table, the tallies and
+the whole loop (128 forced passes and the converging run) against the tuned oracle R2 (bit-identical to the plain one,
+tests/test_oracle.py), sampled blocks against the plain oracle's counts, and two shards == unsharded.  Config 5 (sparse
 20 000 x 50 000 cells -> n_pseudo = 64 -> identify_degs): pseudo-bulk sums and the whole run against the oracle.
 Same tolerances as tests/test_gpu_parity.py."""
 import threading
@@ -89,34 +90,47 @@ def _two_shard_run(pkg, X, gid, seed, pval_reo, ref0, n_iter, n_conv):
     return results
 
 
-def test_config4_30000x4000_one_chunk_per_panel(pkg, oracle):
-    """BASELINE config 4 on one GPU: the geometry with one j-chunk per panel (Q = 1), never reached by the small tests."""
+@pytest.mark.parametrize("family", ["t0", "t1"])
+def test_config4_30000x4000_one_chunk_per_panel(pkg, oracle, family):
+    """BASELINE config 4 on one GPU: the geometry with one j-chunk per panel (Q = 1), never reached by the small tests.
+    Whole class table (9e8 ordered pairs), tallies, 128 forced passes and the converging run against the oracle."""
     G, S, seed = 30000, 4000, 0x5EED0004
-    X = pkg.synth.t0_ranks(G, S, seed)
+    X = (pkg.synth.t0_ranks if family == "t0" else pkg.synth.t1_counts)(G, S, seed)
     group = pkg.synth.groups(S)
     ref0 = pkg.synth.ref_mask(G, 3000, seed)
     ctx, gid, ng = _setup(pkg, X, group, seed)
     Xf = np.asfortranarray(X.astype(np.float64))
+    T = oracle.tuned_build_table(Xf, gid, 2, 0.01, seed)            # R2: about a minute on the box's host cores
     with ctx:
         thr = ctx.get_thresholds()
         assert thr[:, 0].tolist() == [1059, 1059]
         ctx.build_pairs(0)
         info = ctx.info()
-        assert info["chunks_per_panel"] == 1 and info["has_ties"] == 0 and info["Gp"] == 30720
-        # first / last panel, diagonal, the padded tail of the last chunk, mirrored blocks
+        assert info["chunks_per_panel"] == 1 and info["has_ties"] == (0 if family == "t0" else 1) and info["Gp"] == 30720
+        for i0 in range(0, G, 5000):                                # the whole table, 5 000 rows at a time
+            got = ctx.get_codes(i0, i0 + 5000, 0, G)
+            assert np.array_equal(got, oracle.tuned_decode(T, i0, i0 + 5000, 0, G)), ("class table differs from the oracle", i0)
+        del got
+        # the plain oracle's literal comparator on sampled blocks: first / last panel, diagonal, padded tail, mirrored
         for (i0, j0, n) in [(0, 29960, 40), (0, 0, 40), (15000, 15000, 48), (29952, 29952, 48), (1023, 1000, 40), (777, 22000, 32),
                             (22000, 777, 32), (29968, 31, 32), (29690, 29700, 40)]:
-            got = ctx.get_codes(i0, i0 + n, j0, j0 + n)
             exp = _expected_block_codes(oracle, Xf, gid, thr, seed, i0, i0 + n, j0, j0 + n)
-            assert np.array_equal(got, exp), (i0, j0)
+            assert np.array_equal(ctx.get_codes(i0, i0 + n, j0, j0 + n), exp), (i0, j0)
         cont = ctx.tally(ref0)
-        assert np.array_equal(cont.sum(axis=1), ref0.sum() - ref0.astype(np.int64)) and cont.min() >= 0
-        # a few genes' tallies straight from the oracle's counts (all partners)
-        for i in (0, 12345, 29999):
-            codes = _expected_block_codes(oracle, Xf, gid, thr, seed, i, i + 1, 0, G)[0]
-            exp = np.bincount(codes[ref0 & (np.arange(G) != i)], minlength=9)[:9]
-            assert np.array_equal(cont[i], exp), i
+        exp1, _, _ = oracle.tuned_iterate(T, ref0, 1.0, 0.05, 1, 0)  # the first pass's tallies are those of ref0
+        assert np.array_equal(cont, exp1[:, 2:11].astype(np.int64))
+        res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, 128, 0)
+        exp, eit, etr = oracle.tuned_iterate(T, ref0, 1.0, 0.05, 128, 0)
+        assert iters == eit == 128 and trace == etr, (iters, eit, [a for a in zip(trace, etr) if a[0] != a[1]][:3])
+        _check_result(res, exp)
+        res5, it5, tr5 = ctx.identify_degs(ref0, 1.0, 0.05, 128, 5)
+        exp5, eit5, etr5 = oracle.tuned_iterate(T, ref0, 1.0, 0.05, 128, 5)
+        assert it5 == eit5 and tr5 == etr5
+        _check_result(res5, exp5)
         res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, 8, 0)
+    del T
+    if family == "t1":
+        return
     shards = _two_shard_run(pkg, X, gid, seed, 0.01, ref0, 8, 0)
     owned = [s[0]["tiles_owned"] for s in shards]
     assert sum(owned) == shards[0][0]["tiles_total"] and min(owned) > 0.4 * max(owned)

@@ -209,7 +209,8 @@ def test_config2_5000x200_one_iteration(pkg, oracle):
 
 
 def test_full_size_properties_20000x1000(pkg):
-    """BASELINE config 3 size: properties that need no oracle (which would take hours here)."""
+    """BASELINE config 3 size: size-independent properties of the domain (mirror rule, tally identity, count symmetry, BH
+    monotonicity) -- beside, not instead of, the whole-table comparison with the oracle in tests/test_gpu_fullsize.py."""
     G, S, seed = 20000, 1000, 0x5EED0003
     X = pkg.synth.t0_ranks(G, S, seed)
     group = pkg.synth.groups(S)
@@ -882,6 +883,69 @@ def test_in_library_rccl_and_multi_context_from_python(pkg, oracle):
     exp, eit, etr = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, 6, 1, seed)
     assert it0 == eit and tr0 == etr
     _check_result(res0, exp)
+
+
+@pytest.mark.parametrize("shards,family", [(3, "t1"), (2, "t0"), (5, "t1")])
+def test_multi_context_orchestration_on_one_device(pkg, oracle, monkeypatch, shards, family):
+    """reo_create_multi with REO_MULTI_ONE_DEVICE=1 (comm.hip): the shard contexts share this box's one GPU and their
+    packs travel by device copies, everything else is the code an N-GPU node runs -- one host thread per shard building
+    its own pair tiles, x_pack on the peers, hand-over to the leader, x_expand_* there, groups / thresholds / matrix
+    (host and device source, the latter by ONE 2-D copy) handed to the peers.  Equal to the one-context run, bit for bit."""
+    import torch
+    monkeypatch.setenv("REO_MULTI_ONE_DEVICE", "1")
+    G, S, seed = 3300, 72, 0x5EED0061
+    X = (pkg.synth.t1_counts if family == "t1" else pkg.synth.t0_ranks)(G, S, seed)
+    gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+    ref0 = pkg.synth.ref_mask(G, 700, seed)
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+        ctx.build_pairs(0)
+        code0 = ctx.get_codes(0, G, 0, G)
+        res0, it0, tr0 = ctx.identify_degs(ref0, 1.0, 0.05, 6, 1)
+    ld = G + 24   # a device-resident source with a leading dimension
+    Xd = torch.zeros((S, ld), dtype=torch.int64, device="cuda:0")
+    Xd[:, :G] = torch.from_numpy(np.ascontiguousarray(X.T)).to("cuda:0")
+    torch.cuda.synchronize()
+    for source in ("host", "device"):
+        with pkg.Context(seed=seed, n_gpus=shards) as ctx:
+            if source == "host":
+                ctx.set_matrix(X)
+            else:
+                ctx.set_matrix_device(Xd.data_ptr(), G, S, ld, "i64")
+            ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+            ctx.build_pairs(0)
+            info = ctx.info()
+            assert info["tiles_owned"] < info["tiles_total"]       # the leader built a share only
+            assert np.array_equal(ctx.get_codes(0, G, 0, G), code0)
+            res, it, tr = ctx.identify_degs(ref0, 1.0, 0.05, 6, 1)
+            assert it == it0 and tr == tr0 and np.array_equal(res, res0)
+            ctx.build_pairs(1)                                     # a second table on the same contexts
+            code_b = ctx.get_codes(0, 64, 0, G)
+        with pkg.Context(device=0, seed=seed) as ctx:
+            ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+            ctx.build_pairs(1)
+            assert np.array_equal(ctx.get_codes(0, 64, 0, G), code_b)
+    exp, eit, etr = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, 6, 1, seed)
+    assert it0 == eit and tr0 == etr
+    _check_result(res0, exp)
+
+
+@pytest.mark.parametrize("family", ["t0", "t1"])
+def test_workgroup_form_of_the_pair_kernel_still_matches(pkg, oracle, monkeypatch, family):
+    """REO_K1_WAVE=0 selects round 2's workgroup form of K1 (kept for > 2 groups and as a cross-check): same table."""
+    G, S, seed = 2600, 96, 0x5EED0062
+    X = (pkg.synth.t1_counts if family == "t1" else pkg.synth.t0_ranks)(G, S, seed)
+    gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+    codes = []
+    for wave in ("1", "0"):
+        monkeypatch.setenv("REO_K1_WAVE", wave)
+        with pkg.Context(device=0, seed=seed) as ctx:
+            ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+            ctx.build_pairs(0)
+            codes.append(ctx.get_codes(0, G, 0, G))
+    assert np.array_equal(codes[0], codes[1])
+    thr = np.array([oracle.threshold(int((gid == 0).sum())), oracle.threshold(int((gid == 1).sum()))], dtype=np.int32)
+    assert np.array_equal(codes[0], oracle.build_codes(X.astype(np.float64), gid, 2, 0, thr, seed))
 
 
 @pytest.mark.parametrize("window,light,band,xcc", [("3", "1", "32", "1"), ("1", "1", "32", "1"), ("12", "1", "2", "1"), ("12", "1", "0", "0"),

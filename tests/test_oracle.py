@@ -155,3 +155,21 @@ def test_tuned_cpu_variant_equals_the_reference_faithful_restatement(oracle, kin
         got, it, tr = oracle.tuned_identify_degs(X, gid, 2, 0.05, 1.0, 0.05, ref0, n_iter, n_conv, 77)
         assert it == eit and tr == etr
         assert np.array_equal(got, exp, equal_nan=True)
+
+
+def test_tuned_table_functions_agree_with_the_plain_oracle(oracle, pkg):
+    """tuned_build_table / tuned_decode / tuned_iterate (what the config-4 GPU test compares with) == reo_oracle.c."""
+    G, S, seed = 700, 44, 0x5EED0071
+    for fam in (pkg.synth.t0_ranks, pkg.synth.t1_counts):
+        X = fam(G, S, seed).astype(np.float64)
+        gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+        thr = [oracle.threshold(22), oracle.threshold(22)]
+        code = oracle.build_codes(X, gid, 2, 0, thr, seed)
+        T = oracle.tuned_build_table(X, gid, 2, 0.01, seed)
+        assert np.array_equal(oracle.tuned_decode(T, 0, G, 0, G), code)
+        assert np.array_equal(oracle.tuned_decode(T, 13, 77, 600, 700), code[13:77, 600:700])
+        ref0 = pkg.synth.ref_mask(G, 150, seed)
+        for n_iter, n_conv in ((12, 0), (12, 3)):
+            exp, eit, etr = oracle.iterate(code, ref0, 1.0, 0.05, n_iter, n_conv)
+            res, it, tr = oracle.tuned_iterate(T, ref0, 1.0, 0.05, n_iter, n_conv)
+            assert it == eit and tr == etr and np.array_equal(res, exp)
