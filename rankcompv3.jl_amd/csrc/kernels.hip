@@ -489,10 +489,14 @@ __global__ __launch_bounds__(64, 3) void k1w_pairs(K1Args a)
         emit_gene<RI>(a, i0, jl + 64 * r, bi, lane, side ? 2 : 0, m, n - m, [&](int ii) {
             const uint32_t w = cur[ii >> 1];
             int nre = static_cast<int>((ii & 1) ? (w >> 16) : (w & 0xFFFFu));
-            if (TIES) {  // tie coins (:72-77)
+            if (TIES) {  // tie coins (:72-77): n = n_gt + Binomial(n_eq, 1/2) lies in [n_gt, n_ge].  The coins are drawn only
+                         // where they can change the class, i.e. where that interval straddles a threshold (0.4 % of the
+                         // pairs of count-like data; a wave skips the hash unless one of its 64 pairs needs it) -- any
+                         // other pair is in the same class for every outcome, so the table is the oracle's bit for bit.
                 const uint32_t w2 = cge[ii >> 1];
-                const uint32_t neq = ((ii & 1) ? (w2 >> 16) : (w2 & 0xFFFFu)) - static_cast<uint32_t>(nre);
-                if (neq) nre += tie_wins(a.seed, i0 + ii, jl + 64 * r, g, neq);
+                const int nge = static_cast<int>((ii & 1) ? (w2 >> 16) : (w2 & 0xFFFFu));
+                const bool amb = (nre < m && nge >= m) || (nre <= n - m && nge > n - m);
+                if (amb) nre += tie_wins(a.seed, i0 + ii, jl + 64 * r, g, static_cast<uint32_t>(nge - nre));
             }
             return nre;
         });
