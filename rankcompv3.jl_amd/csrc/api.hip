@@ -271,6 +271,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->device = device;
     c->seed = seed;
     if (const char *e = getenv("REO_K1_WAVE")) c->k1_wave = (e[0] != '0');
+    if (const char *e = getenv("REO_CHECK_HOOK_TABLE")) c->check_hook_table = (e[0] != '0');
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
     if (const char *e = getenv("REO_LIGHT_BAND")) c->light_band = std::max(0, atoi(e));
     if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
@@ -471,6 +472,17 @@ int32_t reo_build_pairs(reo_ctx *c, int32_t k)
         if ((rc = build_local(c, k))) { if (c && c->comm && c->world > 1) comm_abort(c); return rc; }
         if ((rc = exchange_table(c))) { if (c->comm) comm_abort(c); return rc; }
         if ((rc = comm_wait(c))) return rc;
+        if (c->table_complete && (c->ag || c->ar) && c->check_hook_table) {
+            // a caller-supplied collective: the table it delivered must be a class table (one 35 us scan), else the
+            // passes would run on tallies that break their invariants
+            int bad = 0;
+            if ((rc = launch_check_table(c, &bad))) return rc;
+            if (bad) {
+                c->table_complete = false;
+                set_error("the exchange hook delivered an inconsistent class table (a pair in two states, or bits outside the table)");
+                return REO_ECOMM;
+            }
+        }
     }
     c->t_ms[5] += 1.0;
     collect_timings(c);

@@ -783,6 +783,26 @@ __global__ void k_decode(const uint32_t *__restrict__ table, int Wp, int i0, int
     code[static_cast<size_t>(i - i0) * (j1 - j0) + (j - j0)] = (i == j) ? 255 : static_cast<uint8_t>(3 * ic + it);
 }
 
+// Consistency of a class table that came through an exchange: a pair is in at most one of the states L / H on each side,
+// nothing sits on the diagonal or past the last gene.  One wave per row; flag[0] |= 1 on a violation.  (A caller-supplied
+// collective that delivers wrong words would otherwise hand the iteration passes tallies that break their invariants.)
+__global__ __launch_bounds__(256) void k_check_table(const uint32_t *__restrict__ table, int G, int Wp, int32_t *__restrict__ flag)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= G) return;
+    const uint32_t *r = table + static_cast<size_t>(row) * kPlanes * Wp;
+    uint32_t bad = 0;
+    for (int w = lane; w < Wp; w += 64) {
+        const uint32_t cl = r[w], ch = r[Wp + w], tl = r[2 * Wp + w], th = r[3 * Wp + w];
+        uint32_t valid = 0xFFFFFFFFu;                                   // columns < G, not the diagonal
+        const int c0 = w * 32;
+        if (c0 + 32 > G) valid = c0 >= G ? 0u : (0xFFFFFFFFu >> (c0 + 32 - G));
+        if ((row >> 5) == w) valid &= ~(1u << (row & 31));
+        bad |= (cl & ch) | (tl & th) | ((cl | ch | tl | th) & ~valid);
+    }
+    if (__ballot(bad != 0) && lane == 0) atomicOr(flag, 1);
+}
+
 // bytes -> bit mask (one workgroup-wide ballot per 64 genes)
 __global__ __launch_bounds__(256) void k_pack_ref(const uint8_t *__restrict__ bytes, int Gp,
                                                   uint32_t *__restrict__ bits)
@@ -2783,6 +2803,23 @@ int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
     k1_counts<<<grid, 256, 0, c->stream>>>(c->pos.p, c->lo.p, c->hi.p, c->Gp, plane_bits(c->G), c->goff_dev.p, c->ngroups,
                                            static_cast<int>(i0), static_cast<int>(i1), static_cast<int>(j0), static_cast<int>(j1), d_gt, d_eq);
     REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+// 0 = consistent, 1 = not (synchronises the stream)
+int32_t launch_check_table(reo_ctx *c, int *bad)
+{
+    *bad = 0;
+    DevBuf<int32_t> flag;
+    int32_t rc = flag.ensure(1);
+    if (rc) return rc;
+    REO_HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(int32_t), c->stream));
+    const int G = static_cast<int>(c->G);
+    k_check_table<<<(G + 3) / 4, 256, 0, c->stream>>>(c->table.p, G, c->Wp, flag.p);
+    int32_t h = 0;
+    REO_HIP_CHECK(hipMemcpyAsync(&h, flag.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *bad = h;
     return REO_OK;
 }
 

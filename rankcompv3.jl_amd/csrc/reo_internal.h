@@ -173,6 +173,7 @@ struct reo_ctx {
     int built_k = -1;
     bool table_complete = false;        // world > 1: the shards' parts have been summed (api.hip, exchange_table)
     void *comm = nullptr;               // ncclComm_t of the in-library RCCL path (comm.hip), or null
+    int check_hook_table = 1;           // REO_CHECK_HOOK_TABLE=0: skip the consistency scan of a table delivered by a caller's hook (timing tools)
     bool comm_dead = false;             // the communicator was aborted after a failure: every later build answers REO_ECOMM
     bool multi_one_device = false;      // reo_create_multi under REO_MULTI_ONE_DEVICE=1 (test seam: shards share one device, no RCCL)
     std::vector<reo_ctx *> peers;       // reo_create_multi: the contexts of devices 1.. owned by this (leader) context
@@ -245,6 +246,7 @@ int32_t exchange_units_per_rank(const reo_ctx *c);
 int32_t launch_pack_units(reo_ctx *c);           // this shard's units -> c->xsend
 int32_t launch_expand_units(reo_ctx *c);         // c->xrecv (every shard's pack) -> the table: the others' words and their mirrors
 int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq);
+int32_t launch_check_table(reo_ctx *c, int *bad);  // consistency of an exchanged class table (kernels.hip, k_check_table)
 int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
 int32_t launch_tally(reo_ctx *c, int nref);

@@ -930,6 +930,35 @@ def test_multi_context_orchestration_on_one_device(pkg, oracle, monkeypatch, sha
     _check_result(res0, exp)
 
 
+def test_a_hook_that_delivers_wrong_words_is_refused(pkg):
+    """A caller-supplied collective that hands back something that is not the other shards' words (here: this shard's own
+    pack in every slot) makes an inconsistent class table -- pairs in two states at once.  reo_build_pairs scans the table
+    it got from a hook and answers REO_ECOMM; the passes never run on it (a timing tool that did exactly this, unchecked,
+    ended in a GPU memory fault: profiles/faults/r3_scaling_model_garbage_table.log)."""
+    import torch
+    G, S, seed, world = 3000, 64, 0x5EED0063, 2
+    X = pkg.synth.t0_ranks(G, S, seed)
+    gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+    dev = torch.device("cuda", 0)
+
+    def gather(send, recv, nbytes, stream):
+        torch.cuda.ExternalStream(stream, device=dev).synchronize()
+        src = torch.as_tensor(pkg.dist._RawDevBytes(send, nbytes), device=dev)
+        dst = torch.as_tensor(pkg.dist._RawDevBytes(recv, nbytes * world), device=dev)
+        for r in range(world):
+            dst[r * nbytes:(r + 1) * nbytes].copy_(src)
+        torch.cuda.synchronize()
+
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+        ctx.set_shard(1, world)
+        ctx.set_allgather(gather)
+        with pytest.raises(pkg.ReoError, match="inconsistent class table"):
+            ctx.build_pairs(0)
+        with pytest.raises(pkg.ReoError):
+            ctx.tally(pkg.synth.ref_mask(G, 300, seed))   # still no complete table
+
+
 @pytest.mark.parametrize("family", ["t0", "t1"])
 def test_workgroup_form_of_the_pair_kernel_still_matches(pkg, oracle, monkeypatch, family):
     """REO_K1_WAVE=0 selects round 2's workgroup form of K1 (kept for > 2 groups and as a cross-check): same table."""
