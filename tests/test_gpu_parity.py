@@ -931,10 +931,9 @@ def test_multi_context_orchestration_on_one_device(pkg, oracle, monkeypatch, sha
 
 
 def test_a_hook_that_delivers_wrong_words_is_refused(pkg):
-    """A caller-supplied collective that hands back something that is not the other shards' words (here: this shard's own
-    pack in every slot) makes an inconsistent class table -- pairs in two states at once.  reo_build_pairs scans the table
-    it got from a hook and answers REO_ECOMM; the passes never run on it (a timing tool that did exactly this, unchecked,
-    ended in a GPU memory fault: profiles/faults/r3_scaling_model_garbage_table.log)."""
+    """A caller-supplied collective that hands back something that is not the other shards' words (here: all ones) makes
+    an inconsistent class table -- pairs in two states at once, bits on the diagonal.  reo_build_pairs scans the table it
+    got from a hook and answers REO_ECOMM; the passes, whose kernels rely on the tally identity, never run on it."""
     import torch
     G, S, seed, world = 3000, 64, 0x5EED0063, 2
     X = pkg.synth.t0_ranks(G, S, seed)
@@ -943,10 +942,8 @@ def test_a_hook_that_delivers_wrong_words_is_refused(pkg):
 
     def gather(send, recv, nbytes, stream):
         torch.cuda.ExternalStream(stream, device=dev).synchronize()
-        src = torch.as_tensor(pkg.dist._RawDevBytes(send, nbytes), device=dev)
         dst = torch.as_tensor(pkg.dist._RawDevBytes(recv, nbytes * world), device=dev)
-        for r in range(world):
-            dst[r * nbytes:(r + 1) * nbytes].copy_(src)
+        dst.fill_(0xFF)
         torch.cuda.synchronize()
 
     with pkg.Context(device=0, seed=seed) as ctx:
