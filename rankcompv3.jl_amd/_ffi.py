@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreo_hip.so")
+LIB_PATH = os.environ.get("REO_LIB_PATH") or os.path.join(_HERE, "libreo_hip.so")  # (REO_LIB_PATH: an instrumented build, tools/asan_host.sh)
 CSRC = os.path.join(_HERE, "csrc")
 
 REO_OK, REO_EINVAL, REO_EHIP, REO_ECOMM, REO_ENOMEM = 0, -1, -2, -3, -4
@@ -58,6 +58,7 @@ def build_library(force: bool = False) -> str:
 
 
 _LIB = None
+SIGNATURES = {}   # name -> (restype, argtypes) of every bound entry point, filled by lib()
 
 
 def lib() -> ctypes.CDLL:
@@ -114,6 +115,8 @@ def lib() -> ctypes.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    global SIGNATURES
+    SIGNATURES = sig
     _LIB = L
     return L
 

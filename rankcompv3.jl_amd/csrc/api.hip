@@ -378,7 +378,7 @@ int32_t reo_set_groups(reo_ctx *c, const int32_t *group_id, int64_t len, int32_t
         set_error("only %d level in 'group', at least 2 levels are needed", ngroups);
         return REO_EINVAL;
     }
-    if (ngroups > 64) { set_error("more than 64 groups"); return REO_EINVAL; }
+    if (ngroups > len) { set_error("%d groups declared for %lld samples", ngroups, (long long)len); return REO_EINVAL; }  // (any number the samples allow, like :353)
     std::vector<int32_t> cnt(ngroups, 0);
     int next = 0;
     for (int64_t s = 0; s < len; ++s) {

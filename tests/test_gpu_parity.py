@@ -437,6 +437,21 @@ def test_three_group_golden_and_synthetic_one_vs_rest(pkg, oracle, golden):
             assert np.array_equal(run.res[:, 1 + 16 * cm["k"]: 16 + 16 * cm["k"]].astype(float), cm["result"])
 
 
+def test_more_than_64_groups(pkg, oracle):
+    """One-vs-rest with 70 groups of two or three samples each (the reference takes any number of levels, :353-362; the
+    threshold falls back to the group size with its warning, :87-90): class tables of a few comparisons against the oracle."""
+    G, S, seed, C = 700, 170, 0x5EED0064, 70
+    X = pkg.synth.t1_counts(G, S, seed)
+    gid = (np.arange(S) % C).astype(np.int32)
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, C); thr = ctx.compute_thresholds(0.01)
+        assert thr.shape == (2, C)
+        for k in (0, 37, 69):
+            ctx.build_pairs(k)
+            code = oracle.build_codes(X.astype(np.float64), gid, C, k, [int(thr[0, k]), int(thr[1, k])], seed)
+            assert np.array_equal(ctx.get_codes(0, G, 0, G), code), k
+
+
 @pytest.mark.parametrize("family", ["t0", "t1"])
 def test_shared_group_counts_equal_recounting(pkg, oracle, family, monkeypatch):
     """> 2 groups: the comparisons classify from per-group counts kept in HBM (counted once); the class
