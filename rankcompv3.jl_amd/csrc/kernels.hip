@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "reo_internal.h"
 
@@ -1809,6 +1810,16 @@ __device__ __forceinline__ void spread_add(int32_t (*parts)[32], int v, bool xcc
 // reo_create's check of what the per-XCD histograms rest on: every wave adds 1 to 64 counters of its XCD's partial, 16
 // times, with atomics that need not be coherent beyond the XCD's L2, and notes its XCD.  Afterwards every partial must
 // hold exactly 16 x (waves that named it) in each counter.
+// (the production pattern is two launches: kl_head zeroes all eight partials with plain stores from whatever XCD its
+//  workgroups run on, kl_rank then adds with L2-local atomics in the next launch -- the self-test does the same)
+__global__ __launch_bounds__(256) void k_xcc_selftest_zero(int32_t *part, int32_t *waves_of)
+{
+    // every workgroup stores into all partials (values from different XCDs race benignly: all zeros), after dirtying its
+    // own XCD's copy of the lines so that a stale line would be seen
+    for (int i = threadIdx.x; i < kHistParts * 64; i += 256) part[i] = 0;
+    if (threadIdx.x < kHistParts) waves_of[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void k_xcc_selftest(int32_t *part, int32_t *waves_of)
 {
     const unsigned x = xcc_id();
@@ -2940,10 +2951,19 @@ int32_t xcc_selftest(reo_ctx *c, int *ok)
 {
     *ok = 0;
     DevBuf<int32_t> buf;
+    // the verdict is a property of the device, not of the context: checked once per device and process
+    static std::mutex mu;
+    static int verdict[64];   // 0 unknown, 1 failed, 2 passed
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (c->device >= 0 && c->device < 64 && verdict[c->device]) { *ok = verdict[c->device] == 2; return REO_OK; }
+    }
     int32_t rc = buf.ensure(kHistParts * 64 + kHistParts);
     if (rc) return rc;
-    REO_HIP_CHECK(hipMemsetAsync(buf.p, 0, buf.n * sizeof(int32_t), c->stream));
-    k_xcc_selftest<<<1024, 256, 0, c->stream>>>(buf.p, buf.p + kHistParts * 64);
+    REO_HIP_CHECK(hipMemsetAsync(buf.p, 0xFF, buf.n * sizeof(int32_t), c->stream));  // garbage first: the zeroing launch has to win
+    k_xcc_selftest<<<1024, 256, 0, c->stream>>>(buf.p, buf.p + kHistParts * 64);      // dirty every XCD's L2 with atomics on the lines
+    k_xcc_selftest_zero<<<1024, 256, 0, c->stream>>>(buf.p, buf.p + kHistParts * 64);  // plain stores from arbitrary XCDs (kl_head's zeroing)
+    k_xcc_selftest<<<1024, 256, 0, c->stream>>>(buf.p, buf.p + kHistParts * 64);      // L2-local atomics in the next launch (kl_rank)
     std::vector<int32_t> h(buf.n);
     REO_HIP_CHECK(hipMemcpyAsync(h.data(), buf.p, buf.n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -2955,6 +2975,10 @@ int32_t xcc_selftest(reo_ctx *c, int *ok)
         for (int l = 0; l < 64; ++l) good = good && h[x * 64 + l] == 16 * w;
     }
     *ok = good && waves == 1024 * 4 ? 1 : 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (c->device >= 0 && c->device < 64) verdict[c->device] = *ok ? 2 : 1;
+    }
     return REO_OK;
 }
 

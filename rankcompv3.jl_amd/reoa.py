@@ -159,6 +159,7 @@ def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: 
         if any(g is None for g in sample_groups):
             raise ArgumentError("Expression matrix has sample columns that the meta data does not describe")
     data = np.asarray(data)
+    all_names = list(sample_names)
     s_inds = (data > 0).sum(axis=0) > min_profiles  # :618
     data = data[:, s_inds]
     sample_names = [n for n, k in zip(sample_names, s_inds) if k]
@@ -197,9 +198,9 @@ def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: 
     # pseudo-bulking the table is rebuilt from the new profile names (:612-613) and has the two columns only
     if n_pseudo > 0:
         meta_out = pd.DataFrame({"Name": sample_names, "Group": sample_groups})
-    else:
-        meta_out = meta.set_index("Name", drop=False).loc[sample_names].reset_index(drop=True)
-        meta_out = meta_out[["Name", "Group"] + [c for c in meta_out.columns if c not in ("Name", "Group")]]
+    else:  # `meta` itself, minus the rows whose first column names a dropped profile (:612-623): row and column order kept
+        dropped = set(all_names) - set(sample_names)
+        meta_out = meta[~meta.iloc[:, 0].isin(dropped)].reset_index(drop=True)
     return {"data": data, "sample_names": sample_names, "sample_groups": sample_groups, "gene_names": gene_names,
             "g_name": g_name, "ref": ref, "meta": meta_out}
 

@@ -152,3 +152,14 @@ def test_df_meta_keeps_every_meta_column(R, tmp_path):
     m = _write(tmp_path, "m.tsv", "sample\tgrp\tbatch\tage\ns1\tx\tb1\t30\ns2\tx\tb2\t41\ns3\ty\tb1\t52\ns4\ty\tb2\t63\n")
     p = R.prepare(e, m, use_hk_genes="no")
     assert list(p["meta"].columns) == ["Name", "Group", "batch", "age"] and p["meta"]["age"].tolist() == [30, 41, 52, 63]
+
+
+def test_df_meta_keeps_the_meta_files_own_row_and_column_order(R, tmp_path):
+    """meta_group is `meta` minus the rows of the profiles that the min_profiles filter dropped (:612-623): the meta
+    file's own row order (here not the expression matrix's column order) and column order survive."""
+    e = _write(tmp_path, "e.tsv", "gene\ts1\ts2\ts3\ts4\nA\t1\t0\t3\t4\nB\t1\t0\t5\t6\nC\t2\t0\t1\t1\n")
+    m = _write(tmp_path, "m.tsv", "sample\tgrp\tbatch\ns4\ty\tb2\ns2\tx\tb2\ns1\tx\tb1\ns3\ty\tb1\n")
+    p = R.prepare(e, m, use_hk_genes="no")            # s2 has no expressed gene: dropped by the profile filter
+    assert p["sample_names"] == ["s1", "s3", "s4"] and p["sample_groups"] == ["x", "y", "y"]
+    assert list(p["meta"].columns) == ["Name", "Group", "batch"]
+    assert p["meta"]["Name"].tolist() == ["s4", "s1", "s3"] and p["meta"]["batch"].tolist() == ["b2", "b1", "b1"]
