@@ -162,14 +162,16 @@ void oracle_build_codes(const double *X, int64_t G, int64_t S, int64_t ld,
                         const int32_t *group_id, int32_t ngroups, int32_t k,
                         const int32_t *thr, uint64_t seed, uint8_t *code)
 {
-    int32_t gs[64];
-    memset(gs, 0, sizeof gs);
+    int32_t *gs = (int32_t *)calloc((size_t)ngroups, sizeof(int32_t));  /* any number of levels (:353) */
     for (int64_t s = 0; s < S; ++s) gs[group_id[s]]++;
     int s1 = gs[k], s2 = (int)S - gs[k];
-#pragma omp parallel for schedule(dynamic, 8)
+    free(gs);
+#pragma omp parallel
+    {
+    int *gt = (int *)malloc(sizeof(int) * (size_t)ngroups), *eq = (int *)malloc(sizeof(int) * (size_t)ngroups);
+#pragma omp for schedule(dynamic, 8)
     for (int64_t i = 0; i < G; ++i) {
         code[i * G + i] = 0xFF;
-        int gt[64], eq[64];
         for (int64_t j = i + 1; j < G; ++j) {
             for (int g = 0; g < ngroups; ++g) gt[g] = eq[g] = 0;
             for (int64_t s = 0; s < S; ++s) {
@@ -187,6 +189,8 @@ void oracle_build_codes(const double *X, int64_t G, int64_t S, int64_t ld,
             code[i * G + j] = (uint8_t)c;       /* :385 */
             code[j * G + i] = (uint8_t)(8 - c); /* :386 */
         }
+    }
+    free(gt); free(eq);
     }
 }
 
