@@ -3,8 +3,9 @@
 # code of every translation unit is built with -fsanitize=address (device code untouched: GPU ASan is not available
 # on this pool), and everything that can run WITHOUT a device is run against it -- symbol table, reo_threshold over
 # n = 2..1500, reo_create / reo_create_multi error paths, null and out-of-range arguments of every entry point that
-# checks before it touches the GPU.  With a GPU (on the box: `bash tools/asan_host.sh gpu`) the parity tests run on
-# the instrumented host code as well.
+# checks before it touches the GPU.  (On a GPU box the instrumented library cannot create a context: AMD's ASan runtime
+# intercepts hsa_amd_memory_pool_allocate and refuses without xnack, which this pool does not offer --
+# gpurun_out/r3_asan_host.log, round 3.  The audit is therefore CPU-only.)
 set -e
 cd "$(dirname "$0")/.."
 B=${TMPDIR:-/tmp}/reo_asan
@@ -21,7 +22,4 @@ RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.asan-x86_64.so" | head
 export LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 REO_LIB_PATH=$B/libreo_hip_asan.so
 python3 tools/asan_host_calls.py
 python3 -m pytest tests/test_library_cpu.py -x -q -p no:cacheprovider
-if [ "$1" = "gpu" ]; then
-  python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -p no:cacheprovider -k "not light_passes_on_random and not 65535"
-fi
 echo "asan_host: clean"
