@@ -92,6 +92,19 @@ static int32_t major_reo_lower_count(int32_t n, double thr)
     return first_above < 0 ? -1 : n - first_above + 1;  // -idx + 2 + n with idx = x + 1
 }
 
+// Host wait for the stream on the hot path.  REO_SPIN_WAIT=1 polls the stream instead of the blocking wait; measured on
+// the bench step (tools/step_breakdown.py, round 3): 6.05 against 6.10 ms -- the host-side gaps of a step are not the
+// wake-up, so the blocking wait stays the default (a polling thread is a bad neighbour in a threaded host program).
+static hipError_t stream_wait(reo_ctx *c)
+{
+    if (!c->spin_wait) return hipStreamSynchronize(c->stream);
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q != hipErrorNotReady) return q;
+        if (spin > (1u << 22)) return hipStreamSynchronize(c->stream);  // a long wait after all: stop burning the core
+    }
+}
+
 static int32_t use(reo_ctx *c)
 {
     if (!c) { set_error("null context"); return REO_EINVAL; }
@@ -271,6 +284,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->device = device;
     c->seed = seed;
     if (const char *e = getenv("REO_K1_WAVE")) c->k1_wave = (e[0] != '0');
+    if (const char *e = getenv("REO_SPIN_WAIT")) c->spin_wait = (e[0] != '0');
     if (const char *e = getenv("REO_CHECK_HOOK_TABLE")) c->check_hook_table = (e[0] != '0');
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
     if (const char *e = getenv("REO_LIGHT_BAND")) c->light_band = std::max(0, atoi(e));
@@ -456,7 +470,7 @@ static int32_t build_local(reo_ctx *c, int32_t k)
     if ((rc = c->table.ensure(static_cast<size_t>(c->G) * kPlanes * c->Wp))) return rc;
     c->built_k = -1;
     if ((rc = launch_k1(c, k))) return rc;
-    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    REO_HIP_CHECK(stream_wait(c));
     return REO_OK;
 }
 
@@ -609,7 +623,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         }
         toc(c);
         REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
-        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        REO_HIP_CHECK(stream_wait(c));
         if (getenv("REO_DEBUG_PASSES"))
             fprintf(stderr, "batch: %d sorting + %d light launches, passes %d -> %d, need_full %d, done %d, last_full %d, changed genes in front of the next pass %d\n", nfull, nlight,
                     passes, c->host_state->passes, c->host_state->need_full, c->host_state->done, c->host_state->last_full,
@@ -659,7 +673,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     }
     if (iters_run) *iters_run = passes;
     REO_HIP_CHECK(hipMemcpyAsync(result, c->result.p, sizeof(double) * 15 * G, hipMemcpyDeviceToHost, c->stream));
-    REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    REO_HIP_CHECK(stream_wait(c));
     collect_timings(c);
     return REO_OK;
 }
