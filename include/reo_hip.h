@@ -63,12 +63,17 @@ void reo_destroy(reo_ctx *ctx);
  * run with no further collective.
  *
  * (a) one process, all GPUs: reo_create_multi(&ctx, n_gpus (0 = all visible), seed) returns a context that is
- *     used exactly like a one-GPU context; it drives one device context each, sums the tables onto device 0
- *     with RCCL (ncclReduce) inside reo_build_pairs and runs the passes there.
+ *     used exactly like a one-GPU context; it drives one device context each; inside reo_build_pairs the peers pack
+ *     the table words of their own pair tiles and hand them to device 0 (grouped ncclSend / ncclRecv), which unpacks
+ *     them, derives the mirror words and runs the passes.  NOT yet run on more than one GPU (no such box in this
+ *     project's pool): the orchestration is tested with the shards sharing one device (REO_MULTI_ONE_DEVICE=1).
  * (b) one process per GPU: rank 0 calls reo_comm_unique_id and hands the 128 bytes to the other ranks by any
  *     means; every rank calls reo_comm_init_rank(ctx, id, rank, world) (ncclCommInitRank + reo_set_shard).
  *     reo_build_pairs then ends with an ncclAllGather of the shards' own table words on the context's stream (see
- *     reo_set_allgather for the protocol); all ranks get identical results.
+ *     reo_set_allgather for the protocol); all ranks get identical results.  A rank that fails inside reo_build_pairs
+ *     aborts its communicator (ncclCommAbort) so that its peers' collective ends with REO_ECOMM instead of waiting;
+ *     the wait itself watches ncclCommGetAsyncError and gives up after REO_COMM_TIMEOUT_S seconds (default 300).  After
+ *     such a failure the context needs a new communicator.  NOT yet run with more than one rank on hardware.
  * (c) bring your own collective: reo_set_shard + reo_set_allgather or reo_set_allreduce (hooks below).  */
 enum { REO_UNIQUE_ID_BYTES = 128 };
 int32_t reo_create_multi(reo_ctx **out, int32_t n_gpus, uint64_t seed);
@@ -87,7 +92,9 @@ int32_t reo_set_shard(reo_ctx *ctx, int32_t rank, int32_t world);
  * precede the sum, and the sum has to precede whatever is enqueued on `stream` afterwards.  A hook that enqueues
  * the collective on `stream` (RCCL ncclAllReduce(..., stream), or torch.distributed.all_reduce under
  * torch.cuda.stream(ExternalStream(stream))) needs no host synchronisation; a hook that works on the host must
- * synchronise `stream` itself before and after.  Return 0 on success. */
+ * synchronise `stream` itself before and after.  Return 0 on success.  A hook that fails must abort its own
+ * communicator: the library cannot release peers that wait inside a caller's collective.  The table a hook delivers is
+ * scanned for consistency (a pair in two states, bits outside the table: REO_ECOMM). */
 typedef int32_t (*reo_allreduce_fn)(void *dev_buf, int64_t count, void *stream, void *user);
 int32_t reo_set_allreduce(reo_ctx *ctx, reo_allreduce_fn fn, void *user);
 
@@ -103,8 +110,8 @@ int32_t reo_set_allgather(reo_ctx *ctx, reo_allgather_fn fn, void *user);
 
 /* Expression matrix, G genes x S samples, column-major with leading dimension
  * ld >= G: the `data` argument of identify_degs (src/RankCompV3.jl:340) as
- * Matrix(df_expr) produces it (:652), eltype Float64 or Int64.  G and S must
- * be in [2, 65535] (16-bit positions) and S in [2, 1048576]; values must be finite.  *_host copies from host memory;
+ * Matrix(df_expr) produces it (:652), eltype Float64 or Int64.  G must be in [2, 65535] (16-bit positions; what
+ * lifting this takes: DESIGN.md section 8) and S in [2, 1048576]; values must be finite.  *_host copies from host memory;
  * *_dev uses a buffer already resident in HBM (it must stay valid until
  * reo_build_pairs returns). */
 int32_t reo_set_matrix_f64(reo_ctx *ctx, const double *X, int64_t G, int64_t S, int64_t ld);
@@ -115,7 +122,7 @@ int32_t reo_set_matrix_dev_i64(reo_ctx *ctx, const void *dX, int64_t G, int64_t 
 /* Group of each sample: the `group` argument (src/RankCompV3.jl:341) recoded
  * to 0-based ids in order of first appearance (unique(), :353).  Length must
  * equal S (else REO_EINVAL = the DimensionMismatch of :355); ngroups must be
- * >= 2 (:356) and <= 64. */
+ * >= 2 (:356); any number of levels that the samples allow. */
 int32_t reo_set_groups(reo_ctx *ctx, const int32_t *group_id, int64_t len, int32_t ngroups);
 
 /* Stable-REO thresholds: get_major_reo_lower_count (src/RankCompV3.jl:81-92)
@@ -150,7 +157,8 @@ int32_t reo_get_codes(reo_ctx *ctx, int64_t i0, int64_t i1, int64_t j0, int64_t 
 
 /* Per-gene 3x3 contingency builder, src/RankCompV3.jl:403: cont is G x 9
  * row-major (n11 n12 n13 n21 ... n33), ref_mask has one byte per gene
- * (non-zero = reference gene).  With world > 1 the all-reduce hook is used. */
+ * (non-zero = reference gene).  Needs the complete class table: with world > 1 and no exchange done by
+ * reo_build_pairs (communicator or hook) it refuses with REO_ECOMM. */
 int32_t reo_tally(reo_ctx *ctx, const uint8_t *ref_mask, int32_t *cont);
 
 /* Iteration driver + McCullagh test, src/RankCompV3.jl:396-425 (and :225-259)

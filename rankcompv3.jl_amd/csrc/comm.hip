@@ -7,9 +7,11 @@
 // (reo_comm_init_rank): every shard packs the forward words of its own units (upper triangle: 107 MB in all at 20 000
 // genes), ONE ncclAllGather per class table hands every pack to every shard, and each shard unpacks the others' words
 // and derives their mirror words itself (api.hip, exchange_table; kernels.hip, x_pack / x_expand_*) -- a quarter of the
-// bytes that an in-place sum of the whole 205 MB table moves.  One process, all GPUs (reo_create_multi): the tables,
-// whose bits are disjoint, are summed onto the leader with one ncclReduce.  The iteration passes then run with no
-// collective at all.
+// bytes that an in-place sum of the whole 205 MB table moves.  One process, all GPUs (reo_create_multi): the peers'
+// packs go to the leader with grouped ncclSend / ncclRecv and are unpacked there.  The iteration passes then run with
+// no collective at all.  Failure handling: comm_abort / comm_wait below -- a rank that cannot go on aborts its
+// communicator, a waiting rank watches ncclCommGetAsyncError and a time limit; nobody blocks for ever.
+// No run with more than one rank has happened on hardware (the pool offers one GPU per box).
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -120,8 +122,8 @@ int32_t reo_comm_init_rank(reo_ctx *c, const void *id, int32_t rank, int32_t wor
 // Single-process form: one context per visible GPU behind one handle.  The returned (leader) context lives on
 // device 0 and owns the others; every entry point of reo_hip.h may be called on it exactly as on a one-GPU
 // context.  reo_build_pairs runs the transform and each device's share of the pair tiles on all devices at once
-// (one host thread per device), the tables are summed onto the leader with one ncclReduce, and the passes run on
-// the leader.
+// (one host thread per device), the peers' packed table words are handed to the leader (multi_build_pairs below), and
+// the passes run on the leader.
 int32_t reo_create_multi(reo_ctx **out, int32_t n_gpus, uint64_t seed)
 {
     if (!out) { set_error("out is null"); return REO_EINVAL; }

@@ -73,7 +73,7 @@ class DegRun:
 
 
 def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv, *,
-                      seed: int = 0, device: int = -1, shard=(0, 1), allreduce=None, profile: bool = False) -> DegRun:
+                      seed: int = 0, device: int = -1, shard=(0, 1), allreduce=None, allgather=None, profile: bool = False) -> DegRun:
     """identify_degs with the extras (trace, timings) kept.  Two groups: one comparison, group 1 vs
     group 2 (the reference's `gnum == 2` path, :387-389,431-434).  More groups: one comparison per
     group, that group vs every other sample (:375-390,396-436), 16 more columns each."""
@@ -97,7 +97,10 @@ def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref
         thr = ctx.compute_thresholds(pval_reo)
         if shard[1] > 1:
             ctx.set_shard(*shard)
-            ctx.set_allreduce(allreduce)
+            if allgather is not None:
+                ctx.set_allgather(allgather)   # all-gather of the shards' own table words (what the in-library RCCL path does)
+            else:
+                ctx.set_allreduce(allreduce)   # in-place sum of the whole table
         for k in range(ncomp):  # `for k=1:gnum ... if gnum==2 break` (:396,431-434)
             ctx.build_pairs(k)
             result, iters, trace = ctx.identify_degs(np.asarray(ref_gene, dtype=bool), pval_deg, padj_deg, n_iter, n_conv)
