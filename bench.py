@@ -215,6 +215,10 @@ def main() -> None:
         with open(pmc) as f:
             tr = json.load(f)
         k1["traffic"], k2["traffic"] = tr.get("k1_pairs"), tr.get("k2_tally")
+        k1["traffic_source"], k2["traffic_source"] = tr.get("k1_pairs_source"), tr.get("k2_tally_source")
+        traffic_tie = (tr.get("k1_pairs_tie_rich"), tr.get("k1_pairs_tie_rich_source"))
+    else:
+        traffic_tie = (None, None)
 
     out = {
         "metric": "gene-pair·sample comparisons/sec at 20k genes × 1k samples",
@@ -255,7 +259,8 @@ def main() -> None:
         r1 = k1_roofline(tm1, info1, True)
         out["tie_rich"] = {"workload": "T1 family (zero-inflated counts, ~2 % tied cells): lo and hi band edges, two borrow chains per pair",
                            "ms_per_step": dt1 / st * 1e3, "value": units * st / dt1, "k1_ms": r1["ms_per_launch"], "frac": r1["frac"],
-                           "peak": r1["peak"], "achieved": r1["achieved"], "kernel": r1["kernel"], "steps": st}
+                           "peak": r1["peak"], "achieved": r1["achieved"], "kernel": r1["kernel"], "steps": st,
+                           "traffic": traffic_tie[0], "traffic_source": traffic_tie[1]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oracle = ge.load_oracle()
