@@ -456,26 +456,32 @@ __global__ __launch_bounds__(64, 3) void k1w_pairs(K1Args a)
     const int side = __builtin_amdgcn_readfirstlane(static_cast<int>(item >> 31));
     const int lane = threadIdx.x, jl = jw + lane, bi = i0 >> 6;
     const int bb = side ? a.tb : a.cb, be = side ? a.te : a.ce;
-    u32x16 gt0 = 0, gt1 = 0, gt2 = 0, gt3 = 0;  // n_gt of the lane's four genes: packed, rows 2h and 2h+1
-    u32x16 ge[TIES ? RJ : 1];                   // n_ge (tie-rich data only)
+    u32x16 gt0, gt1, gt2, gt3;                    // n_gt of the lane's four genes: packed, rows 2h and 2h+1
+    uint32_t park[TIES ? RJ * (RI / 2) : 1];      // n_ge (tie-rich data): the first pass's counts wait in the private segment
     unsigned long long t_loop = 0, t_emit = 0;
     if (a.stamps) t_loop = __builtin_amdgcn_s_memrealtime();
     if (be > bb) {
         const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * 4 * a.Gp * 16;
         const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * 64;
         const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
+        // ONE copy of the loop's code for both passes; nothing but the parked counts (memory) lives across the second pass
 #pragma clang loop unroll(disable)
-        for (int e = 0; e < NE; ++e) {  // (one copy of the loop's code, not two)
+        for (int e = 0; e < NE; ++e) {
             const char *ab = reinterpret_cast<const char *>(e ? a.AL : (TIES ? a.AH : a.AL)) + aoff;  // ties: hi first, lo last
-            u32x16 c0, c1, c2, c3;
-            k1_loop<NB>(c0, c1, c2, c3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * 64u,
+            k1_loop<NB>(gt0, gt1, gt2, gt3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * 64u,
                         static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
-            if (TIES && e == 0) { ge[0] = c0; ge[1 % (TIES ? RJ : 1)] = c1; ge[2 % (TIES ? RJ : 1)] = c2; ge[3 % (TIES ? RJ : 1)] = c3; }
-            else { gt0 = c0; gt1 = c1; gt2 = c2; gt3 = c3; }
-        }
-    } else if (TIES) {
+            if (TIES && e == 0) {
 #pragma unroll
-        for (int r = 0; r < RJ; ++r) ge[r] = 0;
+                for (int h = 0; h < RI / 2; ++h) {
+                    park[h] = gt0[h]; park[(TIES ? 1 : 0) * (RI / 2) + h] = gt1[h];
+                    park[(TIES ? 2 : 0) * (RI / 2) + h] = gt2[h]; park[(TIES ? 3 : 0) * (RI / 2) + h] = gt3[h];
+                }
+            }
+        }
+    } else {
+        gt0 = 0; gt1 = 0; gt2 = 0; gt3 = 0;
+#pragma unroll
+        for (int h = 0; h < (TIES ? RJ * (RI / 2) : 1); ++h) park[h] = 0;
     }
     if (a.stamps) t_emit = __builtin_amdgcn_s_memrealtime();
     const int g = side ? a.gt : a.gc;
@@ -486,7 +492,10 @@ __global__ __launch_bounds__(64, 3) void k1w_pairs(K1Args a)
     for (int r = 0; r < RJ; ++r) {
         const u32x16 cur = gt0;
         u32x16 cge = 0;
-        if (TIES) cge = ge[r];
+        if (TIES) {
+#pragma unroll
+            for (int h = 0; h < RI / 2; ++h) cge[h] = park[r * (RI / 2) + h];  // (dynamic r: the array stays in memory)
+        }
         emit_gene<RI>(a, i0, jl + 64 * r, bi, lane, side ? 2 : 0, m, n - m, [&](int ii) {
             const uint32_t w = cur[ii >> 1];
             int nre = static_cast<int>((ii & 1) ? (w >> 16) : (w & 0xFFFFu));
