@@ -124,8 +124,8 @@ static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64
     int32_t rc = use(c);
     if (rc) return rc;
     if (!X) { set_error("matrix pointer is null"); return REO_EINVAL; }
-    if (G < 2 || G > 65535 || S < 2 || S > (1 << 20)) {
-        set_error("matrix is %lld x %lld; G must be in [2, 65535] (16-bit positions) and S in [2, 1048576]", (long long)G, (long long)S);
+    if (G < 2 || G > kMaxGenes || S < 2 || S > (1 << 20) || (G > 65535 && S > 65535)) {
+        set_error("matrix is %lld x %lld; G must be in [2, %d] and S in [2, 1048576] (S <= 65535 when G > 65535)", (long long)G, (long long)S, kMaxGenes);
         return REO_EINVAL;
     }
     if (ld < G) { set_error("leading dimension %lld < G = %lld", (long long)ld, (long long)G); return REO_EINVAL; }
@@ -170,10 +170,10 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
     if ((rc = c->raw.ensure(G * kRaw)) ||
         (rc = c->delta_list.ensure(2 * static_cast<size_t>(c->Gp))) || (rc = c->cont.ensure(G * 9)) || (rc = c->result.ensure(G * 15)) ||
         (rc = c->sorted_d.ensure((G + 63) / 64 * 64 + (G + 63) / 64)) || (rc = c->sorted_p.ensure(G)) || (rc = c->rank_s.ensure(G)) ||
-        (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(64)) ||
+        (rc = c->rank_a.ensure(G)) || (rc = c->scal.ensure(8)) || (rc = c->blockmin.ensure(std::max<size_t>(64, (G + 1023) / 1024))) ||
         (rc = c->state.ensure(1)) ||
         (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * (kSortChunk + kSortChunk / 32))) ||
-        (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (65536 / 16 + 8))) ||
+        (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (std::max<size_t>(65536, (G + kSortChunk - 1) / kSortChunk * kSortChunk) / 16 + 8))) ||
         (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(2 * kHistParts * ((G + 32767) / 32768 * 32768))) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->clist.ensure(2 * kListStride)) || (rc = c->scal.ensure(64)))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
@@ -324,6 +324,7 @@ void reo_destroy(reo_ctx *c)
     c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
     c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release(); c->k1_items.release();
     c->t_pos16.release(); c->t_lo16.release(); c->t_hi16.release(); c->gcounts.release();
+    c->t_pos32.release(); c->t_lo32.release(); c->t_hi32.release(); c->t_vin32.release(); c->t_vout32.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
@@ -510,6 +511,7 @@ int32_t reo_pair_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t 
     if (rc) return rc;
     if ((rc = ensure_transform(c))) return rc;
     if (c->S > 65535) { set_error("reo_pair_counts returns 16-bit counts: not available with more than 65535 samples"); return REO_EINVAL; }
+    if (c->G > 65535) { set_error("reo_pair_counts reads the 16-plane layout: not available with more than 65535 genes (reo_get_codes is)"); return REO_EINVAL; }
     if (!n_gt || !n_eq || i0 < 0 || j0 < 0 || i1 > c->G || j1 > c->G || i0 >= i1 || j0 >= j1) {
         set_error("bad pair block [%lld,%lld) x [%lld,%lld)", (long long)i0, (long long)i1, (long long)j0, (long long)j1);
         return REO_EINVAL;
@@ -601,7 +603,9 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // the sorting path -- needed for the first pass, whenever the reference set changed by more genes than a tally
     // update takes, and when a quantile window lost its order statistic -- and the light path.  A batch = two
     // sorting passes, or a run of light passes; small problems sort every pass.
-    bool small = G < c->light_min_g || c->light_mode == 0;
+    // (more than 65 535 genes: sorting passes only -- the light passes keep per-workgroup lists and sums for at most 256
+    //  workgroups of 256 genes)
+    bool small = G < c->light_min_g || c->light_mode == 0 || G > 65535;
     c->it_no_light = false;
     int passes = 0, seen_need_full = 1, light_batches = 0, idle_light = 0;  // idle_light: light batches in a row that completed no pass
     while (n_iter > 0) {  // :400

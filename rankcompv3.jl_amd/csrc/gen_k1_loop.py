@@ -36,6 +36,10 @@ class Loop:
     def __init__(self, nb, ties, name, lshl_add=True, opts=()):
         # opts: timing experiments only (tools/k1w_probe.hip) -- never set for the library's loops
         self.nb, self.ties, self.name, self.opts = nb, ties, name, set(opts)
+        # big: more than 16 planes (more than 65 535 genes).  Five pos quads per gene and block, P [nblk][5][Gp]; edge rows
+        # of 8 uint4 (20 words used, plane k in word k: the generator places the registers, no skew needed), A [nblk][Gp][8].
+        self.big = nb > 16
+        assert not (self.big and ties)
         self.rj = 2 if ties else 4
         self.lines = []
         self.lq = []   # outstanding LDS reads, oldest first (tags)
@@ -45,32 +49,53 @@ class Loop:
         self.in_loop = False
         # ---- VGPRs owned by the statement (physical) ----
         self.ACC = 8                       # v[8:71]: four tuples of 16, pinned outputs
-        self.P = 72                        # pos planes: gene r, plane k at P + 16 r + k   (bank = k % 4)
+        self.P = 72                        # pos planes: gene r, plane k at P + PSTR r + k   (bank = k % 4)
         nedge = 2 if ties else 1
-        self.A = [72 + 16 * self.rj + 20 * e for e in range(nedge)]   # row operand words 0..15, +16..19 second copy of quad 3
-        top = 72 + 16 * self.rj + 20 * nedge
-        self.L = top                       # 4 chain registers
-        self.VLDS = top + 4                # LDS byte address of the slot being read
-        self.VA2 = top + 5                 # lane * 16 + 1024 (second half of a DMA'd block)
-        self.vtop = top + 6
-        assert self.vtop <= 168 - 4, self.vtop
-        # bank rule (measured, tools/microbench_bank.hip): a v_bitop3_b32 whose three sources sit in ONE bank issues
-        # at half rate.  pos plane k is in bank k % 4, edge plane k in bank (A + k + 3) % 4: never the same.
-        for a in self.A:
-            assert a % 2 == 0 and (a + 3) % 4 != 0
+        self.PSTR = 20 if self.big else 16
+        self.LQ = 5 if self.big else 4     # pos quads per block in the layout
+        self.ROWB = 128 if self.big else 64  # bytes of one edge row in memory and in LDS
+        self.NDMA = 32 * self.ROWB // 1024   # 1 KiB pieces per block and edge
+        if self.big:
+            top = 72 + self.PSTR * self.rj
+            self.L = top
+            self.VLDS = top + 4
+            self.VA2 = top + 5             # (piece p > 0 of a DMA'd block: lane * 16 + 1024 p at VA2 + p - 1 -- see VAP)
+            self.A = [top + 6]             # 20 words, plane k in word k
+            self.vtop = top + 6 + 20 + 2   # + two more piece offsets
+            self.VAP = [None, self.VA2, self.vtop - 2, self.vtop - 1]
+            assert self.vtop <= 256 - 8, self.vtop
+            for a in self.A:   # pos plane k in bank k % 4, edge plane k in bank (A + k) % 4
+                assert a % 2 == 0 and a % 4 != 0
+        else:
+            self.A = [72 + 16 * self.rj + 20 * e for e in range(nedge)]   # row operand words 0..15, +16..19 second copy of quad 3
+            top = 72 + 16 * self.rj + 20 * nedge
+            self.L = top                       # 4 chain registers
+            self.VLDS = top + 4                # LDS byte address of the slot being read
+            self.VA2 = top + 5                 # lane * 16 + 1024 (second half of a DMA'd block)
+            self.vtop = top + 6
+            self.VAP = [None, self.VA2]
+            assert self.vtop <= 168 - 4, self.vtop
+            # bank rule (measured, tools/microbench_bank.hip): a v_bitop3_b32 whose three sources sit in ONE bank issues
+            # at half rate.  pos plane k is in bank k % 4, edge plane k in bank (A + k + 3) % 4: never the same.
+            for a in self.A:
+                assert a % 2 == 0 and (a + 3) % 4 != 0
         # ---- SGPRs owned by the statement ----
         s = 36
-        self.SB = [s + 2 * q for q in range(4)]; s += 8      # pos quad bases of the next block to load
+        self.SB = [s + 2 * q for q in range(self.LQ)]; s += 2 * self.LQ   # pos quad bases of the next block to load
         self.SA = [s, s + 2][:nedge]; s += 4                 # edge block to DMA next (lo, hi)
         self.S_M0 = s; self.S_REM = s + 1; self.S_LEFT = s + 2; self.S_SLOT = s + 3; self.S_T = s + 4; self.S_T2 = s + 5
         self.S_PS4 = s + 6; s += 7
         self.stop = s
         # planes -> row operand quads
         self.pq = (nb + 3) // 4            # pos quads per gene
-        self.aq = sorted({a_word(k) // 4 for k in range(nb)})
-        self.first_use = {q: min(k for k in range(nb) if a_word(k) // 4 == q) for q in self.aq}
-        self.last_use = {q: max(k for k in range(nb) if a_word(k) // 4 == q) for q in self.aq}
-        self.slot_bytes = 2048 * nedge
+        self.aq = sorted({self.word(k) // 4 for k in range(nb)})
+        self.first_use = {q: min(k for k in range(nb) if self.word(k) // 4 == q) for q in self.aq}
+        self.last_use = {q: max(k for k in range(nb) if self.word(k) // 4 == q) for q in self.aq}
+        self.dbl = None if self.big else 3   # the quad that holds plane 0 AND the last planes: second copy
+        self.slot_bytes = 32 * self.ROWB * nedge
+
+    def word(self, k):
+        return k if self.big else a_word(k)
 
     # ---------------------------------------------------------------- emit helpers
     def e(self, s):
@@ -104,40 +129,39 @@ class Loop:
 
     def areg(self, e, k, row):
         """register of plane k of edge e in row `row`"""
-        w = a_word(k)
-        if w // 4 == 3 and (row & 1):
+        w = self.word(k)
+        if w // 4 == self.dbl and (row & 1):
             return self.A[e] + 16 + (w & 3)
         return self.A[e] + w
 
     def aquad_reg(self, e, q, row):
-        return self.A[e] + 16 if (q == 3 and (row & 1)) else self.A[e] + 4 * q
+        return self.A[e] + 16 if (q == self.dbl and (row & 1)) else self.A[e] + 4 * q
 
     def read_row_quad(self, row, q):
         """request quad q of the row operand(s) of row `row` (row 32 = row 0 of the next block, other slot)"""
         for e in range(len(self.A)):
-            self.lds_read(("a", row & 1 if q == 3 else 0, e, q), self.aquad_reg(e, q, row), 2048 * e + (row % RI) * 64 + q * 16)
+            self.lds_read(("a", row & 1 if q == self.dbl else 0, e, q), self.aquad_reg(e, q, row),
+                          32 * self.ROWB * e + (row % RI) * self.ROWB + q * 16)
 
     def need_row_quad(self, row, q):
-        self.lds_need([("a", row & 1 if q == 3 else 0, e, q) for e in range(len(self.A))])
+        self.lds_need([("a", row & 1 if q == self.dbl else 0, e, q) for e in range(len(self.A))])
 
     def need_row_quads(self, row, qs):
-        self.lds_need([("a", row & 1 if q == 3 else 0, e, q) for q in qs if q in self.aq for e in range(len(self.A))])
+        self.lds_need([("a", row & 1 if q == self.dbl else 0, e, q) for q in qs if q in self.aq for e in range(len(self.A))])
 
     def dma_block(self):
         """LDS-DMA of the next edge block(s) into the slot s_slot, then advance (clamped at the last block)"""
         for e in range(len(self.A)):
             sa = self.SA[e]
-            if e == 0:
-                self.e(f"s_mov_b32 m0, s{self.S_SLOT}")
-            else:
-                self.e(f"s_add_u32 m0, s{self.S_SLOT}, {2048 * e}")
-            self.e("s_nop 0")
-            self.e(f"global_load_lds_dwordx4 %[aoff], s[{sa}:{sa + 1}]")
-            self.vq.append(("dma", e, 0))
-            self.e(f"s_add_u32 m0, s{self.S_SLOT}, {2048 * e + 1024}")
-            self.e("s_nop 0")
-            self.e(f"global_load_lds_dwordx4 v{self.VA2}, s[{sa}:{sa + 1}]")
-            self.vq.append(("dma", e, 1))
+            for piece in range(self.NDMA):   # 1 KiB each: lane * 16 + 1024 piece, to the same offset of the slot
+                off = 32 * self.ROWB * e + 1024 * piece
+                if off == 0:
+                    self.e(f"s_mov_b32 m0, s{self.S_SLOT}")
+                else:
+                    self.e(f"s_add_u32 m0, s{self.S_SLOT}, {off}")
+                self.e("s_nop 0")
+                self.e(f"global_load_lds_dwordx4 {'%[aoff]' if piece == 0 else 'v' + str(self.VAP[piece])}, s[{sa}:{sa + 1}]")
+                self.vq.append(("dma", e, piece))
         # advance the source by one block unless it is the last one; toggle the slot
         self.e(f"s_cmp_gt_u32 s{self.S_LEFT}, 1")
         self.e(f"s_cselect_b32 s{self.S_T}, %[astride], 0")
@@ -153,7 +177,7 @@ class Loop:
         n = min(4, self.nb - 4 * q)
         op = {4: "global_load_dwordx4", 3: "global_load_dwordx3", 2: "global_load_dwordx2", 1: "global_load_dword"}[n]
         for r in range(self.rj):
-            d = self.P + 16 * r + 4 * q
+            d = self.P + self.PSTR * r + 4 * q
             dst = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
             if "noreload" in self.opts and self.in_loop:
                 self.vq.append(("p", q, r))
@@ -173,7 +197,7 @@ class Loop:
         else:
             ch = [(r, 0) for r in range(4)]
         for c, (r, e) in enumerate(ch):
-            p = self.P + 16 * r + k
+            p = self.P + self.PSTR * r + k
             a = self.areg(e, k, row)
             l = self.L + c
             if k == 0:
@@ -215,8 +239,8 @@ class Loop:
             self.vm_need([t for t in self.vq if t[0] == "dma"])
             self.e(f"v_xor_b32 v{self.VLDS}, {self.slot_bytes}, v{self.VLDS}")
         for k in range(nb):
-            q = a_word(k) // 4
-            if "wait4" in self.opts:
+            q = self.word(k) // 4
+            if "wait4" in self.opts or self.big:
                 if k == self.first_use[q] or (q == 3 and k == 0):
                     self.need_row_quad(i, q)
             elif k == 0:        # two waits per row (an s_waitcnt costs the wave an issue slot even when it has nothing to
@@ -227,9 +251,9 @@ class Loop:
                 self.vm_need([("p", k // 4, r) for r in range(self.rj)])
             self.chains(k, i)
             # requests for the next row, as the registers of this row become free
-            if k == 0 and 3 in self.aq:
-                self.read_row_quad(nxt, 3)      # (second copy of quad 3: free since row i - 1)
-            if q != 3 and k == self.last_use[q]:
+            if self.dbl is not None and k == 0 and self.dbl in self.aq:
+                self.read_row_quad(nxt, self.dbl)      # (second copy of that quad: free since row i - 1)
+            if q != self.dbl and k == self.last_use[q]:
                 self.read_row_quad(nxt, q)
             if last and (k % 4 == 3 or k == nb - 1):
                 lab = self.skip_if_last()
@@ -247,7 +271,10 @@ class Loop:
             else:
                 e(f"s_add_u32 s{self.SB[q]}, s{self.SB[q - 1]}, %[pstride]")
                 e(f"s_addc_u32 s{self.SB[q] + 1}, s{self.SB[q - 1] + 1}, 0")
-        e(f"s_lshl_b32 s{self.S_PS4}, %[pstride], 2")
+        if self.LQ == 4:
+            e(f"s_lshl_b32 s{self.S_PS4}, %[pstride], 2")
+        else:
+            e(f"s_mul_i32 s{self.S_PS4}, %[pstride], {self.LQ}")
         e(f"s_mov_b64 s[{self.SA[0]}:{self.SA[0] + 1}], %[albase]")
         if nedge > 1:
             e(f"s_mov_b64 s[{self.SA[1]}:{self.SA[1] + 1}], %[ahbase]")
@@ -255,7 +282,8 @@ class Loop:
         e(f"s_mov_b32 s{self.S_LEFT}, %[nblk]")
         e(f"s_mov_b32 s{self.S_SLOT}, %[ldsbase]")
         e(f"v_mov_b32 v{self.VLDS}, %[ldsbase]")
-        e(f"v_add_u32 v{self.VA2}, 1024, %[aoff]")
+        for piece in range(1, self.NDMA):
+            e(f"v_add_u32 v{self.VAP[piece]}, {1024 * piece}, %[aoff]")
         for r in range(64):
             e(f"v_mov_b32 v{self.ACC + r}, 0")
         self.dma_block()
@@ -264,8 +292,8 @@ class Loop:
         self.advance_pos()
         self.dma_block()
         # first row operand: block 0 has to be in LDS
-        self.vm_need([t for t in self.vq if t[0] == "dma"][:2 * nedge])
-        for q in ([3] if 3 in self.aq else []) + [q for q in self.aq if q != 3]:
+        self.vm_need([t for t in self.vq if t[0] == "dma"][:self.NDMA * nedge])
+        for q in ([self.dbl] if self.dbl in self.aq else []) + [q for q in self.aq if q != self.dbl]:
             self.read_row_quad(0, q)
         top_l, top_v = list(self.lq), list(self.vq)
         self.in_loop = True
@@ -289,7 +317,7 @@ class Loop:
     def cxx(self):
         nedge = len(self.A)
         out = []
-        out.append(f"// {self.name}: NB = {self.nb}, {'with ties (RJ = 2, edges lo and hi)' if self.ties else 'tie-free (RJ = 4)'};"
+        out.append(f"// {self.name}: NB = {self.nb}, {'with ties (RJ = 2, edges lo and hi)' if self.ties else ('more than 65 535 genes: five pos quads, 128-byte edge rows' if self.big else 'one edge per pass (RJ = 4)')};"
                    f" {len(self.lines)} instructions, VGPRs v8..v{self.vtop - 1}")
         out.append(f"__device__ __forceinline__ void {self.name}(u32x16 &acc0, u32x16 &acc1, u32x16 &acc2, u32x16 &acc3,")
         out.append("    const void *pbase, uint32_t pstride, const void *albase, const void *ahbase, uint32_t astride, uint32_t nblk,")
@@ -311,7 +339,7 @@ class Loop:
         return "\n".join(out)
 
 
-VARIANTS = [(12, False), (15, False), (16, False)]   # (tie-rich data: two passes of the same loop, edges lo then hi)
+VARIANTS = [(12, False), (15, False), (16, False), (17, False), (18, False)]   # (tie-rich data: two passes of the same loop, edges hi then lo)
 
 
 def main():

@@ -437,18 +437,24 @@ __device__ __forceinline__ void k1_loop(u32x16 &c0, u32x16 &c1, u32x16 &c2, u32x
 {
     if (NB == 12) k1_loop_nb12_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
     else if (NB == 15) k1_loop_nb15_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
-    else k1_loop_nb16_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+    else if (NB == 16) k1_loop_nb16_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+    else if (NB == 17) k1_loop_nb17_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);   // (more than 65 535 genes:
+    else k1_loop_nb18_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);                 //  the big plane layout)
 }
 
 // Tie-rich data (two band edges per pair): the SAME loop runs twice per item, against the lo planes (n_gt) and then
 // against the hi planes (n_ge); the first pass's 64 count registers wait in the wave's private segment (16 stores and
 // loads per item).  Two chains per pair inside one loop would halve the genes per lane, i.e. double the LDS reads per
 // bit op -- the round-2 form, whose LDS pipe was busy 45 % of the cycles.
+// More than 65 535 genes (NB = 17, 18): the big plane layout of transform.hip (five pos quads per gene and block, edge
+// rows of 8 uint4), 180 registers, two waves per SIMD.
 template <int NB, bool TIES>
-__global__ __launch_bounds__(64, 3) void k1w_pairs(K1Args a)
+__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
 {
     constexpr int RI = kTileI, RJ = kRJ, NE = TIES ? 2 : 1;
-    __shared__ uint4 ring[256];  // two slots of one block's tile operand: 2 x 2 KB
+    constexpr bool BIG = NB > 16;
+    constexpr int LQ = BIG ? 5 : 4, ROWB = BIG ? 128 : 64;  // pos quads per block; bytes of an edge row
+    __shared__ uint4 ring[2 * RI * ROWB / 16];  // two slots of one block's tile operand: 2 x 2 KB (4 KB)
     const unsigned long long t_begin = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     const uint32_t item = a.items[blockIdx.x];  // side << 31 | wave chunk << 16 | i-tile
     const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(item & 0xFFFFu) * RI);
@@ -461,14 +467,14 @@ __global__ __launch_bounds__(64, 3) void k1w_pairs(K1Args a)
     unsigned long long t_loop = 0, t_emit = 0;
     if (a.stamps) t_loop = __builtin_amdgcn_s_memrealtime();
     if (be > bb) {
-        const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * 4 * a.Gp * 16;
-        const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * 64;
+        const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * LQ * a.Gp * 16;
+        const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * ROWB;
         const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
         // ONE copy of the loop's code for both passes; nothing but the parked counts (memory) lives across the second pass
 #pragma clang loop unroll(disable)
         for (int e = 0; e < NE; ++e) {
             const char *ab = reinterpret_cast<const char *>(e ? a.AL : (TIES ? a.AH : a.AL)) + aoff;  // ties: hi first, lo last
-            k1_loop<NB>(gt0, gt1, gt2, gt3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * 64u,
+            k1_loop<NB>(gt0, gt1, gt2, gt3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * static_cast<uint32_t>(ROWB),
                         static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
             if (TIES && e == 0) {
 #pragma unroll
@@ -1286,7 +1292,7 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(IterArgs a, int n
     const int G = a.G;
     const double *cv = a.chunk_v;
     __shared__ double slice[kMergeThreads / kMergeLanes];
-    __shared__ double spl[(65536 / kSortChunk) * kSplit];  // [chunk][kSplit]: 2048 splitters at most (G <= 65535)
+    extern __shared__ double spl[];  // [chunk][kSplit]: 32 splitters per chunk (dynamic: 16 KB at 65 535 genes, 64 KB at 262 143)
     for (int t = threadIdx.x; t < nchunk * kSplit; t += kMergeThreads) spl[t] = a.chunk_spl[t];  // = cv[chunk][32 m], packed
     __syncthreads();
     const int e = blockIdx.x * (kMergeThreads / kMergeLanes) + threadIdx.x / kMergeLanes;  // element (position in the chunked array)
@@ -1378,7 +1384,7 @@ __global__ __launch_bounds__(256) void k3_abs_rank(IterArgs a, int npart)
     const int G = a.G;
     const double *sorted_d = a.sorted_d;
     __shared__ double red[256];
-    __shared__ double spl[1024];  // every 64th element of the sorted vector (G <= 65535)
+    extern __shared__ double spl[];  // every 64th element of the sorted vector (dynamic: 8 KB at 65 535 genes, 32 KB at 262 143)
     const int nspl = (G + 63) >> 6;
     for (int t = threadIdx.x; t < nspl; t += 256) spl[t] = a.sorted_spl[t];  // = sorted_d[64 t], packed
     double n, mean, m2;
@@ -1502,15 +1508,16 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
     int t, nref;
     if (!full_pass_active(a, t, nref)) return;
     const int G = a.G;
-    __shared__ double tail[65];
+    constexpr int kMaxBlocks = (kMaxGenes + 1023) / 1024;
+    __shared__ double tail[kMaxBlocks + 1];
     const int nb = (G + 1023) / 1024;
-    __shared__ double bm[64];
-    if (static_cast<int>(threadIdx.x) < nb) bm[threadIdx.x] = a.blockmin[threadIdx.x];
+    __shared__ double bm[kMaxBlocks];
+    for (int b = threadIdx.x; b < nb; b += 256) bm[b] = a.blockmin[b];
     __syncthreads();
-    if (static_cast<int>(threadIdx.x) <= nb) {  // tail[b] = minimum over the blocks after b (one thread per b)
+    for (int b = threadIdx.x; b <= nb; b += 256) {  // tail[b] = minimum over the blocks after b
         double run = INFINITY;
-        for (int k = threadIdx.x + 1; k < nb; ++k) { const double m = bm[k]; run = m < run ? m : run; }
-        tail[threadIdx.x] = run;
+        for (int k = b + 1; k < nb; ++k) { const double m = bm[k]; run = m < run ? m : run; }
+        tail[b] = run;
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -2593,7 +2600,17 @@ __global__ __launch_bounds__(256) void x_expand_mirror(XArgs a, const uint32_t *
 // ------------------------------------------------------------------ launchers
 
 // bits needed for every number the pair kernel compares: positions 0..G-1 and band ends up to G
-static int plane_bits(int64_t G) { return G <= 4095 ? 12 : (G <= 32767 ? 15 : 16); }
+static int plane_bits(int64_t G) { return G <= 4095 ? 12 : (G <= 32767 ? 15 : (G <= 65535 ? 16 : (G <= 131071 ? 17 : 18))); }
+
+// the wave form with more than 16 planes (more than 65 535 genes): two groups, at most 65 535 samples only
+template <int NB>
+static void launch_big_pairs(reo_ctx *c, const K1Args &a)
+{
+    const unsigned gridw = static_cast<unsigned>(c->k1_items_n);
+    if (gridw == 0) return;
+    if (c->has_ties) k1w_pairs<NB, true><<<gridw, 64, 0, c->stream>>>(a);
+    else k1w_pairs<NB, false><<<gridw, 64, 0, c->stream>>>(a);
+}
 
 template <int NB>
 static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool shared, bool multi, size_t plane_elems, bool wide)
@@ -2646,7 +2663,12 @@ int32_t launch_k1(reo_ctx *c, int k)
     // work units: panel p = Q consecutive j-chunks, cut into i-ranges of kUnitH tiles.  Q keeps the
     // panel's pos planes (Q x 256 RJ genes x nblk blocks x 64 B) within about 2 MiB of the 4 MiB L2 of an XCD.
     const bool wide = c->S > 65535;  // a count may not fit 16 bits: the unpacked form of the pair loop
-    const bool wave = c->k1_wave && !multi && !wide;  // the wave form (two groups): kRJ genes per lane for both families
+    const bool big = c->G > 65535;    // more than 16 position planes: only the wave form has a loop for them
+    if (big && (multi || wide)) {
+        set_error("more than 65535 genes: two groups and at most 65535 samples only (the one-vs-rest and the wide pair kernels read the 16-plane layout)");
+        return REO_EINVAL;
+    }
+    const bool wave = (c->k1_wave || big) && !multi && !wide;  // the wave form (two groups): kRJ genes per lane for both families
     const int RJ = wave ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));  // genes j per lane
     const int CJ = kTileJ * RJ;
     const int NJ = (c->Gp + CJ - 1) / CJ, NIT = c->Gp / kTileI;
@@ -2763,7 +2785,9 @@ int32_t launch_k1(reo_ctx *c, int k)
     switch (plane_bits(c->G)) {
     case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems, wide); break;
     case 15: launch_pair_kernels<15>(c, a, grid, shared, multi, plane_elems, wide); break;
-    default: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems, wide); break;
+    case 16: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems, wide); break;
+    case 17: launch_big_pairs<17>(c, a); break;   // (reo_set_groups / set_matrix admit such gene counts only where the wave form runs)
+    default: launch_big_pairs<18>(c, a); break;
     }
     toc(c);
     REO_HIP_CHECK(hipGetLastError());
@@ -2932,8 +2956,10 @@ int32_t launch_full_pass(reo_ctx *c, bool replay)
     }
     k3_derive<<<nb, 256, 0, c->stream>>>(a);
     k3_sort_chunks<<<nchunk, kSortChunk, 0, c->stream>>>(a);
-    k3_merge_rank<<<nmerge, kMergeThreads, 0, c->stream>>>(a, nchunk);
-    k3_abs_rank<<<nb, 256, 0, c->stream>>>(a, nmerge);
+    if (nchunk > 64)  // (more than 65 535 genes: the splitter table passes the 64 KB a launch gets by default)
+        REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k3_merge_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    k3_merge_rank<<<nmerge, kMergeThreads, static_cast<size_t>(nchunk) * kSplit * sizeof(double), c->stream>>>(a, nchunk);
+    k3_abs_rank<<<nb, 256, static_cast<size_t>((G + 63) / 64) * sizeof(double), c->stream>>>(a, nmerge);
     k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(a);
     k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(a);
     REO_HIP_CHECK(hipGetLastError());

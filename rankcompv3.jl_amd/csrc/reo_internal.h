@@ -18,6 +18,7 @@ constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kUnitH = 32;    // i-tiles per K1 work unit
 constexpr int kRJ = 4;        // genes j per lane in the tie-free pair kernel
 constexpr int kRJTies = 2;    // genes j per lane in the tie-rich pair kernel (two band edges per pair)
+constexpr int kMaxGenes = 262143;  // 18 position planes; above 65 535 genes: two groups, at most 65 535 samples, sorting passes only
 constexpr int kGenePad = 1024;  // Gp is a multiple of this (= kTileJ * kRJ: every lane's genes exist)
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
 constexpr int kDeltaMax = 128;   // at most this many changed reference genes: update the tallies incrementally
@@ -154,6 +155,8 @@ struct reo_ctx {
     reo::DevBuf<uint4> lo;      // [nblk][Gp][4]  16 plane words of the first position of the tie band (plane k in word (k+15)%16)
     reo::DevBuf<uint4> hi;      // [nblk][Gp][4]  the same for one past the last position of the tie band
     reo::DevBuf<uint16_t> t_pos16, t_lo16, t_hi16;  // [S32][Gp] the three numbers before slicing (scratch)
+    reo::DevBuf<uint32_t> t_pos32, t_lo32, t_hi32;  // the same for more than 65 535 genes (32-bit positions; transform.hip, t_slice_big)
+    reo::DevBuf<uint32_t> t_vin32, t_vout32;        // gene indices of the segmented sort, 32-bit
     reo::DevBuf<int32_t> goff_dev;  // group offsets in blocks
     // transform scratch (grow-only, freed with the context)
     reo::DevBuf<uint64_t> t_kin, t_kout;

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <type_traits>
 
 #include "reo_internal.h"
 
@@ -59,10 +60,10 @@ struct Codec<int64_t> {
     __device__ static bool finite(int64_t) { return true; }
 };
 
-template <class T>
+template <class T, class IdxT>
 __global__ __launch_bounds__(256) void t_keys(const T *__restrict__ X, int64_t ld,
                                               const int32_t *__restrict__ colmap, int G, int cb0,
-                                              uint64_t *__restrict__ keys, uint16_t *__restrict__ idx,
+                                              uint64_t *__restrict__ keys, IdxT *__restrict__ idx,
                                               int32_t *__restrict__ bad, unsigned long long *__restrict__ varbits)
 {
     int g = blockIdx.x * 256 + threadIdx.x;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void t_keys(const T *__restrict__ X, int64_t l
         size_t o = static_cast<size_t>(c) * G + g;
         const uint64_t k = Codec<T>::enc(x);
         keys[o] = k;
-        idx[o] = static_cast<uint16_t>(g);
+        idx[o] = static_cast<IdxT>(g);
         diff = k ^ Codec<T>::enc(X[0]);  // bits in which any key differs from one fixed key
     }
     // only the key bits that vary anywhere need sorting: OR-reduce them (wave, then one atomic per wave)
@@ -85,12 +86,12 @@ __global__ __launch_bounds__(256) void t_keys(const T *__restrict__ X, int64_t l
         atomicOr(varbits, diff);
 }
 
-template <class T>
+template <class T, class IdxT>   // IdxT: uint16_t up to 65 535 genes, uint32_t above (positions and gene indices alike)
 __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys,
-                                               const uint16_t *__restrict__ idx, int G, int Gp, int cb0,
+                                               const IdxT *__restrict__ idx, int G, int Gp, int cb0,
                                                const int32_t *__restrict__ slots,
-                                               uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
-                                               uint16_t *__restrict__ hi, int32_t *__restrict__ anytie)
+                                               IdxT *__restrict__ pos, IdxT *__restrict__ lo,
+                                               IdxT *__restrict__ hi, int32_t *__restrict__ anytie)
 {
     int p = blockIdx.x * 256 + threadIdx.x;
     int c = blockIdx.y;
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
     int g = idx[static_cast<size_t>(c) * G + p];
     const int slot = slots[cb0 + c];  // sample slot in the group-padded order
     const size_t o = static_cast<size_t>(slot) * Gp + g;
-    pos[o] = static_cast<uint16_t>(p);
-    lo[o] = static_cast<uint16_t>(l);
-    hi[o] = static_cast<uint16_t>(h + 1);
+    pos[o] = static_cast<IdxT>(p);
+    lo[o] = static_cast<IdxT>(l);
+    hi[o] = static_cast<IdxT>(h + 1);
 }
 
 // One workgroup per sample, everything in LDS: when the varying key bits fit 31 bits and the genes fit
@@ -378,6 +379,48 @@ __global__ __launch_bounds__(256) void t_slice(const uint16_t *__restrict__ pos,
     skewed(AH);
 }
 
+// More than 65 535 genes: 32-bit rows -> the BIG plane layout (up to 20 planes).  One thread per gene and block: its 32
+// numbers of a row are a 32 x 32 bit matrix, transposed in registers; plane k of every number is word k.
+//   P  [nblk][5][Gp] uint4 : planes 4q..4q+3 of pos of gene g in block b at (b * 5 + q) * Gp + g
+//   AL [nblk][Gp][8] uint4 : the plane words of lo of gene g in block b at (b * Gp + g) * 8 .. (words 0..19 used, plane k in
+//                            word k; rows of 128 bytes so that a tile's 32 rows are four 1-KiB LDS-DMA pieces)
+//   AH likewise for hi.  (The count loop's generator places the registers itself: no word skew is needed here.)
+__global__ __launch_bounds__(256) void t_slice_big(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ lo,
+                                                   const uint32_t *__restrict__ hi, int Gp, uint4 *__restrict__ P,
+                                                   uint4 *__restrict__ AL, uint4 *__restrict__ AH)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (g >= Gp) return;
+    uint32_t w[32];
+    auto planes = [&](const uint32_t *__restrict__ src) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) w[s] = src[(static_cast<size_t>(b) * 32 + s) * Gp + g];
+        uint32_t m = 0x0000FFFFu;
+#pragma unroll
+        for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
+#pragma unroll
+            for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+                const uint32_t t = ((w[k] >> j) ^ w[k + j]) & m;
+                w[k] ^= t << j;
+                w[k + j] ^= t;
+            }
+        }
+        // now w[k] = plane k of gene g (bit s = sample s)
+    };
+    planes(pos);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) P[(static_cast<size_t>(b) * 5 + q) * Gp + g] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+    auto rows = [&](uint4 *__restrict__ dst) {
+        uint4 *o = dst + (static_cast<size_t>(b) * Gp + g) * 8;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) o[q] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+    };
+    planes(lo);
+    rows(AL);
+    planes(hi);
+    rows(AH);
+}
+
 template <class T, int IPT>
 int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
 {
@@ -435,18 +478,32 @@ int32_t transform_impl(reo_ctx *c)
     REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff_blocks.data(), sizeof(int32_t) * (c->ngroups + 1),
                                  hipMemcpyHostToDevice, st));
 
-    const size_t n = static_cast<size_t>(S32) * Gp;            // 16-bit numbers per intermediate row set
+    const bool big = G > 65535;  // 32-bit positions and gene indices, the big plane layout
+    const size_t n = static_cast<size_t>(S32) * Gp;            // numbers per intermediate row set
     const size_t nq = static_cast<size_t>(nblk) * Gp * 4;      // uint4 per plane set
-    if ((rc = c->t_pos16.ensure(n)) || (rc = c->t_lo16.ensure(n)) || (rc = c->t_hi16.ensure(n)) ||
-        (rc = c->pos.ensure(nq)) || (rc = c->lo.ensure(nq)) || (rc = c->hi.ensure(nq)))
-        return rc;
-    // rows of padding slots and (segmented path) padded genes: below no band edge
-    REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));
-    REO_HIP_CHECK(hipMemsetAsync(c->t_lo16.p, 0, n * sizeof(uint16_t), st));
-    REO_HIP_CHECK(hipMemsetAsync(c->t_hi16.p, 0, n * sizeof(uint16_t), st));
+    if (!big) {
+        if ((rc = c->t_pos16.ensure(n)) || (rc = c->t_lo16.ensure(n)) || (rc = c->t_hi16.ensure(n)) ||
+            (rc = c->pos.ensure(nq)) || (rc = c->lo.ensure(nq)) || (rc = c->hi.ensure(nq)))
+            return rc;
+        // rows of padding slots and (segmented path) padded genes: below no band edge
+        REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_lo16.p, 0, n * sizeof(uint16_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_hi16.p, 0, n * sizeof(uint16_t), st));
+    } else {
+        if ((rc = c->t_pos32.ensure(n)) || (rc = c->t_lo32.ensure(n)) || (rc = c->t_hi32.ensure(n)) ||
+            (rc = c->pos.ensure(static_cast<size_t>(nblk) * Gp * 5)) || (rc = c->lo.ensure(static_cast<size_t>(nblk) * Gp * 8)) ||
+            (rc = c->hi.ensure(static_cast<size_t>(nblk) * Gp * 8)))
+            return rc;
+        REO_HIP_CHECK(hipMemsetAsync(c->t_pos32.p, 0, n * sizeof(uint32_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_lo32.p, 0, n * sizeof(uint32_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_hi32.p, 0, n * sizeof(uint32_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->lo.p, 0, static_cast<size_t>(nblk) * Gp * 8 * sizeof(uint4), st));  // (words 20..31 of a row are never written)
+        REO_HIP_CHECK(hipMemsetAsync(c->hi.p, 0, static_cast<size_t>(nblk) * Gp * 8 * sizeof(uint4), st));
+    }
     const T *X = static_cast<const T *>(c->dX);
     auto finish = [&](int has_ties) -> int32_t {
-        t_slice<<<dim3(Gp / 512, nblk), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p);
+        if (big) t_slice_big<<<dim3(Gp / 256, nblk), 256, 0, st>>>(c->t_pos32.p, c->t_lo32.p, c->t_hi32.p, Gp, c->pos.p, c->lo.p, c->hi.p);
+        else t_slice<<<dim3(Gp / 512, nblk), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p);
         REO_HIP_CHECK(hipGetLastError());
         c->has_ties = has_ties;
         c->transformed = true;
@@ -484,40 +541,44 @@ int32_t transform_impl(reo_ctx *c)
     // column batches: rocprim takes a 32-bit element count
     const int CB = std::max(1, std::min(std::min(S, 65535), static_cast<int>((1u << 27) / static_cast<unsigned>(G))));  // (grid y <= 65535)
     DevBuf<uint64_t> &k_in = c->t_kin, &k_out = c->t_kout;
-    DevBuf<uint16_t> &v_in = c->t_vin, &v_out = c->t_vout;
     const size_t bn = static_cast<size_t>(CB) * G;
-    if ((rc = k_in.ensure(bn)) || (rc = k_out.ensure(bn)) || (rc = v_in.ensure(bn)) || (rc = v_out.ensure(bn)))
-        return rc;
-
+    if ((rc = k_in.ensure(bn)) || (rc = k_out.ensure(bn))) return rc;
     auto seg_begin = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned>(0),
                                                       SegOff{static_cast<unsigned>(G)});
-    size_t temp_bytes = 0;
-    REO_HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, k_in.p, k_out.p, v_in.p, v_out.p,
-                                                      static_cast<unsigned>(bn), static_cast<unsigned>(CB),
-                                                      seg_begin, seg_begin + 1, 0, 64, st));
-    DevBuf<unsigned char> &temp = c->t_temp;
-    if ((rc = temp.ensure(std::max<size_t>(temp_bytes, 16)))) return rc;
-
-    for (int cb0 = 0; cb0 < S; cb0 += CB) {
-        const int nc = std::min(CB, S - cb0);
-        dim3 grid((G + 255) / 256, nc);
-        REO_HIP_CHECK(hipMemsetAsync(d_varbits, 0, sizeof(unsigned long long), st));
-        t_keys<T><<<grid, 256, 0, st>>>(X, c->ld, d_order.p, G, cb0, k_in.p, v_in.p, d_flags.p, d_varbits);
-        // radix-sort only the bit range in which the keys of this batch differ at all (rank-like data: 15 bits)
-        unsigned long long vb = 0;
-        REO_HIP_CHECK(hipMemcpyAsync(&vb, d_varbits, sizeof vb, hipMemcpyDeviceToHost, st));
-        REO_HIP_CHECK(hipStreamSynchronize(st));
-        unsigned begin_bit = 0, end_bit = 64;
-        if (vb == 0) { begin_bit = 0; end_bit = 1; }
-        else { begin_bit = static_cast<unsigned>(__builtin_ctzll(vb)); end_bit = 64u - static_cast<unsigned>(__builtin_clzll(vb)); }
-        size_t tb = temp_bytes;
-        REO_HIP_CHECK(rocprim::segmented_radix_sort_pairs(temp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p,
-                                                          static_cast<unsigned>(static_cast<size_t>(nc) * G),
-                                                          static_cast<unsigned>(nc), seg_begin, seg_begin + 1,
-                                                          begin_bit, end_bit, st));
-        t_bands<T><<<grid, 256, 0, st>>>(k_out.p, v_out.p, G, Gp, cb0, c->t_slots.p, c->t_pos16.p, c->t_lo16.p, c->t_hi16.p,
-                                         d_flags.p + 1);
-    }
+    auto segmented = [&](auto &v_in, auto &v_out, auto *pos, auto *lo, auto *hi) -> int32_t {
+        using IdxT = std::remove_pointer_t<decltype(pos)>;
+        int32_t rc2;
+        if ((rc2 = v_in.ensure(bn)) || (rc2 = v_out.ensure(bn))) return rc2;
+        size_t temp_bytes = 0;
+        REO_HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, k_in.p, k_out.p, v_in.p, v_out.p,
+                                                          static_cast<unsigned>(bn), static_cast<unsigned>(CB),
+                                                          seg_begin, seg_begin + 1, 0, 64, st));
+        DevBuf<unsigned char> &temp = c->t_temp;
+        if ((rc2 = temp.ensure(std::max<size_t>(temp_bytes, 16)))) return rc2;
+        for (int cb0 = 0; cb0 < S; cb0 += CB) {
+            const int nc = std::min(CB, S - cb0);
+            dim3 grid((G + 255) / 256, nc);
+            REO_HIP_CHECK(hipMemsetAsync(d_varbits, 0, sizeof(unsigned long long), st));
+            t_keys<T, IdxT><<<grid, 256, 0, st>>>(X, c->ld, d_order.p, G, cb0, k_in.p, v_in.p, d_flags.p, d_varbits);
+            // radix-sort only the bit range in which the keys of this batch differ at all (rank-like data: 15 bits)
+            unsigned long long vb = 0;
+            REO_HIP_CHECK(hipMemcpyAsync(&vb, d_varbits, sizeof vb, hipMemcpyDeviceToHost, st));
+            REO_HIP_CHECK(hipStreamSynchronize(st));
+            unsigned begin_bit = 0, end_bit = 64;
+            if (vb == 0) { begin_bit = 0; end_bit = 1; }
+            else { begin_bit = static_cast<unsigned>(__builtin_ctzll(vb)); end_bit = 64u - static_cast<unsigned>(__builtin_clzll(vb)); }
+            size_t tb = temp_bytes;
+            REO_HIP_CHECK(rocprim::segmented_radix_sort_pairs(temp.p, tb, k_in.p, k_out.p, v_in.p, v_out.p,
+                                                              static_cast<unsigned>(static_cast<size_t>(nc) * G),
+                                                              static_cast<unsigned>(nc), seg_begin, seg_begin + 1,
+                                                              begin_bit, end_bit, st));
+            t_bands<T, IdxT><<<grid, 256, 0, st>>>(k_out.p, v_out.p, G, Gp, cb0, c->t_slots.p, pos, lo, hi, d_flags.p + 1);
+        }
+        return REO_OK;
+    };
+    if (big) rc = segmented(c->t_vin32, c->t_vout32, c->t_pos32.p, c->t_lo32.p, c->t_hi32.p);
+    else rc = segmented(c->t_vin, c->t_vout, c->t_pos16.p, c->t_lo16.p, c->t_hi16.p);
+    if (rc) return rc;
     REO_HIP_CHECK(hipGetLastError());
     int32_t flags[2] = {0, 0};
     REO_HIP_CHECK(hipMemcpyAsync(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost, st));

@@ -815,6 +815,53 @@ def test_full_identify_degs_at_65535_genes(pkg, oracle):
     _check_result(run.result, exp)
 
 
+@pytest.mark.parametrize("G,S,family,n_iter", [(70000, 24, "t1", 8), (140000, 16, "t0", 6)])
+def test_more_than_65535_genes(pkg, oracle, G, S, family, n_iter):
+    """Above 65 535 genes positions take 17 or 18 bit planes (round 3): 32-bit transform rows on the segmented path, the
+    big plane layout, the generated count loop for NB = 17 / 18 at two waves per SIMD, the sorting passes with their
+    splitter tables in dynamic LDS (the light passes are not used there).  Sampled blocks of the class table against the
+    oracle's counts -- first / last columns, the diagonal, across the 65 536 boundary, the padded tail -- and the whole
+    run (trace, tallies, statistics) against the oracle."""
+    seed = 0x5EED0065
+    X = (pkg.synth.t1_counts if family == "t1" else pkg.synth.t0_ranks)(G, S, seed)
+    group = np.array(["a", "b"] * (S // 2), dtype=object)      # interleaved groups: the transform re-orders the samples
+    gid, lev = pkg.encode_groups(group)
+    ref0 = pkg.synth.ref_mask(G, 3000, seed)
+    Xf = np.asfortranarray(X.astype(np.float64))
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, 2)
+        thr = ctx.compute_thresholds(0.05)
+        ctx.build_pairs(0)
+        info = ctx.info()
+        assert info["has_ties"] == (1 if family == "t1" else 0) and info["transform_in_lds"] == 0
+        for (i0, j0, n) in [(0, G - 40, 40), (0, 0, 40), (65520, 65520, 48), (65500, 100, 40), (100, 65530, 40), (G - 48, G - 48, 48),
+                            (G - 33, 17, 32), (40000, G - 300, 32)]:
+            exp = _expected_block_codes(oracle, Xf, gid, thr, seed, i0, i0 + n, j0, j0 + n)
+            assert np.array_equal(ctx.get_codes(i0, i0 + n, j0, j0 + n), exp), (i0, j0)
+        cont = ctx.tally(ref0)
+        assert np.array_equal(cont.sum(axis=1), ref0.sum() - ref0.astype(np.int64)) and cont.min() >= 0
+        res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, n_iter, 3)
+        with pytest.raises(pkg.ReoError):
+            ctx.pair_counts(0, 8, 0, 8)                           # the debug hook reads the 16-plane layout
+    exp, eit, etr = oracle.identify_degs(Xf, gid, 2, 0.05, 1.0, 0.05, ref0, n_iter, 3, seed)
+    assert iters == eit and trace == etr, (iters, eit, trace, etr)
+    _check_result(res, exp)
+
+
+def test_gene_count_limits(pkg):
+    """G <= 262 143 (18 position planes); above 65 535 genes only two groups and at most 65 535 samples."""
+    rng = np.random.default_rng(1)
+    with pkg.Context(device=0, seed=1) as ctx:
+        with pytest.raises(pkg.ReoError):
+            ctx.set_matrix(np.zeros((262144, 2), dtype=np.int64))
+        X = rng.integers(0, 1000, size=(66000, 6))
+        ctx.set_matrix(X)
+        ctx.set_groups(np.array([0, 1, 2, 0, 1, 2], dtype=np.int32), 3)
+        ctx.compute_thresholds(0.5)
+        with pytest.raises(pkg.ReoError, match="two groups"):
+            ctx.build_pairs(0)
+
+
 @pytest.mark.parametrize("case", ["two_samples", "one_vs_nine", "empty_ref", "full_ref", "g11", "constant", "one_group_all_ties"])
 def test_edge_cases_against_oracle(pkg, oracle, case):
     rng = np.random.default_rng(zlib.crc32(case.encode()))

@@ -132,3 +132,33 @@ def test_gloo_world2_sharded_iteration_matches_unsharded():
         p.join(timeout=60)
     assert all(g[1] == "ok" for g in got), got
     assert got[0][2] == got[1][2] >= 1
+
+
+def test_mirror_geometry_of_the_three_kernel_forms(pkg):
+    """launch_k1's unit geometry depends on which pair kernel it selects (ADVICE, round 2): the wave form (two groups) uses
+    kRJ genes per lane for both data families, the workgroup form kRJ / kRJTies, the wide form (S > 65535) kRJWide /
+    kRJWideTies.  The mirror's constants against the sources, and the chunk widths that follow."""
+    src = open(os.path.join(ROOT, "rankcompv3.jl_amd", "csrc", "kernels.hip")).read()
+    m = re.search(r"constexpr int kRJWide = (\d+), kRJWideTies = (\d+);", src)
+    sh = pkg.sharding
+    assert (int(m.group(1)), int(m.group(2))) == (sh.RJ_WIDE, sh.RJ_WIDE_TIES)
+    assert "const int RJ = wave ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));" in src
+    for ties in (False, True):
+        assert sh.geometry(5000, 208, ties, "wave")[1] == sh.TILE_J * sh.RJ
+        assert sh.geometry(5000, 208, ties, "wg")[1] == sh.TILE_J * (sh.RJ_TIES if ties else sh.RJ)
+        assert sh.geometry(300, 66112, ties, "wide")[1] == sh.TILE_J * (sh.RJ_WIDE_TIES if ties else sh.RJ_WIDE)
+    assert sh.geometry(5000, 208, True)[1] == sh.geometry(5000, 208, True, "wave")[1]   # the default form
+    # every form still partitions the tiles
+    for form in ("wave", "wg", "wide"):
+        owner = sh.tile_owner(3000, 64, True, 3, form)
+        Gp, CJ, Q = sh.geometry(3000, 64, True, form)
+        it, jc = np.meshgrid(np.arange(owner.shape[0]), np.arange(owner.shape[1]), indexing="ij")
+        assert ((owner == -1) == ((jc * CJ + CJ - 1) // 64 < (it * sh.TILE_I) // 64)).all()
+
+
+def test_generated_count_loops_are_current(pkg):
+    """csrc/k1_loop_gen.inc is committed next to its generator: it must be what gen_k1_loop.py prints."""
+    import subprocess, sys
+    csrc = os.path.join(ROOT, "rankcompv3.jl_amd", "csrc")
+    out = subprocess.run([sys.executable, os.path.join(csrc, "gen_k1_loop.py")], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(csrc, "k1_loop_gen.inc")).read()
