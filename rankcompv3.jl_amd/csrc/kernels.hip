@@ -2956,9 +2956,10 @@ int32_t launch_full_pass(reo_ctx *c, bool replay)
     }
     k3_derive<<<nb, 256, 0, c->stream>>>(a);
     k3_sort_chunks<<<nchunk, kSortChunk, 0, c->stream>>>(a);
-    if (nchunk > 64)  // (more than 65 535 genes: the splitter table passes the 64 KB a launch gets by default)
-        REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k3_merge_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    k3_merge_rank<<<nmerge, kMergeThreads, static_cast<size_t>(nchunk) * kSplit * sizeof(double), c->stream>>>(a, nchunk);
+    const size_t spl_bytes = static_cast<size_t>(nchunk) * kSplit * sizeof(double);
+    if (spl_bytes > (size_t(48) << 10))  // (near the top of the gene range the splitter table passes what a launch gets by default)
+        REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k3_merge_rank), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(spl_bytes)));
+    k3_merge_rank<<<nmerge, kMergeThreads, spl_bytes, c->stream>>>(a, nchunk);
     k3_abs_rank<<<nb, 256, static_cast<size_t>((G + 63) / 64) * sizeof(double), c->stream>>>(a, nmerge);
     k3_bh_local<<<(G + 1023) / 1024, 1024, 0, c->stream>>>(a);
     k3_finalize<<<c->Gp / 256, 256, 0, c->stream>>>(a);
