@@ -606,8 +606,8 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // (more than 65 535 genes: sorting passes only -- the light passes keep per-workgroup lists and sums for at most 256
     //  workgroups of 256 genes)
     bool small = G < c->light_min_g || c->light_mode == 0 || G > 65535;
-    c->it_no_light = false;
-    int passes = 0, seen_need_full = 1, light_batches = 0, idle_light = 0;  // idle_light: light batches in a row that completed no pass
+    c->it_no_light = G > 65535;  // (the device must know as well: a sorting pass that left need_full clear would wait for light passes nobody enqueues)
+    int passes = 0, seen_need_full = 1, light_batches = 0, idle_light = 0, idle_any = 0;  // idle_light: light batches in a row that completed no pass
     while (n_iter > 0) {  // :400
         const int remaining = n_iter - passes;
         // the state read after the last batch says which kind of pass is due: sorting launches are enqueued only then
@@ -635,6 +635,11 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         if (c->host_state->fault) {
             set_error("the persistent iteration kernel gave up at a grid barrier (a workgroup did not arrive within its bound); "
                       "REO_LIGHT=1 runs the same passes as separate launches");
+            return REO_EHIP;
+        }
+        idle_any = c->host_state->passes == passes ? idle_any + 1 : 0;
+        if (idle_any >= 4) {  // no kind of batch completes a pass any more: an error of the loop control, never a reason to spin
+            set_error("the iteration made no progress in four batches of launches (passes %d, need_full %d): loop control fault", passes, c->host_state->need_full);
             return REO_EHIP;
         }
         if (nlight > 0) idle_light = c->host_state->passes == passes ? idle_light + 1 : 0;
