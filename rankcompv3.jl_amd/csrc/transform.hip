@@ -144,6 +144,10 @@ template <> constexpr bool kCountingPath<int64_t> = true;
 constexpr unsigned kCountBits = 15;
 constexpr int kCountPer = (1 << kCountBits) / 1024;  // bins per thread in the prefix sums
 constexpr size_t kCountWords = (size_t(1) << kCountBits) + (size_t(1) << (kCountBits - 5));  // the histogram, skewed by one word in 32
+// the compressed form of the histogram ranking for 16 .. 24 varying key bits (t_sample)
+constexpr unsigned kWideBits = 24, kWideExact = 13;
+constexpr int kWideBins = 1 << 14, kWideScan = 128;   // codes; largest lossy bucket that is still scanned
+constexpr size_t kWideWords = static_cast<size_t>(kWideBins) + (kWideBins >> 5);
 
 template <class T, int IPT>
 __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
@@ -251,6 +255,96 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         }
         if (tied && *anytie == 0) atomicOr(anytie, 1);
         return;
+    }
+    if (kCountingPath<T> && nbits <= kWideBits) {
+        // Integer data with 16 to 24 varying key bits (counts with a long tail): a histogram of a MONOTONE COMPRESSION of
+        // the key -- exact below 2^13, above that octave and the top mb mantissa bits (kWideBins codes in all) -- puts every
+        // gene into a bucket that is ordered against every other bucket; genes whose bucket dropped low bits are scattered
+        // into LDS by bucket and rank themselves inside it by scanning its (few) members.  Count data is dense at small
+        // values, where the code is exact, and sparse in the tail, where a bucket holds a handful of genes; a sample with a
+        // crowded lossy bucket (more than kWideScan members) takes the radix sort below instead.  No sort, no payload.
+        uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+        auto at = [](uint32_t b) { return b + (b >> 5); };
+        uint32_t *wtot = hist + kWideWords;                       // 16 wave totals, then the largest lossy bucket
+        uint16_t *skey = reinterpret_cast<uint16_t *>(wtot + 32);  // [Gp] low bits of the genes of lossy buckets, by slot
+        const unsigned oct = nbits - kWideExact;                  // octaves above the exact range (3 .. 11)
+        const unsigned mb = 31u - static_cast<unsigned>(__builtin_clz(kWideBins / 2 / oct));  // mantissa bits kept per octave
+        for (int b = t; b < static_cast<int>(kWideWords); b += 1024) hist[b] = 0;
+        if (t < 32) wtot[t] = 0;
+        __syncthreads();
+        uint32_t code[IPT], low[IPT], arrival[IPT];
+#pragma unroll
+        for (int e = 0; e < IPT; ++e) {
+            const int i = e * 1024 + t;
+            code[e] = 0; low[e] = 0; arrival[e] = 0;
+            if (i < G) {
+                const uint32_t k = static_cast<uint32_t>((kKeep ? kk[e] : Codec<T>::enc(col[i])) >> begin_bit) & mask;
+                if (k < (1u << kWideExact)) code[e] = k;
+                else {
+                    const unsigned ex = 31u - static_cast<unsigned>(__builtin_clz(k)), d = ex - mb;  // ex >= 13 > mb
+                    code[e] = (1u << kWideExact) + ((ex - kWideExact) << mb) + ((k >> d) & ((1u << mb) - 1u));
+                    low[e] = (k & ((1u << d) - 1u)) | 0x10000u;   // bit 16: the bucket dropped bits
+                }
+                arrival[e] = atomicAdd(&hist[at(code[e])], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive prefix sums of the bins, in place: thread t owns bins [16 t, 16 t + 16)
+        constexpr int per = kWideBins / 1024;
+        uint32_t cnt[per], tot = 0;
+#pragma unroll
+        for (int u = 0; u < per; ++u) { cnt[u] = hist[at(t * per + u)]; tot += cnt[u]; }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += up; }
+        if ((t & 63) == 63) wtot[t >> 6] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot;
+        for (int w = 0; w < (t >> 6); ++w) run += wtot[w];
+#pragma unroll
+        for (int u = 0; u < per; ++u) { hist[at(t * per + u)] = run; run += cnt[u]; }
+        __syncthreads();
+        uint32_t s0[IPT], s1[IPT], crowd = 0;
+#pragma unroll
+        for (int e = 0; e < IPT; ++e) {
+            const int i = e * 1024 + t;
+            s0[e] = s1[e] = 0;
+            if (i >= G) continue;
+            s0[e] = hist[at(code[e])];
+            s1[e] = code[e] + 1 < static_cast<uint32_t>(kWideBins) ? hist[at(code[e] + 1)] : static_cast<uint32_t>(G);
+            if (low[e] >> 16) {
+                skey[s0[e] + arrival[e]] = static_cast<uint16_t>(low[e]);
+                crowd = max(crowd, s1[e] - s0[e]);
+            }
+        }
+        if (__ballot(crowd > static_cast<uint32_t>(kWideScan)) != 0 && (t & 63) == 0) atomicOr(&wtot[16], 1u);
+        __syncthreads();
+        if (wtot[16] == 0) {  // workgroup-uniform
+            bool tied = false;
+            uint16_t *prow = pos + static_cast<size_t>(slot) * Gp, *lrow = lo + static_cast<size_t>(slot) * Gp, *hrow = hi + static_cast<size_t>(slot) * Gp;
+#pragma unroll
+            for (int e = 0; e < IPT; ++e) {
+                const int i = e * 1024 + t;
+                if (i >= G) continue;
+                uint32_t l = s0[e], h = s1[e], p = s0[e] + arrival[e];
+                if ((low[e] >> 16) && s1[e] - s0[e] > 1u) {  // rank inside the bucket: members with smaller / equal low bits
+                    const uint32_t mine = low[e] & 0xFFFFu, me = s0[e] + arrival[e];
+                    uint32_t smaller = 0, equal = 0, before = 0;
+                    for (uint32_t q = s0[e]; q < s1[e]; ++q) {
+                        const uint32_t o = skey[q];
+                        smaller += o < mine; equal += o == mine; before += (o == mine) & (q < me);
+                    }
+                    l = s0[e] + smaller; h = l + equal; p = l + before;
+                }
+                tied |= h - l > 1u;
+                prow[i] = static_cast<uint16_t>(p);
+                lrow[i] = static_cast<uint16_t>(l);
+                hrow[i] = static_cast<uint16_t>(h);
+            }
+            if (tied && *anytie == 0) atomicOr(anytie, 1);
+            return;
+        }
+        __syncthreads();  // a crowded bucket: the radix sort below starts from scratch in the same LDS
     }
     uint32_t k[IPT];
     uint16_t v[IPT];
@@ -426,7 +520,8 @@ int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d
 {
     using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
     const size_t lds = std::max({sizeof(typename sorter::storage_type), static_cast<size_t>(IPT <= 24 ? 6 : 4) * c->Gp,
-                                 kCountingPath<T> ? sizeof(uint32_t) * kCountWords + 64 : size_t(0)});
+                                 kCountingPath<T> ? sizeof(uint32_t) * kCountWords + 64 : size_t(0),
+                                 kCountingPath<T> ? sizeof(uint32_t) * (kWideWords + 32) + sizeof(uint16_t) * static_cast<size_t>(c->Gp) : size_t(0)});
     // every time: the attribute belongs to the (function, device) pair and a process may use several devices
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,

@@ -575,6 +575,38 @@ def test_transform_key_width_decides_the_path(pkg, oracle, monkeypatch):
         assert np.array_equal(out[0], egt) and np.array_equal(out[1], eeq), name
 
 
+@pytest.mark.parametrize("G", [3000, 20000, 32768])
+def test_transform_compressed_histogram_ranking(pkg, oracle, G, monkeypatch):
+    """Integer keys with 16 to 24 varying bits rank by a histogram of a monotone compression of the key (transform.hip,
+    t_sample): exact codes below 2^13, octave + mantissa above, ranks inside a lossy bucket by scanning its members.
+    Values on octave boundaries, equal values inside lossy buckets, moderately crowded buckets (scanned) and crowded
+    ones (the sample then takes the radix sort) -- all against the oracle's counts and against the segmented path."""
+    rng = np.random.default_rng(G)
+    S = 12
+    gid = np.array([0, 1] * 6, dtype=np.int32)
+    X = pkg.synth.t1_counts(G, S, 0x5EED0066).copy()
+    # sample 1: a long tail to 2^23 with values exactly on octave boundaries and repeated values in the tail
+    X[:, 1] = (rng.lognormal(6.0, 3.0, G)).astype(np.int64) % (1 << 23)
+    X[: G // 50, 1] = 1 << rng.integers(13, 23, G // 50)
+    X[G // 50: G // 25, 1] = (1 << 20) + rng.integers(0, 40, G // 25 - G // 50)       # one moderately crowded region, many ties
+    # sample 2: 200 genes inside one lossy bucket (more than the scan limit): the radix sort takes that sample
+    X[:, 2] = rng.integers(0, 1 << 18, G)
+    X[:200, 2] = (1 << 17) + rng.integers(0, 16, 200)
+    # sample 3: 20 bits, uniformly spread (every bucket nearly empty)
+    X[:, 3] = rng.integers(0, 1 << 20, G)
+    blocks = [(0, 48, 0, 48), (0, 40, G // 50, G // 50 + 64), (G - 40, G, G - 40, G), (100, 124, 150, 214)]
+    monkeypatch.delenv("REO_TRANSFORM", raising=False)
+    a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
+    assert info_a["transform_in_lds"] == 1
+    monkeypatch.setenv("REO_TRANSFORM", "segmented")
+    b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
+    Xf = X.astype(np.float64)
+    for blk, (ga, ea), (gb, eb) in zip(blocks, a, b):
+        egt, eeq = oracle.pair_counts(Xf, gid, 2, *blk)
+        assert np.array_equal(ga, egt) and np.array_equal(ea, eeq), blk
+        assert np.array_equal(ga, gb) and np.array_equal(ea, eb), blk
+
+
 def test_plain_c_client_of_the_abi(pkg, oracle, tmp_path):
     """include/reo_hip.h from a C program (no Python, no torch in that process): compile tests/abi/abi_client.c
     with gcc, run it, and compare what it prints with the oracle and with the ctypes path."""
