@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "reo_internal.h"
 
@@ -280,20 +281,16 @@ __device__ __forceinline__ void write_lane(uint32_t &v, uint32_t x, int l)
 // the mirror word of row j (:386: L and H swap) grows by one bit per row with an add-with-carry from the
 // same mask.  Only pairs i < j < G are real; everything else contributes zero bits.  The diagonal 64x64
 // blocks are written by several tiles and use atomicOr on the pre-zeroed table.
-template <int RI, typename F>
-__device__ __forceinline__ void emit_gene(const K1Args &a, int i0, int j, int bi, int lane, int pl, int hi_thr, int lo_thr, F val)
+// NEAR: 0 no row of the tile reaches the diagonal inside this wave's 64 genes, 1 some do (d > ii per row), 2 decided at
+// run time per row (one copy of the code: the workgroup kernels, whose epilogues are unrolled over their genes)
+template <int RI, int NEAR, typename F>
+__device__ __forceinline__ void emit_rows(bool near, int d, unsigned long long lanes_ok, int hi_thr, int lo_thr, uint32_t &wL, uint32_t &wH,
+                                          uint32_t &fLlo, uint32_t &fLhi, uint32_t &fHlo, uint32_t &fHhi, F val)
 {
-    const int bj = __builtin_amdgcn_readfirstlane(j >> 6);  // wave-uniform, and the compiler should know it
-    if ((bj << 6) >= a.Gp || bj < bi) return;
-    const int d = j - i0;                          // rows i0+ii with ii < d are above the diagonal
-    const bool near = (bj << 6) - i0 < RI;         // wave-uniform: some lane has d < 32
-    const unsigned long long lanes_ok = __ballot(j < a.G);
-    uint32_t wL = 0, wH = 0;
-    uint32_t fLlo = 0, fLhi = 0, fHlo = 0, fHhi = 0;  // lane ii: forward words of row i0+ii
 #pragma unroll
     for (int ii = RI - 1; ii >= 0; --ii) {
         const int n = val(ii);
-        const unsigned long long ok = near ? (__ballot(d > ii) & lanes_ok) : lanes_ok;
+        const unsigned long long ok = (NEAR == 1 || (NEAR == 2 && near)) ? (__ballot(d > ii) & lanes_ok) : lanes_ok;
         const unsigned long long mH = __ballot(n >= hi_thr) & ok;
         const unsigned long long mL = __ballot(n <= lo_thr) & ok & ~mH;
         shift_in(wH, mH);
@@ -303,6 +300,24 @@ __device__ __forceinline__ void emit_gene(const K1Args &a, int i0, int j, int bi
         write_lane(fLlo, static_cast<uint32_t>(mL), ii);
         write_lane(fLhi, static_cast<uint32_t>(mL >> 32), ii);
     }
+}
+
+template <int RI, bool SPLIT, typename F>
+__device__ __forceinline__ void emit_gene(const K1Args &a, int i0, int j, int bi, int lane, int pl, int hi_thr, int lo_thr, F val)
+{
+    const int bj = __builtin_amdgcn_readfirstlane(j >> 6);  // wave-uniform, and the compiler should know it
+    if ((bj << 6) >= a.Gp || bj < bi) return;
+    const int d = j - i0;                          // rows i0+ii with ii < d are above the diagonal
+    const bool near = (bj << 6) - i0 < RI;         // wave-uniform: some lane has d < 32
+    const unsigned long long lanes_ok = __ballot(j < a.G);
+    uint32_t wL = 0, wH = 0;
+    uint32_t fLlo = 0, fLhi = 0, fHlo = 0, fHhi = 0;  // lane ii: forward words of row i0+ii
+    // two copies of the 32 rows, chosen once (near is wave-uniform and rare): inside a copy the rows are straight-line code,
+    // so the compare -> lane mask -> writelane / add-with-carry chains of neighbouring rows overlap instead of queueing
+    // behind a branch per row
+    if (!SPLIT) emit_rows<RI, 2>(near, d, lanes_ok, hi_thr, lo_thr, wL, wH, fLlo, fLhi, fHlo, fHhi, val);
+    else if (near) emit_rows<RI, 1>(near, d, lanes_ok, hi_thr, lo_thr, wL, wH, fLlo, fLhi, fHlo, fHhi, val);
+    else emit_rows<RI, 0>(near, d, lanes_ok, hi_thr, lo_thr, wL, wH, fLlo, fLhi, fHlo, fHhi, val);
     const bool diag = (bj == bi);
     if (lane < RI && i0 + lane < a.G) {
         uint32_t *row = a.table + (static_cast<size_t>(i0 + lane) * kPlanes + pl) * a.Wp + 2 * bj;
@@ -332,7 +347,7 @@ __device__ __forceinline__ void emit_side(const K1Args &a, int i0, int jl, int b
 {
 #pragma unroll
     for (int r = 0; r < RJ; ++r)
-        emit_gene<RI>(a, i0, jl + 64 * r, bi, lane, pl, hi_thr, lo_thr, [&](int ii) { return val(r, ii); });
+        emit_gene<RI, false>(a, i0, jl + 64 * r, bi, lane, pl, hi_thr, lo_thr, [&](int ii) { return val(r, ii); });
 }
 
 // block -> tile mapping shared by k1_pairs, k1_group_counts and k1_classify.  Work order (speed only, never
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
 #pragma unroll
             for (int h = 0; h < RI / 2; ++h) cge[h] = park[r * (RI / 2) + h];  // (dynamic r: the array stays in memory)
         }
-        emit_gene<RI>(a, i0, jl + 64 * r, bi, lane, side ? 2 : 0, m, n - m, [&](int ii) {
+        emit_gene<RI, true>(a, i0, jl + 64 * r, bi, lane, side ? 2 : 0, m, n - m, [&](int ii) {
             const uint32_t w = cur[ii >> 1];
             int nre = static_cast<int>((ii & 1) ? (w >> 16) : (w & 0xFFFFu));
             if (TIES) {  // tie coins (:72-77): n = n_gt + Binomial(n_eq, 1/2) lies in [n_gt, n_ge].  The coins are drawn only
