@@ -33,11 +33,12 @@ def a_word(k):
 
 
 class Loop:
-    def __init__(self, nb, ties, name, lshl_add=True, opts=()):
+    def __init__(self, nb, ties, name, lshl_add=True, opts=(), ri=RI):
         # opts: timing experiments only (tools/k1w_probe.hip) -- never set for the library's loops
         self.nb, self.ties, self.name, self.opts = nb, ties, name, set(opts)
         # big: more than 16 planes (more than 65 535 genes).  Five pos quads per gene and block, P [nblk][5][Gp]; edge rows
         # of 8 uint4 (20 words used, plane k in word k: the generator places the registers, no skew needed), A [nblk][Gp][8].
+        self.ri = ri                       # gene rows per item (16: the four-waves-per-SIMD experiment of tools/k1w_probe.hip)
         self.big = nb > 16
         assert not (self.big and ties)
         self.rj = 2 if ties else 4
@@ -54,7 +55,7 @@ class Loop:
         self.PSTR = 20 if self.big else 16
         self.LQ = 5 if self.big else 4     # pos quads per block in the layout
         self.ROWB = 128 if self.big else 64  # bytes of one edge row in memory and in LDS
-        self.NDMA = 32 * self.ROWB // 1024   # 1 KiB pieces per block and edge
+        self.NDMA = self.ri * self.ROWB // 1024   # 1 KiB pieces per block and edge
         if self.big:
             top = 72 + self.PSTR * self.rj
             self.L = top
@@ -66,6 +67,16 @@ class Loop:
             assert self.vtop <= 256 - 8, self.vtop
             for a in self.A:   # pos plane k in bank k % 4, edge plane k in bank (A + k) % 4
                 assert a % 2 == 0 and a % 4 != 0
+        elif self.ri == 16:   # 128 registers: 32 counts, the two addresses in the unused 16th word of the pos planes (NB <= 15)
+            assert nb <= 15 and not ties
+            self.P = 8 + 32
+            self.A = [self.P + 64]
+            self.L = self.A[0] + 20
+            self.VLDS = self.P + 15
+            self.VA2 = self.P + 31
+            self.vtop = self.L + 4
+            self.VAP = [None]
+            assert self.vtop <= 128
         else:
             self.A = [72 + 16 * self.rj + 20 * e for e in range(nedge)]   # row operand words 0..15, +16..19 second copy of quad 3
             top = 72 + 16 * self.rj + 20 * nedge
@@ -92,7 +103,7 @@ class Loop:
         self.first_use = {q: min(k for k in range(nb) if self.word(k) // 4 == q) for q in self.aq}
         self.last_use = {q: max(k for k in range(nb) if self.word(k) // 4 == q) for q in self.aq}
         self.dbl = None if self.big else 3   # the quad that holds plane 0 AND the last planes: second copy
-        self.slot_bytes = 32 * self.ROWB * nedge
+        self.slot_bytes = self.ri * self.ROWB * nedge
 
     def word(self, k):
         return k if self.big else a_word(k)
@@ -141,7 +152,7 @@ class Loop:
         """request quad q of the row operand(s) of row `row` (row 32 = row 0 of the next block, other slot)"""
         for e in range(len(self.A)):
             self.lds_read(("a", row & 1 if q == self.dbl else 0, e, q), self.aquad_reg(e, q, row),
-                          32 * self.ROWB * e + (row % RI) * self.ROWB + q * 16)
+                          self.ri * self.ROWB * e + (row % self.ri) * self.ROWB + q * 16)
 
     def need_row_quad(self, row, q):
         self.lds_need([("a", row & 1 if q == self.dbl else 0, e, q) for e in range(len(self.A))])
@@ -154,7 +165,7 @@ class Loop:
         for e in range(len(self.A)):
             sa = self.SA[e]
             for piece in range(self.NDMA):   # 1 KiB each: lane * 16 + 1024 piece, to the same offset of the slot
-                off = 32 * self.ROWB * e + 1024 * piece
+                off = self.ri * self.ROWB * e + 1024 * piece
                 if off == 0:
                     self.e(f"s_mov_b32 m0, s{self.S_SLOT}")
                 else:
@@ -209,7 +220,7 @@ class Loop:
         h = row >> 1
         if "nopop" in self.opts:
             return
-        accs = [self.ACC + 16 * c + h for c in range(4)]   # tie-free: gene c; ties: gt[0], gt[1], ge[0], ge[1]
+        accs = [self.ACC + (self.ri // 2) * c + h for c in range(4)]   # tie-free: gene c; ties: gt[0], gt[1], ge[0], ge[1]
         if row & 1:
             for c in range(4):
                 self.e(f"v_bcnt_u32_b32 v{self.L + c}, v{self.L + c}, 0")
@@ -232,7 +243,7 @@ class Loop:
     # ---------------------------------------------------------------- the loop
     def row(self, i):
         nb = self.nb
-        last = i == RI - 1
+        last = i == self.ri - 1
         nxt = i + 1
         if last:
             # the next row is row 0 of the next block: its operand must have landed in the other slot
@@ -284,7 +295,7 @@ class Loop:
         e(f"v_mov_b32 v{self.VLDS}, %[ldsbase]")
         for piece in range(1, self.NDMA):
             e(f"v_add_u32 v{self.VAP[piece]}, {1024 * piece}, %[aoff]")
-        for r in range(64):
+        for r in range(2 * self.ri):
             e(f"v_mov_b32 v{self.ACC + r}, 0")
         self.dma_block()
         for q in range(self.pq):
@@ -298,7 +309,7 @@ class Loop:
         top_l, top_v = list(self.lq), list(self.vq)
         self.in_loop = True
         e(f".Lk1loop_{self.name}_%=:")
-        for i in range(RI):
+        for i in range(self.ri):
             self.row(i)
         # end of the block: the slot just read is free -- DMA of the block after the next one; pos bases move on
         lab = self.skip_if_last()
@@ -319,15 +330,16 @@ class Loop:
         out = []
         out.append(f"// {self.name}: NB = {self.nb}, {'with ties (RJ = 2, edges lo and hi)' if self.ties else ('more than 65 535 genes: five pos quads, 128-byte edge rows' if self.big else 'one edge per pass (RJ = 4)')};"
                    f" {len(self.lines)} instructions, VGPRs v8..v{self.vtop - 1}")
-        out.append(f"__device__ __forceinline__ void {self.name}(u32x16 &acc0, u32x16 &acc1, u32x16 &acc2, u32x16 &acc3,")
+        ty = "u32x16" if self.ri == 32 else "u32x8"
+        out.append(f"__device__ __forceinline__ void {self.name}({ty} &acc0, {ty} &acc1, {ty} &acc2, {ty} &acc3,")
         out.append("    const void *pbase, uint32_t pstride, const void *albase, const void *ahbase, uint32_t astride, uint32_t nblk,")
         out.append("    uint32_t poff, uint32_t aoff, uint32_t ldsbase)")
         out.append("{")
         out.append("    asm volatile(")
         for l in self.lines:
             out.append(f'        "{l}\\n\\t"')
-        out.append(f'        : "=&{{v[{self.ACC}:{self.ACC + 15}]}}"(acc0), "=&{{v[{self.ACC + 16}:{self.ACC + 31}]}}"(acc1), '
-                   f'"=&{{v[{self.ACC + 32}:{self.ACC + 47}]}}"(acc2), "=&{{v[{self.ACC + 48}:{self.ACC + 63}]}}"(acc3)')
+        w = self.ri // 2
+        out.append("        : " + ", ".join(f'"=&{{v[{self.ACC + w * c}:{self.ACC + w * c + w - 1}]}}"(acc{c})' for c in range(4)))
         ins = '[pbase] "s"(pbase), [pstride] "s"(pstride), [albase] "s"(albase), '
         if nedge > 1:
             ins += '[ahbase] "s"(ahbase), '

@@ -38,6 +38,30 @@ __global__ __launch_bounds__(64, 3) void probe(const uint4 *P, const uint4 *AL, 
     out[blockIdx.x * 64 + threadIdx.x] = s;
 }
 
+// the four-waves-per-SIMD experiment: items of 16 rows (128 registers)
+template <int V>
+__global__ __launch_bounds__(64, 4) void probe16(const uint4 *P, const uint4 *AL, int Gp, int nblk, const uint32_t *items, uint32_t *out)
+{
+    extern __shared__ uint4 ring[];
+    const uint32_t it = items[blockIdx.x];
+    if (it == 0xFFFFFFFFu) return;
+    const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(it & 0xFFFFu) * 16);
+    const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((it >> 16) & 0x7FFFu) * 256);
+    const int side = __builtin_amdgcn_readfirstlane(static_cast<int>(it >> 31));
+    const int bb = side * nblk;
+    u32x8 c0, c1, c2, c3;
+    const char *pb = reinterpret_cast<const char *>(P) + static_cast<size_t>(bb) * 4 * Gp * 16;
+    const char *al = reinterpret_cast<const char *>(AL) + (static_cast<size_t>(bb) * Gp + i0) * 64;
+    const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
+    const uint32_t poff = static_cast<uint32_t>(jw + threadIdx.x) * 16u, aoff = threadIdx.x * 16u;
+    if (V == 0) probe16_half(c0, c1, c2, c3, pb, static_cast<uint32_t>(Gp) * 16u, al, al, static_cast<uint32_t>(Gp) * 64u, static_cast<uint32_t>(nblk), poff, aoff, lds);
+    else probe16_half_noreload(c0, c1, c2, c3, pb, static_cast<uint32_t>(Gp) * 16u, al, al, static_cast<uint32_t>(Gp) * 64u, static_cast<uint32_t>(nblk), poff, aoff, lds);
+    uint32_t s = 0;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) s += c0[h] + c1[h] + c2[h] + c3[h];
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+
 int main()
 {
     const int G = 20000, Gp = 21504, nblk = 16, nblk_all = 32;
@@ -110,6 +134,33 @@ int main()
 #define RUN(i, fn, nm) if (run(nm, probe<i>, balanced, 3)) return 1;
         PROBE_VARIANTS(RUN)
 #undef RUN
+    }
+    {   // 16-row items: every item of the balanced list as two halves (same XCD), 4 waves per SIMD
+        std::vector<uint32_t> half;
+        for (size_t k = 0; k < balanced.size(); k += 8)
+            for (int h = 0; h < 2; ++h)
+                for (int x = 0; x < 8; ++x) {
+                    const uint32_t it = balanced[k + x];
+                    half.push_back(it == 0xFFFFFFFFu ? it : ((it & 0xFFFF0000u) | ((it & 0xFFFFu) * 2 + h)));
+                }
+        CHECK(hipFree(dItems)); CHECK(hipFree(dOut));
+        CHECK(hipMalloc(&dItems, half.size() * 4)); CHECK(hipMalloc(&dOut, half.size() * 64 * 4));
+        CHECK(hipMemcpy(dItems, half.data(), half.size() * 4, hipMemcpyHostToDevice));
+        for (int v = 0; v < 2; ++v)
+            for (int rep = 0; rep < 3; ++rep) {
+                float best = 1e30f;
+                for (int r2 = 0; r2 < 6; ++r2) {
+                    CHECK(hipEventRecord(e0));
+                    if (v == 0) probe16<0><<<static_cast<unsigned>(half.size()), 64, 2048>>>(dP, dA, Gp, nblk, dItems, dOut);
+                    else probe16<1><<<static_cast<unsigned>(half.size()), 64, 2048>>>(dP, dA, Gp, nblk, dItems, dOut);
+                    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    best = std::min(best, ms);
+                }
+                printf("%-12s half-items 4w  %7.3f ms  %6.2f Tcmp/s\n", v == 0 ? "half" : "half_norel", best, cmp / best / 1e9);
+            }
+        CHECK(hipFree(dItems)); CHECK(hipFree(dOut));
+        CHECK(hipMalloc(&dItems, full.size() * 4)); CHECK(hipMalloc(&dOut, full.size() * 64 * 4));
     }
     if (run("base", probe<0>, full, 3)) return 1;
     if (run("base", probe<0>, compact, 3)) return 1;

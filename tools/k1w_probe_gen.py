@@ -11,4 +11,9 @@ for name, opts in VARIANTS:
     lp = Loop(15, False, "probe_" + name, opts=opts)
     lp.generate()
     print(lp.cxx())
+print("typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));")
+for name, opts in (("half", ()), ("half_noreload", ("noreload",))):
+    lp = Loop(15, False, "probe16_" + name, opts=opts, ri=16)
+    lp.generate()
+    print(lp.cxx())
 print("#define PROBE_VARIANTS(X) " + " ".join(f'X({i}, probe_{n}, "{n}")' for i, (n, _) in enumerate(VARIANTS)))
