@@ -16,12 +16,14 @@ plane by plane) and one v_bcnt_u32_b32.  What the hand schedule does that the co
     the running block, each register quad as soon as its last reader has issued;
   * counted s_waitcnt vmcnt(N) throughout (the generator keeps the queues and asserts the loop invariant).
 
-Register file of a loop (tie-free, RJ = 4): acc 64 (two 16-bit counts per register: rows 2h, 2h+1), pos planes 64,
-row operand 16 + 4 (the quad that holds plane 0 is double-buffered), chains 4, addresses 4.
-With ties (RJ = 2, edges lo and hi): acc 64 (gt and ge), pos planes 32, row operands 2 x 20, chains 4.
-
-Data layout (kernels.hip header): P uint4 [nblk][4][Gp] (plane quad q of gene g in block b at (b*4+q)*Gp + g);
-AL / AH uint4 [nblk][Gp][4], plane k in word (k + 15) % 16.
+Register file of a loop (RJ = 4 genes per lane, one band edge per pass): acc 64 (two 16-bit counts per register: rows 2h,
+2h+1), pos planes 64, row operand 16 + 4 (the quad that holds plane 0 is double-buffered), chains 4, addresses 2: v8..v161,
+three waves per SIMD.  Tie-rich data runs the loop twice (hi planes, then lo planes: kernels.hip, k1w_pairs).
+The library's loops: NB = 12, 15, 16 on the 16-plane layout -- P uint4 [nblk][4][Gp] (plane quad q of gene g in block b
+at (b*4+q)*Gp + g), AL / AH uint4 [nblk][Gp][4], plane k in word (k + 15) % 16 -- and NB = 17, 18 on the big layout
+(more than 65 535 genes: P [nblk][5][Gp], AL / AH [nblk][Gp][8], plane k in word k; 180 registers, two waves per SIMD).
+`ties=True` (two edges and RJ = 2 inside one loop: round 2's tiling) and `ri=16` (four waves per SIMD) are kept for the
+probe (tools/k1w_probe.hip); both measured slower and neither is generated for the library.
 """
 import sys
 

@@ -1,7 +1,11 @@
 // Hand-written gfx950 kernels of the REO hot path.
 //
-//   K1  k1_pairs    pair compare -> per-group counts -> stable-REO class ->
+//   K1  k1w_pairs   pair compare -> per-group counts -> stable-REO class ->
 //                   4 bit planes per ordered pair      (src/RankCompV3.jl:363-392)
+//                   wave form (round 3, the default for two groups): one wave per workgroup, the count loop a generated,
+//                   hand-scheduled asm statement (gen_k1_loop.py -> k1_loop_gen.inc), up to 262 143 genes
+//       k1_pairs    the workgroup form of round 2 (REO_K1_WAVE=0; more than two groups without shared counts),
+//       k1_pairs_wide the same with 32-bit counts (more than 65 535 samples)
 //       k1_group_counts + k1_classify: the same for one-vs-rest over more than two groups
 //                   (:375-390) -- every group counted once, counts kept in HBM, one cheap
 //                   classification per comparison
@@ -22,6 +26,7 @@
 //   AL  uint4 [nblk][Gp][4]  the 16 plane words of lo (first position of g's tie band) of gene g in block b,
 //                   plane k in word (k + 15) % 16 (tile operand: staged through LDS)
 //   AH  likewise for hi (one past the last position of g's tie band); padding samples have lo = hi = 0
+//   (more than 65 535 genes: the big layout of transform.hip, t_slice_big -- P [nblk][5][Gp], AL / AH [nblk][Gp][8], plane k in word k)
 //   table u32 [G][4][Wp]  bit planes cL cH tL tH of row i: bit j of plane cL is
 //                   set iff pair (i,j) is "i<j stable" in ctrl (ic==1), cH iff
 //                   ic==3, tL/tH likewise for treat.  4 bits per ORDERED pair,
