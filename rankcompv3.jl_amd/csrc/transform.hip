@@ -580,23 +580,10 @@ int32_t transform_impl(reo_ctx *c)
         if ((rc = c->t_pos16.ensure(n)) || (rc = c->t_lo16.ensure(n)) || (rc = c->t_hi16.ensure(n)) ||
             (rc = c->pos.ensure(nq)) || (rc = c->lo.ensure(nq)) || (rc = c->hi.ensure(nq)))
             return rc;
-        // rows of padding slots and padded genes: below no band edge.  Every (sample, gene < G) entry is written by whichever
-        // path ranks the sample, so only the padding needs zeros: the genes [G, Gp) of every row (one 2-D fill) and the
-        // padding slots at the end of each group -- 12 MB instead of 129 MB at config 3.  (Many groups: one fill of it all.)
-        uint16_t *rows16[3] = {c->t_pos16.p, c->t_lo16.p, c->t_hi16.p};
-        for (uint16_t *r16 : rows16) {
-            if (c->ngroups > 4 || Gp == G) {
-                REO_HIP_CHECK(hipMemsetAsync(r16, 0, n * sizeof(uint16_t), st));
-                continue;
-            }
-            REO_HIP_CHECK(hipMemset2DAsync(r16 + G, static_cast<size_t>(Gp) * sizeof(uint16_t), 0, static_cast<size_t>(Gp - G) * sizeof(uint16_t),
-                                           static_cast<size_t>(S32), st));
-            for (int g = 0; g < c->ngroups; ++g) {
-                const int used = c->goff32[g] + (c->goff[g + 1] - c->goff[g]), end = c->goff32[g + 1];
-                if (end > used)
-                    REO_HIP_CHECK(hipMemsetAsync(r16 + static_cast<size_t>(used) * Gp, 0, static_cast<size_t>(end - used) * Gp * sizeof(uint16_t), st));
-            }
-        }
+        // rows of padding slots and (segmented path) padded genes: below no band edge
+        REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_lo16.p, 0, n * sizeof(uint16_t), st));
+        REO_HIP_CHECK(hipMemsetAsync(c->t_hi16.p, 0, n * sizeof(uint16_t), st));
     } else {
         if ((rc = c->t_pos32.ensure(n)) || (rc = c->t_lo32.ensure(n)) || (rc = c->t_hi32.ensure(n)) ||
             (rc = c->pos.ensure(static_cast<size_t>(nblk) * Gp * 5)) || (rc = c->lo.ensure(static_cast<size_t>(nblk) * Gp * 8)) ||
