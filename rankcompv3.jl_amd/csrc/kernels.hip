@@ -58,30 +58,18 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
 // Loads and stores of data that travels between workgroups of ONE launch (the persistent light kernel): relaxed
 // agent-scope atomics = global_load / global_store with sc1, which bypass the CU's L1 and are served coherently
 // across the XCDs' L2s (measured hand-off form: MI355X_MICROARCH.md, "Valid forms"; tools/microbench_gridbar.hip reads
-// every workgroup's value in every round and finds none stale).  COH = 0 (false): plain accesses (separate launches).
-// COH = 2: every workgroup of the launch runs on ONE XCD (kl_persist<2>), so the XCD's own L2 is the point of coherence:
-// workgroup-scope atomics = sc0 accesses, which bypass the CU's L1 and stop at that L2 -- no trip to the memory side.
-template <int COH, class T>
+// every workgroup's value in every round and finds none stale).  COH = false: plain accesses (separate launches).
+template <bool COH, class T>
 __device__ __forceinline__ T ldc(const T *p)
 {
-    if (COH == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <int COH, class T>
+template <bool COH, class T>
 __device__ __forceinline__ void stc(T *p, T v)
 {
-    if (COH == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
-}
-
-// returning integer add at the scope of COH (see ldc): 1 device-wide, 2 in the XCD's L2
-template <int COH>
-__device__ __forceinline__ int aadd(int *p, int v)
-{
-    if (COH == 2) return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding global
@@ -911,7 +899,7 @@ __device__ __forceinline__ void tally_rows(const uint4 *__restrict__ table, cons
 // by the mirror rule (:386) column j of the table is row j with L and H swapped, so gene j entering
 // (leaving) the reference set adds (removes), for every gene i, the class bits found at bit i of ROW j:
 // one contiguous row per changed gene instead of the whole table.  Exact (integer sums).
-template <int COH, int U = 4>
+template <bool COH, int U = 4>
 __device__ __forceinline__ void delta_counts(const uint32_t *__restrict__ table, int Wp, const uint32_t *list, int n, int i, int (&d)[kRaw])
 {
     const int w = i >> 5, sh = i & 31;
@@ -1632,7 +1620,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // with zero bins to whole rounds.
 // rmax: H never exceeds the number of genes with a finite rank, so no r above that count can qualify: only the
 // tiles that reach up to rank min(G, rmax) are read (a few thousand bins instead of G).
-template <int COH>
+template <bool COH>
 __device__ __forceinline__ int bh_cut(const int32_t *hist, int G, int rmax)
 {
     __shared__ __attribute__((aligned(16))) int wsum[16][4];
@@ -1749,7 +1737,7 @@ __device__ __forceinline__ bool slice_std_vals(const IterArgs &a, double x, doub
     return static_cast<int>(n) == a.b0 - a.a0 + 1;
 }
 
-template <int COH>
+template <bool COH>
 __device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand, int npart, int below_a, int below_b, int cnt_a, int cnt_b,
                                           double (*sel)[4], double *red, double &se, double &va, double &vb)
 {
@@ -1866,7 +1854,6 @@ __global__ __launch_bounds__(256) void k_xcc_selftest_zero(int32_t *part, int32_
     // own XCD's copy of the lines so that a stale line would be seen
     for (int i = threadIdx.x; i < kHistParts * 64; i += 256) part[i] = 0;
     if (threadIdx.x < kHistParts) waves_of[threadIdx.x] = 0;
-    if (threadIdx.x == 0) waves_of[kHistParts + blockIdx.x] = -1;
 }
 
 __global__ __launch_bounds__(256) void k_xcc_selftest(int32_t *part, int32_t *waves_of)
@@ -1875,11 +1862,10 @@ __global__ __launch_bounds__(256) void k_xcc_selftest(int32_t *part, int32_t *wa
     const int lane = threadIdx.x & 63;
     for (int k = 0; k < 16; ++k) __hip_atomic_fetch_add(&part[x * 64 + lane], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (lane == 0) atomicAdd(&waves_of[x], 1);
-    if (threadIdx.x == 0) waves_of[kHistParts + blockIdx.x] = static_cast<int32_t>(x);  // which XCD workgroup blockIdx.x ran on (kl_persist<2>)
 }
 
 // lane l's four words of row R of mrank (COH: coherent 8-byte loads, for the persistent kernel)
-template <int COH>
+template <bool COH>
 __device__ __forceinline__ int4 load_rank_row(const int32_t *mrank, int R, int lane)
 {
     if (!COH) return reinterpret_cast<const int4 *>(mrank)[R * 64 + lane];
@@ -1898,7 +1884,7 @@ __device__ __forceinline__ int4 load_rank_row(const int32_t *mrank, int R, int l
 // last such row" without a branch -- a taken branch over a block of cold code costs an instruction-cache miss, and a
 // chain of twenty of them was two microseconds -- and the changed genes of that one row are then noted by the wave
 // together.  sum(inds) follows from the old count and the changes.
-template <int COH>
+template <bool COH>
 __device__ __forceinline__ void mask_scan(const int4 (&mv)[kHeadPre], int kstar, int nrow, const int32_t *mrank, uint32_t *dl, int *s_n, int *s_nn, bool reload_all = false)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2321,8 +2307,6 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
 // has arrived, the workgroup meets again.  No fences: measured 2.3 us per round with 80 workgroups against 4.6 us with a
 // release / acquire fence pair (tools/microbench_gridbar.hip).  Every spin is bounded (about 0.5 s): on expiry the
 // workgroup raises st->fault and leaves, and so do the others at their next barrier, so the grid always drains.
-// SC = 2 (all workgroups on one XCD): the counter lives in that XCD's L2 -- workgroup-scope atomic and loads.
-template <int SC>
 __device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned nwg, unsigned &gen, int *fault)
 {
     __shared__ int ok_s;
@@ -2330,13 +2314,12 @@ __device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned nwg, unsign
     __syncthreads();
     if (threadIdx.x == 0) {
         ++gen;
-        if (SC == 2) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = gen * nwg;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
         int ok = 1;
-        while (ldc<SC>(bar) < target) {
-            if (SC != 2) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull || __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
@@ -2349,16 +2332,8 @@ __device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned nwg, unsign
     return ok_s != 0;
 }
 
-// SC = 1: the workgroups are spread over the chip, what crosses them is coherent at the memory side (sc1).  SC = 2: the launch
-// has 8 x as many workgroups, dealt round-robin to the 8 XCDs by the dispatcher, and only those with (blockIdx.x & 7) == 0 --
-// all on ONE XCD (checked per device: xcc_selftest) -- take part, numbered blockIdx.x >> 3; everything that crosses them is
-// coherent in that XCD's L2 (sc0 loads / stores, L2-local atomics): a barrier is two L2 round trips instead of two trips to
-// the memory side, and nobody reads the other seven L2s.
-template <int SC>
 __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, unsigned *bar)
 {
-    if (SC == 2 && (blockIdx.x & 7u) != 0u) return;
-    const unsigned bx = SC == 2 ? blockIdx.x >> 3 : blockIdx.x;
     IterState *st = a.st;
     LightRec r;  // the state as the previous launch left it (a kernel boundary: plain loads)
     r.t = st->passes; r.nref = st->nref; r.nref_prev = st->nref_prev; r.done = st->done; r.need_full = st->need_full;
@@ -2366,9 +2341,9 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
     r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
     if (!r.active || st->fault) return;  // the same in every workgroup
     const int G = a.G, Gp = a.Gp;
-    const unsigned nwg = SC == 2 ? gridDim.x >> 3 : gridDim.x;
-    const int i = bx * 256 + threadIdx.x;
-    const bool live = i < G, holds = static_cast<int>(bx) * 256 < G;  // (workgroups of padding genes only help with the barriers)
+    const unsigned nwg = gridDim.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < G, holds = static_cast<int>(blockIdx.x) * 256 < G;  // (workgroups of padding genes only help with the barriers)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nrow = (G + 255) >> 8;
     __shared__ uint32_t dl[kDeltaMax];
@@ -2415,7 +2390,7 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
             double out[5];
             mccullagh3<false>(c, out);
             d1 = out[1];
-            stc<SC>(hist + i, 0);  // this parity's histogram: last read two passes ago
+            stc<true>(hist + i, 0);  // this parity's histogram: last read two passes ago
             belowA = d1 < win[0]; inA = !belowA && d1 <= win[1];
             belowB = d1 < win[2]; inB = !belowB && d1 <= win[3];
             inner = d1 > win[1] && d1 < win[2];
@@ -2426,45 +2401,45 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
             block_sum2_256(inner ? 1.0 : 0.0, inner ? d1 : 0.0, red, nb, sum);
             const double mean = nb > 0.0 ? sum / nb : 0.0;
             const double m2 = block_sum_256(inner ? (d1 - mean) * (d1 - mean) : 0.0, red);
-            if (threadIdx.x == 0 && holds) { stc<SC>(a.part + 3 * bx, nb); stc<SC>(a.part + 3 * bx + 1, mean); stc<SC>(a.part + 3 * bx + 2, m2); }
+            if (threadIdx.x == 0 && holds) { stc<true>(a.part + 3 * blockIdx.x, nb); stc<true>(a.part + 3 * blockIdx.x + 1, mean); stc<true>(a.part + 3 * blockIdx.x + 2, m2); }
         }
         {
             const unsigned long long mA = __ballot(inA), mB = __ballot(inB), bA = __ballot(belowA), bB = __ballot(belowB);
             int baseA = 0, baseB = 0;
             if (lane == 0) {
-                if (mA) baseA = aadd<SC>(&lc->cnt_a, __popcll(mA));
-                if (mB) baseB = aadd<SC>(&lc->cnt_b, __popcll(mB));
+                if (mA) baseA = atomicAdd(&lc->cnt_a, __popcll(mA));
+                if (mB) baseB = atomicAdd(&lc->cnt_b, __popcll(mB));
                 wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
             }
             baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
             const unsigned long long lt = (1ULL << lane) - 1ULL;
-            if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) stc<SC>(a.cand + at, d1); }
-            if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) stc<SC>(a.cand + kCandMax + at, d1); }
+            if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) stc<true>(a.cand + at, d1); }
+            if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) stc<true>(a.cand + kCandMax + at, d1); }
             lds_barrier();
             if (threadIdx.x == 0) {
                 const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
-                if (ba) aadd<SC>(&lc->below_a[bx & (kSpread - 1)][0], ba);
-                if (bb) aadd<SC>(&lc->below_b[bx & (kSpread - 1)][0], bb);
+                if (ba) atomicAdd(&lc->below_a[blockIdx.x & (kSpread - 1)][0], ba);
+                if (bb) atomicAdd(&lc->below_b[blockIdx.x & (kSpread - 1)][0], bb);
             }
         }
         STAMP(a, 1);
-        if (!grid_barrier<SC>(bar, nwg, gen, &st->fault)) break;
+        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
         STAMP(a, 2);
         // ---------------- phase 2 (kl_rank): the selection, p-values, BH ranks and their histogram
-        if (bx == 0 && threadIdx.x < kSpread) {
+        if (blockIdx.x == 0 && threadIdx.x < kSpread) {
             // the other parity's counters: every workgroup is past its last look at them (the mask step in front of phase 1)
             LightCnt *z = &ls->slot[par ^ 1].lc;
-            if (threadIdx.x == 0) { stc<SC>(&z->cnt_a, 0); stc<SC>(&z->cnt_b, 0); }
-            stc<SC>(&z->below_a[threadIdx.x][0], 0); stc<SC>(&z->below_b[threadIdx.x][0], 0); stc<SC>(&z->sig[threadIdx.x][0], 0);
+            if (threadIdx.x == 0) { stc<true>(&z->cnt_a, 0); stc<true>(&z->cnt_b, 0); }
+            stc<true>(&z->below_a[threadIdx.x][0], 0); stc<true>(&z->below_b[threadIdx.x][0], 0); stc<true>(&z->sig[threadIdx.x][0], 0);
         }
         {
-            const int cnt_a = ldc<SC>(&lc->cnt_a), cnt_b = ldc<SC>(&lc->cnt_b);
+            const int cnt_a = ldc<true>(&lc->cnt_a), cnt_b = ldc<true>(&lc->cnt_b);
             int below_a = 0, below_b = 0;
 #pragma unroll
-            for (int q = 0; q < kSpread; ++q) { below_a += ldc<SC>(&lc->below_a[q][0]); below_b += ldc<SC>(&lc->below_b[q][0]); }
-            const double x = wave < 2 ? ldc<SC>(a.cand + wave * kCandMax + lane) : 0.0;
+            for (int q = 0; q < kSpread; ++q) { below_a += ldc<true>(&lc->below_a[q][0]); below_b += ldc<true>(&lc->below_b[q][0]); }
+            const double x = wave < 2 ? ldc<true>(a.cand + wave * kCandMax + lane) : 0.0;
             double pn = 0.0, pm = 0.0, pq = 0.0;
-            if (static_cast<int>(threadIdx.x) < nrow) { pn = ldc<SC>(a.part + 3 * threadIdx.x); pm = ldc<SC>(a.part + 3 * threadIdx.x + 1); pq = ldc<SC>(a.part + 3 * threadIdx.x + 2); }
+            if (static_cast<int>(threadIdx.x) < nrow) { pn = ldc<true>(a.part + 3 * threadIdx.x); pm = ldc<true>(a.part + 3 * threadIdx.x + 1); pq = ldc<true>(a.part + 3 * threadIdx.x + 2); }
             double va = 0.0, vb = 0.0;
             bool ok = slice_std_vals(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
             ok = ok && (va + wd1 < vb - wd2);
@@ -2480,15 +2455,15 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
         }
         row[4 * lane + wave] = live ? static_cast<int32_t>(static_cast<uint32_t>(own_rank) | (inref ? 0x80000000u : 0u)) : 0;
         lds_barrier();
-        stc<SC>(a.mrank + bx * 256 + threadIdx.x, row[threadIdx.x]);
+        stc<true>(a.mrank + blockIdx.x * 256 + threadIdx.x, row[threadIdx.x]);
         {
             const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
-            if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) aadd<SC>(&hist[0], __popcll(first)); }
-            else if (m <= G) aadd<SC>(&hist[m - 1], 1);
-            if (lane == 0 && finite) aadd<SC>(&lc->sig[bx & (kSpread - 1)][0], __popcll(finite));
+            if (m == 1) { if (lane == __ffsll(static_cast<long long>(first)) - 1) atomicAdd(&hist[0], __popcll(first)); }
+            else if (m <= G) atomicAdd(&hist[m - 1], 1);
+            if (lane == 0 && finite) atomicAdd(&lc->sig[blockIdx.x & (kSpread - 1)][0], __popcll(finite));
         }
         STAMP(a, 3);
-        if (!grid_barrier<SC>(bar, nwg, gen, &st->fault)) break;
+        if (!grid_barrier(bar, nwg, gen, &st->fault)) break;
         STAMP(a, 4);
         // ---------------- the mask step of pass r.t (kl_head's first half, :413-424), by every workgroup for itself
         int hv[4][8];
@@ -2497,17 +2472,17 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
         for (int e = 0; e < 4; ++e) {
             const unsigned long long *hp = reinterpret_cast<const unsigned long long *>(hist + (e * 256 + threadIdx.x) * 8);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const unsigned long long w = ldc<SC>(hp + u); hv[e][2 * u] = static_cast<int>(w); hv[e][2 * u + 1] = static_cast<int>(w >> 32); }
+            for (int u = 0; u < 4; ++u) { const unsigned long long w = ldc<true>(hp + u); hv[e][2 * u] = static_cast<int>(w); hv[e][2 * u + 1] = static_cast<int>(w >> 32); }
         }
 #pragma unroll
         for (int q = 0; q < kHeadPre; ++q) {
             const int R = wave + 4 * q;
             mv[q] = make_int4(0, 0, 0, 0);
-            if (R < nrow) mv[q] = load_rank_row<SC>(a.mrank, R, lane);
+            if (R < nrow) mv[q] = load_rank_row<true>(a.mrank, R, lane);
         }
         int sig = 0;
 #pragma unroll
-        for (int q = 0; q < kSpread; ++q) sig += ldc<SC>(&lc->sig[q][0]);
+        for (int q = 0; q < kSpread; ++q) sig += ldc<true>(&lc->sig[q][0]);
         STAMP(a, 5);
         const int t = r.t, nxt = par ^ 1;
         int carry0 = 0;
@@ -2515,14 +2490,14 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
         STAMP(a, 6);
         if (threadIdx.x == 0) { s_n = 0; s_nn = 0; }
         lds_barrier();
-        mask_scan<SC>(mv, kstar, nrow, a.mrank, dl, &s_n, &s_nn);
+        mask_scan<true>(mv, kstar, nrow, a.mrank, dl, &s_n, &s_nn);
         const bool ind = live && own_rank > kstar;
         if (i < Gp) a.refbytes[nxt][i] = ind ? 1 : 0;  // (read again by later launches only)
         const unsigned long long mk = __ballot(ind);
         if (lane == 0 && i < Gp) { a.refbits[nxt][i >> 5] = static_cast<uint32_t>(mk); a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(mk >> 32); }
         lds_barrier();
         const int chg = s_n, nn = r.nref + s_nn;  // sum(inds), :417-418
-        if (bx == 0) {
+        if (blockIdx.x == 0) {
             if (threadIdx.x == 0) { a.trace[2 * t] = G - nn; a.trace[2 * t + 1] = nn; }
             if (static_cast<int>(threadIdx.x) < min(chg, kDeltaMax)) a.delta_list[static_cast<size_t>(nxt) * Gp + threadIdx.x] = dl[threadIdx.x];
         }
@@ -2545,7 +2520,7 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
         a.result[11 * static_cast<size_t>(G) + i] = d1;
         a.result[i] = p;
     }
-    if (bx == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->passes = r.t; st->nref = r.nref; st->nref_prev = r.nref_prev; st->done = r.done; st->need_full = r.need_full;
         st->i_iter = r.t - (r.done ? 1 : 0);
         st->raw_pass = r.raw_pass;
@@ -3019,10 +2994,7 @@ int32_t launch_light_persistent(reo_ctx *c)
     const unsigned nwg = static_cast<unsigned>(a.Gp / 256);  // every mask byte, padding included, has its thread
     REO_HIP_CHECK(hipMemsetAsync(c->gridbar.p, 0, sizeof(unsigned), c->stream));
     REO_HIP_CHECK(hipMemsetAsync(c->lstate.p, 0, 2 * sizeof(LightSlot), c->stream));  // the counters of both pass parities
-    // one-XCD form: only where the dispatcher was seen to deal workgroups round-robin (xcc_selftest) and all participants
-    // fit one XCD at once (they spin on each other: 128 workgroups = 512 waves of its 32 CUs)
-    if (c->light_mode == 3 && c->xcc_round_robin && nwg <= 128) kl_persist<2><<<nwg * 8, 256, 0, c->stream>>>(a, c->lstate.p, c->gridbar.p);
-    else kl_persist<1><<<nwg, 256, 0, c->stream>>>(a, c->lstate.p, c->gridbar.p);
+    kl_persist<<<nwg, 256, 0, c->stream>>>(a, c->lstate.p, c->gridbar.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -3054,12 +3026,11 @@ int32_t xcc_selftest(reo_ctx *c, int *ok)
     // the verdict is a property of the device, not of the context: checked once per device and process
     static std::mutex mu;
     static int verdict[64];   // 0 unknown, 1 failed, 2 passed
-    static int verdict_rr[64];  // workgroups are dealt to the XCDs round-robin by their index: 1 no, 2 yes
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (c->device >= 0 && c->device < 64 && verdict[c->device]) { *ok = verdict[c->device] == 2; c->xcc_round_robin = verdict_rr[c->device] == 2; return REO_OK; }
+        if (c->device >= 0 && c->device < 64 && verdict[c->device]) { *ok = verdict[c->device] == 2; return REO_OK; }
     }
-    int32_t rc = buf.ensure(kHistParts * 64 + kHistParts + 1024);
+    int32_t rc = buf.ensure(kHistParts * 64 + kHistParts);
     if (rc) return rc;
     REO_HIP_CHECK(hipMemsetAsync(buf.p, 0xFF, buf.n * sizeof(int32_t), c->stream));  // garbage first: the zeroing launch has to win
     k_xcc_selftest<<<1024, 256, 0, c->stream>>>(buf.p, buf.p + kHistParts * 64);      // dirty every XCD's L2 with atomics on the lines
@@ -3076,14 +3047,9 @@ int32_t xcc_selftest(reo_ctx *c, int *ok)
         for (int l = 0; l < 64; ++l) good = good && h[x * 64 + l] == 16 * w;
     }
     *ok = good && waves == 1024 * 4 ? 1 : 0;
-    bool rr = *ok != 0;   // every workgroup b of a launch on the XCD that workgroup b & 7 names (what kl_persist<2> relies on)
-    for (int b = 0; b < 1024 && rr; ++b) rr = h[kHistParts * 64 + kHistParts + b] >= 0 && h[kHistParts * 64 + kHistParts + b] == h[kHistParts * 64 + kHistParts + (b & 7)];
-    for (int k = 0; k < 8 && rr; ++k)
-        for (int k2 = 0; k2 < k; ++k2) rr = rr && h[kHistParts * 64 + kHistParts + k] != h[kHistParts * 64 + kHistParts + k2];
-    c->xcc_round_robin = rr;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (c->device >= 0 && c->device < 64) { verdict[c->device] = *ok ? 2 : 1; verdict_rr[c->device] = rr ? 2 : 1; }
+        if (c->device >= 0 && c->device < 64) verdict[c->device] = *ok ? 2 : 1;
     }
     return REO_OK;
 }

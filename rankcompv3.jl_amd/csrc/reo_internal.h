@@ -218,9 +218,8 @@ struct reo_ctx {
     reo::DevBuf<int32_t> clist;         // [2][256 + 256 * kListCap * 2] genes near the BH cut, by workgroup (kernels.hip, kl_rank)
     int light_band = 32;                // REO_LIGHT_BAND (tests)
     int xcc_local = 0;                  // the per-XCD histogram atomics may stay in the XCD's L2 (checked once per context: kernels.hip, xcc_selftest)
-    bool xcc_round_robin = false;       // workgroup b of a launch runs on the XCD that b & 7 names (xcc_selftest): kl_persist<2> may be used
     int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
-    int light_mode = 1;                 // 0 sorting passes only, 1 light passes as two launches each, 2 as one persistent launch, 3 the same with all its workgroups on one XCD (REO_LIGHT)
+    int light_mode = 1;                 // 0 sorting passes only, 1 light passes as two launches each, 2 as one persistent launch (REO_LIGHT)
     reo::DevBuf<int32_t> hist, mrank;   // [2][G padded to whole 32768-bin rounds], [Gp] light passes: histogram of the BH ranks (by launch parity), the ranks
     // parameters of the running reo_identify_degs call (kernels.hip, iter_args)
     double it_pval_deg = 1.0, it_padj_deg = 0.05;
