@@ -186,10 +186,12 @@ class Loop:
         self.e(f"s_sub_u32 s{self.S_LEFT}, s{self.S_LEFT}, s{self.S_T2}")
         self.e(f"s_xor_b32 s{self.S_SLOT}, s{self.S_SLOT}, {self.slot_bytes}")
 
-    def load_pos_quad(self, q):
+    def load_pos_quad(self, q, only=None):
         n = min(4, self.nb - 4 * q)
         op = {4: "global_load_dwordx4", 3: "global_load_dwordx3", 2: "global_load_dwordx2", 1: "global_load_dword"}[n]
         for r in range(self.rj):
+            if only is not None and r != only:
+                continue
             d = self.P + self.PSTR * r + 4 * q
             dst = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
             if "noreload" in self.opts and self.in_loop:
@@ -268,7 +270,18 @@ class Loop:
                 self.read_row_quad(nxt, self.dbl)      # (second copy of that quad: free since row i - 1)
             if q != self.dbl and k == self.last_use[q]:
                 self.read_row_quad(nxt, q)
-            if last and (k % 4 == 3 or k == nb - 1):
+            if last and "spread" in self.opts:
+                # (probe) one reload per plane group instead of four in a row: gene r's quad q after plane 4 q + 3 + r
+                todo = [(q2, r) for q2 in range(self.pq) for r in range(self.rj)
+                        if min(4 * q2 + 3 + r, nb - 1) == k and (4 * q2 + 3 <= k or k == nb - 1)]
+                if k == nb - 1:
+                    todo = [(q2, r) for q2 in range(self.pq) for r in range(self.rj) if 4 * q2 + 3 + r >= nb - 1]
+                if todo:
+                    lab = self.skip_if_last()
+                    for q2, r in todo:
+                        self.load_pos_quad(q2, only=r)
+                    self.e(lab + ":")
+            elif last and (k % 4 == 3 or k == nb - 1):
                 lab = self.skip_if_last()
                 self.load_pos_quad(k // 4)
                 self.e(lab + ":")

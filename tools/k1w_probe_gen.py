@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "rankcompv3.jl_
 from gen_k1_loop import Loop
 
 VARIANTS = [("base", ()), ("wait4", ("wait4",)), ("nowaitvm", ("nowait_vm",)), ("noreload", ("noreload",)), ("nowaitlds", ("nowait_lds",)),
-            ("nowait", ("nowait_lds", "nowait_vm")), ("nolds", ("nolds",)), ("nopop", ("nopop",)), ("lshl", ("lshl",)),
+            ("nowait", ("nowait_lds", "nowait_vm")), ("nolds", ("nolds",)), ("nopop", ("nopop",)), ("lshl", ("lshl",)), ("spread", ("spread",)),
             ("valuonly", ("noreload", "nolds")), ("bitoponly", ("noreload", "nolds", "nopop"))]
 print("typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));")
 for name, opts in VARIANTS:
