@@ -768,6 +768,84 @@ __global__ __launch_bounds__(256) void k1_classify(K1Args a, const uint16_t *__r
     emit_side<RI, RJ>(a, i0, jl, i0 >> 6, lane, 2, a.m2, a.nt - a.m2, nt_of);
 }
 
+// The per-group counts by the wave form (round 3): one wave per workgroup, one item = (tile of 32 rows, 256 genes), the
+// generated count loop of k1w_pairs run once per group (twice with ties: hi planes, then lo planes), the counts of group
+// g written to plane g as they come and summed into the last plane.  Stored counts carry their tie coins (every pair:
+// the classification of a comparison adds counts of several groups, so no coin can be skipped here).
+template <int NB, bool TIES>
+__global__ __launch_bounds__(64, 3) void k1w_group_counts(K1Args a, uint16_t *__restrict__ planes, size_t plane_elems)
+{
+    constexpr int RI = kTileI, RJ = kRJ, NE = TIES ? 2 : 1;
+    __shared__ uint4 ring[2 * RI * 4];
+    const uint32_t item = a.items[blockIdx.x];  // wave chunk << 16 | i-tile
+    const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(item & 0xFFFFu) * RI);
+    const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((item >> 16) & 0x7FFFu) * (64 * RJ));
+    const int lane = threadIdx.x, jl = jw + lane, it = i0 / RI;
+    const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
+    uint32_t tot[RJ * (RI / 2)];   // sums over the groups: two u16 per word (a sum is at most S < 65536); indexed by a loop counter: memory
+    uint32_t park[TIES ? RJ * (RI / 2) : 1];
+#pragma unroll
+    for (int h = 0; h < RJ * (RI / 2); ++h) tot[h] = 0;
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < a.ngroups; ++g) {
+        const int bb = __builtin_amdgcn_readfirstlane(a.goff[g]), be = __builtin_amdgcn_readfirstlane(a.goff[g + 1]);
+        u32x16 gt0 = 0, gt1 = 0, gt2 = 0, gt3 = 0;
+        if (be > bb) {
+            const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * 4 * a.Gp * 16;
+            const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * 64;
+#pragma clang loop unroll(disable)
+            for (int e = 0; e < NE; ++e) {
+                const char *ab = reinterpret_cast<const char *>(e ? a.AL : (TIES ? a.AH : a.AL)) + aoff;
+                k1_loop<NB>(gt0, gt1, gt2, gt3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * 64u,
+                            static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
+                if (TIES && e == 0) {
+#pragma unroll
+                    for (int h = 0; h < RI / 2; ++h) {
+                        park[h] = gt0[h]; park[(TIES ? 1 : 0) * (RI / 2) + h] = gt1[h];
+                        park[(TIES ? 2 : 0) * (RI / 2) + h] = gt2[h]; park[(TIES ? 3 : 0) * (RI / 2) + h] = gt3[h];
+                    }
+                }
+            }
+        } else if (TIES) {
+#pragma unroll
+            for (int h = 0; h < RJ * (RI / 2); ++h) park[h] = 0;
+        }
+        uint16_t *plane = planes + static_cast<size_t>(g) * plane_elems;
+#pragma clang loop unroll(disable)
+        for (int r = 0; r < RJ; ++r) {
+            const int j = jl + 64 * r;
+            uint32_t pk[RI / 2];
+#pragma unroll
+            for (int h = 0; h < RI / 2; ++h) {
+                uint32_t w = gt0[h];
+                if (TIES) {  // n = n_gt + Binomial(n_eq, 1/2), :72-77
+                    const uint32_t w2 = park[r * (RI / 2) + h];
+                    uint32_t n0 = w & 0xFFFFu, n1 = w >> 16;
+                    const uint32_t e0 = (w2 & 0xFFFFu) - n0, e1 = (w2 >> 16) - n1;
+                    if (e0) n0 += tie_wins(a.seed, i0 + 2 * h, j, g, e0);
+                    if (e1) n1 += tie_wins(a.seed, i0 + 2 * h + 1, j, g, e1);
+                    w = n0 | (n1 << 16);
+                }
+                pk[h] = w;
+                tot[r * (RI / 2) + h] += w;  // no carry between the halves: each half-sum stays below 2^16
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4 *>(plane + gc_index(it, q, j, a.Gp)) = uint4{pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]};
+            gt0 = gt1; gt1 = gt2; gt2 = gt3;
+        }
+    }
+    uint16_t *plane = planes + static_cast<size_t>(a.ngroups) * plane_elems;
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < RJ; ++r) {
+        const int j = jl + 64 * r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<uint4 *>(plane + gc_index(it, q, j, a.Gp)) =
+                uint4{tot[r * (RI / 2) + 4 * q], tot[r * (RI / 2) + 4 * q + 1], tot[r * (RI / 2) + 4 * q + 2], tot[r * (RI / 2) + 4 * q + 3]};
+    }
+}
+
 // Parity hook: the raw counts of a block of ordered pairs, one thread per pair, the same borrow chain over the
 // same planes as count_pass (plain loads, no staging: blocks of a few hundred genes).
 __global__ __launch_bounds__(256) void k1_counts(const uint4 *__restrict__ P, const uint4 *__restrict__ AL,
@@ -2645,11 +2723,17 @@ static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool
         }
     } else if (shared) {
         if (!c->gc_valid) {
-            if (c->has_ties) k1_group_counts<NB, true><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+            if (c->k1_wave) {  // one wave per workgroup, the generated count loop, one item per (tile, chunk)
+                const unsigned gridw = static_cast<unsigned>(c->k1_items_n);
+                if (gridw > 0) {
+                    if (c->has_ties) k1w_group_counts<NB, true><<<gridw, 64, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+                    else k1w_group_counts<NB, false><<<gridw, 64, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+                }
+            } else if (c->has_ties) k1_group_counts<NB, true><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
             else k1_group_counts<NB, false><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
             c->gc_valid = true;
         }
-        if (c->has_ties) k1_classify<kRJTies><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+        if (c->has_ties && !c->k1_wave) k1_classify<kRJTies><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
         else k1_classify<kRJ><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
     } else if (multi) {
         if (c->has_ties) k1_pairs<NB, true, true><<<grid, 256, 0, c->stream>>>(a);
@@ -2689,7 +2773,20 @@ int32_t launch_k1(reo_ctx *c, int k)
         return REO_EINVAL;
     }
     const bool wave = (c->k1_wave || big) && !multi && !wide;  // the wave form (two groups): kRJ genes per lane for both families
-    const int RJ = wave ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));  // genes j per lane
+    int32_t rc;
+    // > 2 groups: count every group once, then classify per comparison -- if the planes fit
+    const size_t plane_elems = static_cast<size_t>(c->Gp) * c->Gp;
+    bool shared = multi && c->share_counts && !wide;
+    if (shared && !c->gc_valid) {
+        size_t free_b = 0, total_b = 0;
+        REO_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const size_t need = plane_elems * (c->ngroups + 1) * sizeof(uint16_t);
+        const size_t have = c->gcounts.n * sizeof(uint16_t);
+        if (need > have && need - have + (size_t(4) << 30) > free_b) shared = false;  // keep 4 GiB for everything else
+        if (shared && (rc = c->gcounts.ensure(plane_elems * (c->ngroups + 1)))) return rc;
+    }
+    const bool wcounts = shared && c->k1_wave;  // the per-group counts by the wave form's loop (k1w_group_counts): kRJ genes per lane too
+    const int RJ = (wave || wcounts) ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));  // genes j per lane
     const int CJ = kTileJ * RJ;
     const int NJ = (c->Gp + CJ - 1) / CJ, NIT = c->Gp / kTileI;
     const size_t chunk_bytes = static_cast<size_t>(CJ) * (c->goff32[c->ngroups] / 32) * 64;
@@ -2716,7 +2813,6 @@ int32_t launch_k1(reo_ctx *c, int k)
     c->tiles_owned = owned; c->tiles_total = total;
     c->k1_cj = CJ; c->k1_q = Q;
     a.n_units = static_cast<int>(units.size()); a.Q = Q;
-    int32_t rc;
     if ((rc = c->unit_map.ensure(std::max<size_t>(units.size(), 1)))) return rc;
     if (!units.empty()) {
         REO_HIP_CHECK(hipMemcpyAsync(c->unit_map.p, units.data(), units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -2724,13 +2820,15 @@ int32_t launch_k1(reo_ctx *c, int k)
     }
     a.unit_map = c->unit_map.p;
     a.items = nullptr; a.stamps = nullptr;
-    if (wave) {
+    if (wave || (wcounts && !c->gc_valid)) {
         // item list of the wave form: the owned units in order, side-major, i-tile-major, wave chunks fastest; kept
-        // until the geometry changes
+        // until the geometry changes.  (Group counts: one item per tile and chunk, all groups' blocks.)
         const int CW = 64 * RJ, QW = Q * (CJ / CW);
+        const uint32_t nsides = wave ? 2u : 1u;
         const uint64_t key[4] = {static_cast<uint64_t>(c->G) << 32 | static_cast<uint32_t>(c->Gp), static_cast<uint64_t>(RJ) << 32 | static_cast<uint32_t>(Q),
                                  static_cast<uint64_t>(c->world) << 32 | static_cast<uint32_t>(c->rank),
-                                 static_cast<uint64_t>(units.size()) << 24 | static_cast<uint64_t>(std::max(a.ce - a.cb, a.te - a.tb))};
+                                 static_cast<uint64_t>(nsides) << 56 | static_cast<uint64_t>(units.size()) << 24 |
+                                     static_cast<uint64_t>(wave ? std::max(a.ce - a.cb, a.te - a.tb) : c->goff32[c->ngroups] / 32)};
         if (!c->k1_items.p || std::memcmp(key, c->k1_items_key, sizeof key) != 0) {
             // Workgroup b runs on XCD b & 7.  An item goes to the list of XCD (wave chunk & 7), and an XCD walks its list
             // group by group of its chunks (as many pos chunks of one side as fit about 2.5 MB of its 4 MiB L2), inside a
@@ -2742,11 +2840,11 @@ int32_t launch_k1(reo_ctx *c, int k)
             std::vector<uint32_t> lists[8];
             const int G = static_cast<int>(c->G);
             size_t total_items = 0;
-            const int side_blocks = std::max(a.ce - a.cb, a.te - a.tb);
+            const int side_blocks = wave ? std::max(a.ce - a.cb, a.te - a.tb) : c->goff32[c->ngroups] / 32;
             const size_t chunk_side_bytes = static_cast<size_t>(CW) * std::max(side_blocks, 1) * 64;
             const int per_group = static_cast<int>(std::max<size_t>(1, (size_t(5) << 19) / chunk_side_bytes));  // chunks of one XCD per group
             for (uint32_t um : units)
-                for (uint32_t side = 0; side < 2; ++side)
+                for (uint32_t side = 0; side < nsides; ++side)
                     for (int t = 0; t < kUnitH; ++t)
                         for (int w = 0; w < QW; ++w) {
                             const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + t, cw = static_cast<int>(um >> 16) * QW + w;
@@ -2789,17 +2887,6 @@ int32_t launch_k1(reo_ctx *c, int k)
     REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
     if (units.empty()) return REO_OK;
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
-    // > 2 groups: count every group once, then classify per comparison -- if the planes fit
-    const size_t plane_elems = static_cast<size_t>(c->Gp) * c->Gp;
-    bool shared = multi && c->share_counts && !wide;
-    if (shared && !c->gc_valid) {
-        size_t free_b = 0, total_b = 0;
-        REO_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const size_t need = plane_elems * (c->ngroups + 1) * sizeof(uint16_t);
-        const size_t have = c->gcounts.n * sizeof(uint16_t);
-        if (need > have && need - have + (size_t(4) << 30) > free_b) shared = false;  // keep 4 GiB for everything else
-        if (shared && (rc = c->gcounts.ensure(plane_elems * (c->ngroups + 1)))) return rc;
-    }
     c->last_k1_shared = shared ? 1 : 0;
     tic(c, 1);
     switch (plane_bits(c->G)) {

@@ -135,14 +135,14 @@ def test_gloo_world2_sharded_iteration_matches_unsharded():
 
 
 def test_mirror_geometry_of_the_three_kernel_forms(pkg):
-    """launch_k1's unit geometry depends on which pair kernel it selects (ADVICE, round 2): the wave form (two groups) uses
-    kRJ genes per lane for both data families, the workgroup form kRJ / kRJTies, the wide form (S > 65535) kRJWide /
-    kRJWideTies.  The mirror's constants against the sources, and the chunk widths that follow."""
+    """launch_k1's unit geometry depends on which pair kernel it selects (ADVICE, round 2): the wave form (two groups, and the
+    shared per-group counts of more than two) uses kRJ genes per lane for both data families, the workgroup form kRJ /
+    kRJTies, the wide form (S > 65535) kRJWide / kRJWideTies.  The mirror's constants against the sources, and the chunk widths that follow."""
     src = open(os.path.join(ROOT, "rankcompv3.jl_amd", "csrc", "kernels.hip")).read()
     m = re.search(r"constexpr int kRJWide = (\d+), kRJWideTies = (\d+);", src)
     sh = pkg.sharding
     assert (int(m.group(1)), int(m.group(2))) == (sh.RJ_WIDE, sh.RJ_WIDE_TIES)
-    assert "const int RJ = wave ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));" in src
+    assert "const int RJ = (wave || wcounts) ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));" in src
     for ties in (False, True):
         assert sh.geometry(5000, 208, ties, "wave")[1] == sh.TILE_J * sh.RJ
         assert sh.geometry(5000, 208, ties, "wg")[1] == sh.TILE_J * (sh.RJ_TIES if ties else sh.RJ)
