@@ -773,10 +773,12 @@ __global__ __launch_bounds__(256) void k1_classify(K1Args a, const uint16_t *__r
 // g written to plane g as they come and summed into the last plane.  Stored counts carry their tie coins (every pair:
 // the classification of a comparison adds counts of several groups, so no coin can be skipped here).
 template <int NB, bool TIES>
-__global__ __launch_bounds__(64, 3) void k1w_group_counts(K1Args a, uint16_t *__restrict__ planes, size_t plane_elems)
+__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_group_counts(K1Args a, uint16_t *__restrict__ planes, size_t plane_elems)
 {
     constexpr int RI = kTileI, RJ = kRJ, NE = TIES ? 2 : 1;
-    __shared__ uint4 ring[2 * RI * 4];
+    constexpr bool BIG = NB > 16;
+    constexpr int LQ = BIG ? 5 : 4, ROWB = BIG ? 128 : 64;
+    __shared__ uint4 ring[2 * RI * ROWB / 16];
     const uint32_t item = a.items[blockIdx.x];  // wave chunk << 16 | i-tile
     const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(item & 0xFFFFu) * RI);
     const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((item >> 16) & 0x7FFFu) * (64 * RJ));
@@ -791,12 +793,12 @@ __global__ __launch_bounds__(64, 3) void k1w_group_counts(K1Args a, uint16_t *__
         const int bb = __builtin_amdgcn_readfirstlane(a.goff[g]), be = __builtin_amdgcn_readfirstlane(a.goff[g + 1]);
         u32x16 gt0 = 0, gt1 = 0, gt2 = 0, gt3 = 0;
         if (be > bb) {
-            const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * 4 * a.Gp * 16;
-            const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * 64;
+            const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * LQ * a.Gp * 16;
+            const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * ROWB;
 #pragma clang loop unroll(disable)
             for (int e = 0; e < NE; ++e) {
                 const char *ab = reinterpret_cast<const char *>(e ? a.AL : (TIES ? a.AH : a.AL)) + aoff;
-                k1_loop<NB>(gt0, gt1, gt2, gt3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * 64u,
+                k1_loop<NB>(gt0, gt1, gt2, gt3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * static_cast<uint32_t>(ROWB),
                             static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
                 if (TIES && e == 0) {
 #pragma unroll
@@ -843,6 +845,74 @@ __global__ __launch_bounds__(64, 3) void k1w_group_counts(K1Args a, uint16_t *__
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<uint4 *>(plane + gc_index(it, q, j, a.Gp)) =
                 uint4{tot[r * (RI / 2) + 4 * q], tot[r * (RI / 2) + 4 * q + 1], tot[r * (RI / 2) + 4 * q + 2], tot[r * (RI / 2) + 4 * q + 3]};
+    }
+}
+
+// One comparison of a one-vs-rest run WITHOUT the shared count planes (they did not fit, or REO_SHARE_GROUP_COUNTS=0), wave
+// form: one item = (tile, chunk), the generated loop once per group; the counts of group k stay apart, those of every
+// other group are summed (not = sum(nre) - nre[k], :374), and both sides are classified at the end (:376-377).
+template <int NB, bool TIES>
+__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs_multi(K1Args a)
+{
+    constexpr int RI = kTileI, RJ = kRJ, NE = TIES ? 2 : 1;
+    constexpr bool BIG = NB > 16;
+    constexpr int LQ = BIG ? 5 : 4, ROWB = BIG ? 128 : 64;
+    __shared__ uint4 ring[2 * RI * ROWB / 16];
+    const uint32_t item = a.items[blockIdx.x];  // wave chunk << 16 | i-tile
+    const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(item & 0xFFFFu) * RI);
+    const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((item >> 16) & 0x7FFFu) * (64 * RJ));
+    const int lane = threadIdx.x, jl = jw + lane, bi = i0 >> 6;
+    const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
+    uint32_t nk[RJ * (RI / 2)], tot[RJ * (RI / 2)];   // packed u16 pairs; indexed by loop counters: memory
+    uint32_t park[TIES ? RJ * (RI / 2) : 1];
+#pragma unroll
+    for (int h = 0; h < RJ * (RI / 2); ++h) { nk[h] = 0; tot[h] = 0; }
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < a.ngroups; ++g) {
+        const int bb = __builtin_amdgcn_readfirstlane(a.goff[g]), be = __builtin_amdgcn_readfirstlane(a.goff[g + 1]);
+        if (be <= bb) continue;
+        u32x16 gt0, gt1, gt2, gt3;
+        const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * LQ * a.Gp * 16;
+        const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * ROWB;
+#pragma clang loop unroll(disable)
+        for (int e = 0; e < NE; ++e) {
+            const char *ab = reinterpret_cast<const char *>(e ? a.AL : (TIES ? a.AH : a.AL)) + aoff;
+            k1_loop<NB>(gt0, gt1, gt2, gt3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * static_cast<uint32_t>(ROWB),
+                        static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
+            if (TIES && e == 0) {
+#pragma unroll
+                for (int h = 0; h < RI / 2; ++h) {
+                    park[h] = gt0[h]; park[(TIES ? 1 : 0) * (RI / 2) + h] = gt1[h];
+                    park[(TIES ? 2 : 0) * (RI / 2) + h] = gt2[h]; park[(TIES ? 3 : 0) * (RI / 2) + h] = gt3[h];
+                }
+            }
+        }
+#pragma clang loop unroll(disable)
+        for (int r = 0; r < RJ; ++r) {
+            const int j = jl + 64 * r;
+#pragma unroll
+            for (int h = 0; h < RI / 2; ++h) {
+                uint32_t w = gt0[h];
+                if (TIES) {  // the coins are keyed by group (:72-77): every group's count carries its own
+                    const uint32_t w2 = park[r * (RI / 2) + h];
+                    uint32_t n0 = w & 0xFFFFu, n1 = w >> 16;
+                    const uint32_t e0 = (w2 & 0xFFFFu) - n0, e1 = (w2 >> 16) - n1;
+                    if (e0) n0 += tie_wins(a.seed, i0 + 2 * h, j, g, e0);
+                    if (e1) n1 += tie_wins(a.seed, i0 + 2 * h + 1, j, g, e1);
+                    w = n0 | (n1 << 16);
+                }
+                if (g == a.gc) nk[r * (RI / 2) + h] = w; else tot[r * (RI / 2) + h] += w;  // (no carry between the halves: sums stay below 2^16)
+            }
+            gt0 = gt1; gt1 = gt2; gt2 = gt3;
+        }
+    }
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < RJ; ++r) {
+        uint32_t ck[RI / 2], ct[RI / 2];
+#pragma unroll
+        for (int h = 0; h < RI / 2; ++h) { ck[h] = nk[r * (RI / 2) + h]; ct[h] = tot[r * (RI / 2) + h]; }
+        emit_gene<RI, true>(a, i0, jl + 64 * r, bi, lane, 0, a.m1, a.nc - a.m1, [&](int ii) { return static_cast<int>((ii & 1) ? (ck[ii >> 1] >> 16) : (ck[ii >> 1] & 0xFFFFu)); });
+        emit_gene<RI, true>(a, i0, jl + 64 * r, bi, lane, 2, a.m2, a.nt - a.m2, [&](int ii) { return static_cast<int>((ii & 1) ? (ct[ii >> 1] >> 16) : (ct[ii >> 1] & 0xFFFFu)); });
     }
 }
 
@@ -2700,13 +2770,28 @@ __global__ __launch_bounds__(256) void x_expand_mirror(XArgs a, const uint32_t *
 // bits needed for every number the pair kernel compares: positions 0..G-1 and band ends up to G
 static int plane_bits(int64_t G) { return G <= 4095 ? 12 : (G <= 32767 ? 15 : (G <= 65535 ? 16 : (G <= 131071 ? 17 : 18))); }
 
-// the wave form with more than 16 planes (more than 65 535 genes): two groups, at most 65 535 samples only
+// the wave form with more than 16 planes (more than 65 535 genes; at most 65 535 samples): only the wave kernels have a loop for them
 template <int NB>
-static void launch_big_pairs(reo_ctx *c, const K1Args &a)
+static void launch_big_pairs(reo_ctx *c, const K1Args &a, bool shared, bool multi, size_t plane_elems)
 {
     const unsigned gridw = static_cast<unsigned>(c->k1_items_n);
+    if (shared) {
+        if (!c->gc_valid) {
+            if (gridw > 0) {
+                if (c->has_ties) k1w_group_counts<NB, true><<<gridw, 64, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+                else k1w_group_counts<NB, false><<<gridw, 64, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+            }
+            c->gc_valid = true;
+        }
+        const unsigned grid = static_cast<unsigned>((a.n_units + 7) / 8 * 8 * kUnitH * a.Q);
+        k1_classify<kRJ><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+        return;
+    }
     if (gridw == 0) return;
-    if (c->has_ties) k1w_pairs<NB, true><<<gridw, 64, 0, c->stream>>>(a);
+    if (multi) {
+        if (c->has_ties) k1w_pairs_multi<NB, true><<<gridw, 64, 0, c->stream>>>(a);
+        else k1w_pairs_multi<NB, false><<<gridw, 64, 0, c->stream>>>(a);
+    } else if (c->has_ties) k1w_pairs<NB, true><<<gridw, 64, 0, c->stream>>>(a);
     else k1w_pairs<NB, false><<<gridw, 64, 0, c->stream>>>(a);
 }
 
@@ -2735,6 +2820,11 @@ static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool
         }
         if (c->has_ties && !c->k1_wave) k1_classify<kRJTies><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
         else k1_classify<kRJ><<<grid, 256, 0, c->stream>>>(a, c->gcounts.p, plane_elems);
+    } else if (multi && c->k1_wave) {  // a comparison recounted, wave form
+        const unsigned gridw = static_cast<unsigned>(c->k1_items_n);
+        if (gridw == 0) return;
+        if (c->has_ties) k1w_pairs_multi<NB, true><<<gridw, 64, 0, c->stream>>>(a);
+        else k1w_pairs_multi<NB, false><<<gridw, 64, 0, c->stream>>>(a);
     } else if (multi) {
         if (c->has_ties) k1_pairs<NB, true, true><<<grid, 256, 0, c->stream>>>(a);
         else k1_pairs<NB, false, true><<<grid, 256, 0, c->stream>>>(a);
@@ -2768,8 +2858,8 @@ int32_t launch_k1(reo_ctx *c, int k)
     // panel's pos planes (Q x 256 RJ genes x nblk blocks x 64 B) within about 2 MiB of the 4 MiB L2 of an XCD.
     const bool wide = c->S > 65535;  // a count may not fit 16 bits: the unpacked form of the pair loop
     const bool big = c->G > 65535;    // more than 16 position planes: only the wave form has a loop for them
-    if (big && (multi || wide)) {
-        set_error("more than 65535 genes: two groups and at most 65535 samples only (the one-vs-rest and the wide pair kernels read the 16-plane layout)");
+    if (big && wide) {
+        set_error("more than 65535 genes: at most 65535 samples (the wide pair kernels read the 16-plane layout)");
         return REO_EINVAL;
     }
     const bool wave = (c->k1_wave || big) && !multi && !wide;  // the wave form (two groups): kRJ genes per lane for both families
@@ -2785,8 +2875,9 @@ int32_t launch_k1(reo_ctx *c, int k)
         if (need > have && need - have + (size_t(4) << 30) > free_b) shared = false;  // keep 4 GiB for everything else
         if (shared && (rc = c->gcounts.ensure(plane_elems * (c->ngroups + 1)))) return rc;
     }
-    const bool wcounts = shared && c->k1_wave;  // the per-group counts by the wave form's loop (k1w_group_counts): kRJ genes per lane too
-    const int RJ = (wave || wcounts) ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));  // genes j per lane
+    const bool wcounts = shared && (c->k1_wave || big);  // the per-group counts by the wave form's loop (k1w_group_counts): kRJ genes per lane too
+    const bool wmulti = multi && !shared && !wide && (c->k1_wave || big);  // a comparison recounted by the wave form (k1w_pairs_multi)
+    const int RJ = (wave || wcounts || wmulti) ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));  // genes j per lane
     const int CJ = kTileJ * RJ;
     const int NJ = (c->Gp + CJ - 1) / CJ, NIT = c->Gp / kTileI;
     const size_t chunk_bytes = static_cast<size_t>(CJ) * (c->goff32[c->ngroups] / 32) * 64;
@@ -2820,7 +2911,7 @@ int32_t launch_k1(reo_ctx *c, int k)
     }
     a.unit_map = c->unit_map.p;
     a.items = nullptr; a.stamps = nullptr;
-    if (wave || (wcounts && !c->gc_valid)) {
+    if (wave || (wcounts && !c->gc_valid) || wmulti) {
         // item list of the wave form: the owned units in order, side-major, i-tile-major, wave chunks fastest; kept
         // until the geometry changes.  (Group counts: one item per tile and chunk, all groups' blocks.)
         const int CW = 64 * RJ, QW = Q * (CJ / CW);
@@ -2893,8 +2984,8 @@ int32_t launch_k1(reo_ctx *c, int k)
     case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems, wide); break;
     case 15: launch_pair_kernels<15>(c, a, grid, shared, multi, plane_elems, wide); break;
     case 16: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems, wide); break;
-    case 17: launch_big_pairs<17>(c, a); break;   // (reo_set_groups / set_matrix admit such gene counts only where the wave form runs)
-    default: launch_big_pairs<18>(c, a); break;
+    case 17: launch_big_pairs<17>(c, a, shared, multi, plane_elems); break;
+    default: launch_big_pairs<18>(c, a, shared, multi, plane_elems); break;
     }
     toc(c);
     REO_HIP_CHECK(hipGetLastError());

@@ -880,18 +880,28 @@ def test_more_than_65535_genes(pkg, oracle, G, S, family, n_iter):
     _check_result(res, exp)
 
 
-def test_gene_count_limits(pkg):
-    """G <= 262 143 (18 position planes); above 65 535 genes only two groups and at most 65 535 samples."""
+def test_gene_count_limits(pkg, oracle, monkeypatch):
+    """G <= 262 143 (18 position planes).  Above 65 535 genes one-vs-rest works too (the wave kernels have loops for 17 / 18
+    planes; with the count planes shared, or recounted per comparison); only more than 65 535 samples are refused there."""
     rng = np.random.default_rng(1)
     with pkg.Context(device=0, seed=1) as ctx:
         with pytest.raises(pkg.ReoError):
             ctx.set_matrix(np.zeros((262144, 2), dtype=np.int64))
-        X = rng.integers(0, 1000, size=(66000, 6))
-        ctx.set_matrix(X)
-        ctx.set_groups(np.array([0, 1, 2, 0, 1, 2], dtype=np.int32), 3)
-        ctx.compute_thresholds(0.5)
-        with pytest.raises(pkg.ReoError, match="two groups"):
-            ctx.build_pairs(0)
+    G, S, seed = 66000, 9, 0x5EED0067
+    X = rng.integers(0, 1000, size=(G, S))
+    gid = np.array([0, 1, 2, 0, 1, 2, 0, 1, 2], dtype=np.int32)
+    Xf = np.asfortranarray(X.astype(np.float64))
+    for share in ("1", "0"):
+        monkeypatch.setenv("REO_SHARE_GROUP_COUNTS", share)
+        with pkg.Context(device=0, seed=seed) as ctx:
+            ctx.set_matrix(X); ctx.set_groups(gid, 3)
+            thr = ctx.compute_thresholds(0.5)
+            for k in (1, 0):
+                ctx.build_pairs(k)
+                assert ctx.info()["shared_group_counts"] == int(share)
+                for (i0, j0, n) in [(0, G - 40, 40), (65520, 65520, 40), (100, 65530, 32), (G - 33, 17, 32)]:
+                    exp = _expected_block_codes(oracle, Xf, gid, thr, seed, i0, i0 + n, j0, j0 + n, ngroups=3, k=k)
+                    assert np.array_equal(ctx.get_codes(i0, i0 + n, j0, j0 + n), exp), (share, k, i0, j0)
 
 
 @pytest.mark.parametrize("case", ["two_samples", "one_vs_nine", "empty_ref", "full_ref", "g11", "constant", "one_group_all_ties"])
