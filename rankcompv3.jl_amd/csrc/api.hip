@@ -511,7 +511,6 @@ int32_t reo_pair_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t 
     if (rc) return rc;
     if ((rc = ensure_transform(c))) return rc;
     if (c->S > 65535) { set_error("reo_pair_counts returns 16-bit counts: not available with more than 65535 samples"); return REO_EINVAL; }
-    if (c->G > 65535) { set_error("reo_pair_counts reads the 16-plane layout: not available with more than 65535 genes (reo_get_codes is)"); return REO_EINVAL; }
     if (!n_gt || !n_eq || i0 < 0 || j0 < 0 || i1 > c->G || j1 > c->G || i0 >= i1 || j0 >= j1) {
         set_error("bad pair block [%lld,%lld) x [%lld,%lld)", (long long)i0, (long long)i1, (long long)j0, (long long)j1);
         return REO_EINVAL;

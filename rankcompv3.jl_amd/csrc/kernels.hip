@@ -952,6 +952,43 @@ __global__ __launch_bounds__(256) void k1_counts(const uint4 *__restrict__ P, co
     }
 }
 
+// The same on the big plane layout (more than 65 535 genes: five pos quads, edge rows of 8 uint4, plane k in word k).
+__global__ __launch_bounds__(256) void k1_counts_big(const uint4 *__restrict__ P, const uint4 *__restrict__ AL,
+                                                     const uint4 *__restrict__ AH, int Gp, int nbits,
+                                                     const int32_t *__restrict__ goff, int ngroups, int ci0, int ci1, int cj0, int cj1,
+                                                     uint16_t *__restrict__ out_gt, uint16_t *__restrict__ out_eq)
+{
+    const int j = cj0 + blockIdx.x * 256 + threadIdx.x, i = ci0 + blockIdx.y;
+    if (j >= cj1 || i >= ci1) return;
+    const int nj = cj1 - cj0;
+    for (int g = 0; g < ngroups; ++g) {
+        uint32_t n_gt = 0, n_ge = 0;
+        for (int b = goff[g]; b < goff[g + 1]; ++b) {
+            uint32_t p[20], lo[20], hi[20];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const uint4 pv = P[(static_cast<size_t>(b) * 5 + q) * Gp + j];
+                const uint4 lv = AL[(static_cast<size_t>(b) * Gp + i) * 8 + q], hv = AH[(static_cast<size_t>(b) * Gp + i) * 8 + q];
+                p[4 * q] = pv.x; p[4 * q + 1] = pv.y; p[4 * q + 2] = pv.z; p[4 * q + 3] = pv.w;
+                lo[4 * q] = lv.x; lo[4 * q + 1] = lv.y; lo[4 * q + 2] = lv.z; lo[4 * q + 3] = lv.w;
+                hi[4 * q] = hv.x; hi[4 * q + 1] = hv.y; hi[4 * q + 2] = hv.z; hi[4 * q + 3] = hv.w;
+            }
+            uint32_t lt = 0, le = 0;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) {
+                if (k >= nbits) break;
+                lt = __builtin_amdgcn_bitop3_b32(p[k], lo[k], lt, 0x8e);
+                le = __builtin_amdgcn_bitop3_b32(p[k], hi[k], le, 0x8e);
+            }
+            n_gt += __builtin_popcount(lt);
+            n_ge += __builtin_popcount(le);
+        }
+        const size_t o = (static_cast<size_t>(i - ci0) * nj + (j - cj0)) * ngroups + g;
+        out_gt[o] = static_cast<uint16_t>(n_gt);
+        out_eq[o] = static_cast<uint16_t>(n_ge - n_gt);
+    }
+}
+
 // Parity hook: decode the bit planes of a block into class codes 0..8.
 __global__ void k_decode(const uint32_t *__restrict__ table, int Wp, int i0, int i1, int j0, int j1,
                          uint8_t *__restrict__ code)
@@ -3054,8 +3091,12 @@ int32_t launch_expand_units(reo_ctx *c)
 int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq)
 {
     dim3 grid(static_cast<unsigned>((j1 - j0 + 255) / 256), static_cast<unsigned>(i1 - i0));
-    k1_counts<<<grid, 256, 0, c->stream>>>(c->pos.p, c->lo.p, c->hi.p, c->Gp, plane_bits(c->G), c->goff_dev.p, c->ngroups,
-                                           static_cast<int>(i0), static_cast<int>(i1), static_cast<int>(j0), static_cast<int>(j1), d_gt, d_eq);
+    if (c->G > 65535)
+        k1_counts_big<<<grid, 256, 0, c->stream>>>(c->pos.p, c->lo.p, c->hi.p, c->Gp, plane_bits(c->G), c->goff_dev.p, c->ngroups,
+                                                   static_cast<int>(i0), static_cast<int>(i1), static_cast<int>(j0), static_cast<int>(j1), d_gt, d_eq);
+    else
+        k1_counts<<<grid, 256, 0, c->stream>>>(c->pos.p, c->lo.p, c->hi.p, c->Gp, plane_bits(c->G), c->goff_dev.p, c->ngroups,
+                                               static_cast<int>(i0), static_cast<int>(i1), static_cast<int>(j0), static_cast<int>(j1), d_gt, d_eq);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

@@ -873,8 +873,10 @@ def test_more_than_65535_genes(pkg, oracle, G, S, family, n_iter):
         cont = ctx.tally(ref0)
         assert np.array_equal(cont.sum(axis=1), ref0.sum() - ref0.astype(np.int64)) and cont.min() >= 0
         res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, n_iter, 3)
-        with pytest.raises(pkg.ReoError):
-            ctx.pair_counts(0, 8, 0, 8)                           # the debug hook reads the 16-plane layout
+        for (i0, i1, j0, j1) in [(0, 24, G - 40, G), (65530, 65560, 65500, 65580)]:
+            gt, eq = ctx.pair_counts(i0, i1, j0, j1)              # the raw counts (deterministic part) on the big plane layout
+            egt, eeq = oracle.pair_counts(Xf, gid, 2, i0, i1, j0, j1)
+            assert np.array_equal(gt, egt) and np.array_equal(eq, eeq)
     exp, eit, etr = oracle.identify_degs(Xf, gid, 2, 0.05, 1.0, 0.05, ref0, n_iter, 3, seed)
     assert iters == eit and trace == etr, (iters, eit, trace, etr)
     _check_result(res, exp)
