@@ -124,8 +124,8 @@ static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64
     int32_t rc = use(c);
     if (rc) return rc;
     if (!X) { set_error("matrix pointer is null"); return REO_EINVAL; }
-    if (G < 2 || G > kMaxGenes || S < 2 || S > (1 << 20) || (G > 65535 && S > 65535)) {
-        set_error("matrix is %lld x %lld; G must be in [2, %d] and S in [2, 1048576] (S <= 65535 when G > 65535)", (long long)G, (long long)S, kMaxGenes);
+    if (G < 2 || G > kMaxGenes || S < 2 || S > (1 << 20)) {
+        set_error("matrix is %lld x %lld; G must be in [2, %d] and S in [2, 1048576]", (long long)G, (long long)S, kMaxGenes);
         return REO_EINVAL;
     }
     if (ld < G) { set_error("leading dimension %lld < G = %lld", (long long)ld, (long long)G); return REO_EINVAL; }

@@ -768,6 +768,68 @@ __global__ __launch_bounds__(256) void k1_classify(K1Args a, const uint16_t *__r
     emit_side<RI, RJ>(a, i0, jl, i0 >> 6, lane, 2, a.m2, a.nt - a.m2, nt_of);
 }
 
+// More than 65 535 samples (single-cell mode without pseudo-bulking, :608-616), wave form: a side's blocks in runs of at most
+// 2 047 (65 504 samples: the packed 16-bit counts of the loop cannot overflow inside a run), the runs' counts added into
+// 32-bit totals that wait in the private segment; classification from the totals.  Two groups.
+constexpr int kWideRun = 2047;  // 32-sample blocks per run of the count loop
+
+template <int NB, bool TIES>
+__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs_wide(K1Args a)
+{
+    constexpr int RI = kTileI, RJ = kRJ, NE = TIES ? 2 : 1;
+    constexpr bool BIG = NB > 16;
+    constexpr int LQ = BIG ? 5 : 4, ROWB = BIG ? 128 : 64;
+    __shared__ uint4 ring[2 * RI * ROWB / 16];
+    const uint32_t item = a.items[blockIdx.x];  // side << 31 | wave chunk << 16 | i-tile
+    const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(item & 0xFFFFu) * RI);
+    const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((item >> 16) & 0x7FFFu) * (64 * RJ));
+    const int side = __builtin_amdgcn_readfirstlane(static_cast<int>(item >> 31));
+    const int lane = threadIdx.x, jl = jw + lane, bi = i0 >> 6;
+    const int bb = side ? a.tb : a.cb, be = side ? a.te : a.ce;
+    const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
+    uint32_t tgt[RJ * RI], tge[TIES ? RJ * RI : 1];   // 32-bit totals of n_gt (n_ge); indexed by loop counters: memory
+#pragma unroll
+    for (int h = 0; h < RJ * RI; ++h) { tgt[h] = 0; if (TIES) tge[h] = 0; }
+#pragma clang loop unroll(disable)
+    for (int c0 = bb; c0 < be; c0 += kWideRun) {
+        const int nrun = min(kWideRun, be - c0);
+        const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(c0) * LQ * a.Gp * 16;
+        const size_t aoff = (static_cast<size_t>(c0) * a.Gp + i0) * ROWB;
+#pragma clang loop unroll(disable)
+        for (int e = 0; e < NE; ++e) {
+            const char *ab = reinterpret_cast<const char *>(e ? a.AL : (TIES ? a.AH : a.AL)) + aoff;  // ties: hi (n_ge) first, lo (n_gt) last
+            u32x16 c[4];
+            k1_loop<NB>(c[0], c[1], c[2], c[3], pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * static_cast<uint32_t>(ROWB),
+                        static_cast<uint32_t>(nrun), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
+            uint32_t *dst = (TIES && e == 0) ? tge : tgt;
+#pragma unroll
+            for (int r = 0; r < RJ; ++r)
+#pragma unroll
+                for (int h = 0; h < RI / 2; ++h) {
+                    dst[r * RI + 2 * h] += c[r][h] & 0xFFFFu;
+                    dst[r * RI + 2 * h + 1] += c[r][h] >> 16;
+                }
+        }
+    }
+    const int g = side ? a.gt : a.gc;
+    const int m = side ? a.m2 : a.m1, n = side ? a.nt : a.nc;
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < RJ; ++r) {
+        uint32_t cg[RI], ce[TIES ? RI : 1];
+#pragma unroll
+        for (int ii = 0; ii < RI; ++ii) { cg[ii] = tgt[r * RI + ii]; if (TIES) ce[ii] = tge[r * RI + ii]; }
+        emit_gene<RI, true>(a, i0, jl + 64 * r, bi, lane, side ? 2 : 0, m, n - m, [&](int ii) {
+            int nre = static_cast<int>(cg[ii]);
+            if (TIES) {  // coins only where they can change the class (as in k1w_pairs)
+                const int nge = static_cast<int>(ce[ii]);
+                const bool amb = (nre < m && nge >= m) || (nre <= n - m && nge > n - m);
+                if (amb) nre += tie_wins(a.seed, i0 + ii, jl + 64 * r, g, static_cast<uint32_t>(nge - nre));
+            }
+            return nre;
+        });
+    }
+}
+
 // The per-group counts by the wave form (round 3): one wave per workgroup, one item = (tile of 32 rows, 256 genes), the
 // generated count loop of k1w_pairs run once per group (twice with ties: hi planes, then lo planes), the counts of group
 // g written to plane g as they come and summed into the last plane.  Stored counts carry their tie coins (every pair:
@@ -2809,9 +2871,15 @@ static int plane_bits(int64_t G) { return G <= 4095 ? 12 : (G <= 32767 ? 15 : (G
 
 // the wave form with more than 16 planes (more than 65 535 genes; at most 65 535 samples): only the wave kernels have a loop for them
 template <int NB>
-static void launch_big_pairs(reo_ctx *c, const K1Args &a, bool shared, bool multi, size_t plane_elems)
+static void launch_big_pairs(reo_ctx *c, const K1Args &a, bool shared, bool multi, size_t plane_elems, bool wide)
 {
     const unsigned gridw = static_cast<unsigned>(c->k1_items_n);
+    if (wide) {  // (two groups: launch_k1 refuses the rest)
+        if (gridw == 0) return;
+        if (c->has_ties) k1w_pairs_wide<NB, true><<<gridw, 64, 0, c->stream>>>(a);
+        else k1w_pairs_wide<NB, false><<<gridw, 64, 0, c->stream>>>(a);
+        return;
+    }
     if (shared) {
         if (!c->gc_valid) {
             if (gridw > 0) {
@@ -2839,6 +2907,11 @@ static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool
         if (multi) {
             if (c->has_ties) k1_pairs_wide<NB, true, true><<<grid, 256, 0, c->stream>>>(a);
             else k1_pairs_wide<NB, false, true><<<grid, 256, 0, c->stream>>>(a);
+        } else if (c->k1_wave) {  // wave form: the count loop in runs of 2 047 blocks, 32-bit totals
+            const unsigned gridw = static_cast<unsigned>(c->k1_items_n);
+            if (gridw == 0) return;
+            if (c->has_ties) k1w_pairs_wide<NB, true><<<gridw, 64, 0, c->stream>>>(a);
+            else k1w_pairs_wide<NB, false><<<gridw, 64, 0, c->stream>>>(a);
         } else {
             if (c->has_ties) k1_pairs_wide<NB, true, false><<<grid, 256, 0, c->stream>>>(a);
             else k1_pairs_wide<NB, false, false><<<grid, 256, 0, c->stream>>>(a);
@@ -2890,11 +2963,11 @@ int32_t launch_k1(reo_ctx *c, int k)
     // panel's pos planes (Q x 256 RJ genes x nblk blocks x 64 B) within about 2 MiB of the 4 MiB L2 of an XCD.
     const bool wide = c->S > 65535;  // a count may not fit 16 bits: the unpacked form of the pair loop
     const bool big = c->G > 65535;    // more than 16 position planes: only the wave form has a loop for them
-    if (big && wide) {
-        set_error("more than 65535 genes: at most 65535 samples (the wide pair kernels read the 16-plane layout)");
+    if (big && wide && multi) {
+        set_error("more than 65535 genes and more than 65535 samples: two groups only (the one-vs-rest wide kernel reads the 16-plane layout)");
         return REO_EINVAL;
     }
-    const bool wave = (c->k1_wave || big) && !multi && !wide;  // the wave form (two groups): kRJ genes per lane for both families
+    const bool wave = (c->k1_wave || big) && !multi;  // the wave form (two groups; also more than 65 535 samples: k1w_pairs_wide): kRJ genes per lane
     int32_t rc;
     // > 2 groups: count every group once, then classify per comparison -- if the planes fit
     const size_t plane_elems = static_cast<size_t>(c->Gp) * c->Gp;
@@ -3017,8 +3090,8 @@ int32_t launch_k1(reo_ctx *c, int k)
     case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems, wide); break;
     case 15: launch_pair_kernels<15>(c, a, grid, shared, multi, plane_elems, wide); break;
     case 16: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems, wide); break;
-    case 17: launch_big_pairs<17>(c, a, shared, multi, plane_elems); break;
-    default: launch_big_pairs<18>(c, a, shared, multi, plane_elems); break;
+    case 17: launch_big_pairs<17>(c, a, shared, multi, plane_elems, wide); break;
+    default: launch_big_pairs<18>(c, a, shared, multi, plane_elems, wide); break;
     }
     toc(c);
     REO_HIP_CHECK(hipGetLastError());

@@ -29,8 +29,9 @@ GENE_PAD = 1024 # kGenePad
 SLOT_PAD = 32   # sample slots per block of the bit planes
 
 
-FORM = "wave"   # which pair kernel launch_k1 selects: "wave" (S <= 65535: two groups, or more with shared per-group counts -- the
-                # default), "wg" (the workgroup form: per-comparison recounts of more than two groups, or REO_K1_WAVE=0), "wide" (S > 65535)
+FORM = "wave"   # which pair kernel launch_k1 selects: "wave" (two groups; more with shared per-group counts when S <= 65535 -- the
+                # default), "wg" (the workgroup form: per-comparison recounts of more than two groups, or REO_K1_WAVE=0), "wide"
+                # (the workgroup form for S > 65535: more than two groups, or REO_K1_WAVE=0)
 
 
 def genes_per_lane(has_ties: bool, form: str | None = None) -> int:

@@ -1149,12 +1149,15 @@ def test_sorting_passes_only_and_large_cuts_at_a_size_that_uses_light_passes(pkg
         assert np.allclose(r1[ok][:, :2], r0[ok][:, :2], rtol=0, atol=P_ATOL)
 
 
-@pytest.mark.parametrize("family,ngroups", [("t1", 2), ("t0", 2), ("float", 2), ("t1", 3)])
+@pytest.mark.parametrize("family,ngroups", [("t1", 2), ("t0", 2), ("float", 2), ("t1", 3), ("t1", -2), ("t0", -2)])
 def test_more_than_65535_samples(pkg, oracle, family, ngroups):
     """Single-cell mode without pseudo-bulking (src/RankCompV3.jl:608-616 with n_pseudo = 0) can hand over more samples
-    than a 16-bit count holds: the wide form of the pair kernel (32-bit counts).  66 100 samples, the whole run."""
+    than a 16-bit count holds: the wide forms of the pair kernel (two groups: the count loop in runs of 2 047 blocks with
+    32-bit totals; more groups: the workgroup form with 32-bit counts).  66 100 samples, the whole run; ngroups = -2: one
+    group of 66 000 samples, i.e. a side of more than one run."""
     G, seed = 260, 0x5EED0091
-    sizes = [33100, 33000] if ngroups == 2 else [33000, 33040, 60]
+    sizes = [33100, 33000] if ngroups == 2 else ([66000, 100] if ngroups == -2 else [33000, 33040, 60])
+    ngroups = abs(ngroups)
     S = sum(sizes)
     gen = {"t0": pkg.synth.t0_ranks, "t1": pkg.synth.t1_counts, "float": pkg.synth.float_expr}[family]
     X = gen(G, S, seed)
