@@ -111,7 +111,7 @@ int32_t reo_set_allgather(reo_ctx *ctx, reo_allgather_fn fn, void *user);
 /* Expression matrix, G genes x S samples, column-major with leading dimension
  * ld >= G: the `data` argument of identify_degs (src/RankCompV3.jl:340) as
  * Matrix(df_expr) produces it (:652), eltype Float64 or Int64.  G must be in [2, 262143] and S in [2, 1048576];
- * above 65535 genes at most 65535 samples are served; values must be finite.  *_host copies from host memory;
+ * with more than two groups G and S may not both exceed 65535; values must be finite.  *_host copies from host memory;
  * *_dev uses a buffer already resident in HBM (it must stay valid until
  * reo_build_pairs returns). */
 int32_t reo_set_matrix_f64(reo_ctx *ctx, const double *X, int64_t G, int64_t S, int64_t ld);

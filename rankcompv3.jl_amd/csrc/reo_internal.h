@@ -18,7 +18,7 @@ constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kUnitH = 32;    // i-tiles per K1 work unit
 constexpr int kRJ = 4;        // genes j per lane in the tie-free pair kernel
 constexpr int kRJTies = 2;    // genes j per lane in the tie-rich pair kernel (two band edges per pair)
-constexpr int kMaxGenes = 262143;  // 18 position planes; above 65 535 genes: at most 65 535 samples, sorting passes only
+constexpr int kMaxGenes = 262143;  // 18 position planes; above 65 535 genes: sorting passes only
 constexpr int kGenePad = 1024;  // Gp is a multiple of this (= kTileJ * kRJ: every lane's genes exist)
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
 constexpr int kDeltaMax = 128;   // at most this many changed reference genes: update the tallies incrementally
