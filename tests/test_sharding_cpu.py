@@ -142,7 +142,7 @@ def test_mirror_geometry_of_the_three_kernel_forms(pkg):
     m = re.search(r"constexpr int kRJWide = (\d+), kRJWideTies = (\d+);", src)
     sh = pkg.sharding
     assert (int(m.group(1)), int(m.group(2))) == (sh.RJ_WIDE, sh.RJ_WIDE_TIES)
-    assert "const int RJ = (wave || wcounts) ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));" in src
+    assert "const int RJ = (wave || wcounts || wmulti) ? kRJ : (wide ? (c->has_ties ? kRJWideTies : kRJWide) : (c->has_ties ? kRJTies : kRJ));" in src
     for ties in (False, True):
         assert sh.geometry(5000, 208, ties, "wave")[1] == sh.TILE_J * sh.RJ
         assert sh.geometry(5000, 208, ties, "wg")[1] == sh.TILE_J * (sh.RJ_TIES if ties else sh.RJ)
