@@ -791,6 +791,57 @@ def test_randomized_sweep_against_oracle(pkg, oracle):
     assert len(kinds) == 5
 
 
+def test_one_context_through_many_problems(pkg, oracle):
+    """A context is reused the way a long-lived caller would: problems of different sizes, element types, tie structure and
+    group layouts one after the other (buffers grow and are kept, the cached item list / transform / table of the previous
+    problem must never leak into the next), small -> large -> small, across the size where the light passes start, and
+    the first problem once more at the end."""
+    rng = np.random.default_rng(424242)
+    seed = 0x5EED0123
+    sizes = [(300, 3), (5000, 2), (40, 2), (9000, 2), (700, 4), (5000, 2), (12, 2), (2600, 3)]
+    problems = []
+    for G, ng in sizes:
+        per = rng.integers(3, 20, size=ng)
+        S = int(per.sum())
+        gid = np.concatenate([[g] * int(n) for g, n in enumerate(per)]).astype(np.int32)
+        if rng.random() < 0.5:
+            gid = gid[rng.permutation(S)]
+        gid, _ = pkg.encode_groups([f"grp{g}" for g in gid])   # ids in order of first appearance (unique(), :353)
+        kind = str(rng.choice(["small_int", "ranks", "float_band", "wide_int"]))
+        if kind == "small_int":
+            X = rng.integers(0, 9, size=(G, S))
+        elif kind == "ranks":
+            X = np.argsort(np.argsort(rng.random((G, S)), axis=0), axis=0)
+        elif kind == "float_band":
+            X = np.round(rng.normal(5, 1.0, size=(G, S)), 1) + rng.choice([0.0, 0.04, 0.099, 0.1], size=(G, S))
+        else:
+            X = rng.integers(-50000, 50000, size=(G, S))
+        problems.append(dict(G=G, S=S, ng=ng, gid=gid, X=X, kind=kind, ref0=pkg.synth.ref_mask(G, int(rng.integers(3, G)), seed),
+                             n_iter=int(rng.integers(1, 12)), n_conv=int(rng.choice([0, 5])), pval=float(rng.choice([0.01, 0.05]))))
+    problems.append(problems[0])
+    first = None
+    with pkg.Context(device=0, seed=seed) as ctx:
+        for no, pr in enumerate(problems):
+            tag = (no, pr["kind"], pr["G"], pr["S"], pr["ng"])
+            ctx.set_matrix(pr["X"])
+            ctx.set_groups(pr["gid"], pr["ng"])
+            ctx.compute_thresholds(pr["pval"])
+            Xf = np.asarray(pr["X"], dtype=np.float64)
+            for k in (range(pr["ng"]) if pr["ng"] > 2 else [0]):
+                ctx.build_pairs(k)
+                res, iters, trace = ctx.identify_degs(pr["ref0"], 1.0, 0.05, pr["n_iter"], pr["n_conv"])
+                exp, eit, etr = oracle.identify_degs(Xf, pr["gid"], pr["ng"], pr["pval"], 1.0, 0.05, pr["ref0"], pr["n_iter"], pr["n_conv"], seed, k=k)
+                assert iters == eit and trace == etr, tag
+                assert np.array_equal(res[:, 2:11], exp[:, 2:11]), tag
+                ok = np.isfinite(exp).all(axis=1)
+                assert np.allclose(res[ok][:, :2], exp[ok][:, :2], rtol=0, atol=P_ATOL), tag
+                assert np.allclose(res[ok][:, 11:], exp[ok][:, 11:], rtol=STAT_RTOL, atol=1e-9), tag
+                if no == 0 and k == 0:
+                    first = res.copy()
+                if no == len(problems) - 1 and k == 0:
+                    assert np.array_equal(res, first, equal_nan=True), "the same problem on the same context gave a different result the second time"
+
+
 def test_maximum_gene_count_65535(pkg, oracle):
     """G = 65535 (the u16 position limit), S = 16: sampled pair blocks and the mirror rule at full size."""
     G, S, seed = 65535, 16, 77
