@@ -842,6 +842,42 @@ def test_one_context_through_many_problems(pkg, oracle):
                     assert np.array_equal(res, first, equal_nan=True), "the same problem on the same context gave a different result the second time"
 
 
+def test_contexts_in_concurrent_host_threads(pkg, oracle):
+    """Three callers, each with its own context on the same device, running at the same time (ctypes drops the GIL during a
+    call): contexts share nothing but the device and the per-device self-test verdict; reo_last_error is per thread."""
+    import threading
+    seed = 77
+    jobs = []
+    for t, (G, S, fam) in enumerate([(5200, 40, "t1"), (4700, 56, "t0"), (900, 30, "float")]):
+        X = {"t0": pkg.synth.t0_ranks, "t1": pkg.synth.t1_counts, "float": pkg.synth.float_expr}[fam](G, S, seed + t)
+        gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+        jobs.append(dict(X=X, gid=gid, ng=len(lev), ref0=pkg.synth.ref_mask(G, 200, seed + t), out=[], err=[]))
+
+    def work(job):
+        try:
+            for rep in range(3):
+                with pkg.Context(device=0, seed=seed) as ctx:
+                    ctx.set_matrix(job["X"])
+                    ctx.set_groups(job["gid"], job["ng"])
+                    ctx.compute_thresholds(0.01)
+                    ctx.build_pairs(0)
+                    job["out"].append(ctx.identify_degs(job["ref0"], 1.0, 0.05, 24, 0))
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            job["err"].append(e)
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for j in jobs:
+        assert not j["err"], j["err"]
+        exp, eit, etr = oracle.identify_degs(np.asarray(j["X"], dtype=np.float64), j["gid"], j["ng"], 0.01, 1.0, 0.05, j["ref0"], 24, 0, seed)
+        for res, iters, trace in j["out"]:
+            assert iters == eit and trace == etr
+            _check_result(res, exp)
+
+
 def test_maximum_gene_count_65535(pkg, oracle):
     """G = 65535 (the u16 position limit), S = 16: sampled pair blocks and the mirror rule at full size."""
     G, S, seed = 65535, 16, 77
