@@ -4,11 +4,12 @@
 //                   4 bit planes per ordered pair      (src/RankCompV3.jl:363-392)
 //                   wave form (round 3, the default for two groups): one wave per workgroup, the count loop a generated,
 //                   hand-scheduled asm statement (gen_k1_loop.py -> k1_loop_gen.inc), up to 262 143 genes
-//       k1_pairs    the workgroup form of round 2 (REO_K1_WAVE=0; more than two groups without shared counts),
-//       k1_pairs_wide the same with 32-bit counts (more than 65 535 samples)
-//       k1_group_counts + k1_classify: the same for one-vs-rest over more than two groups
-//                   (:375-390) -- every group counted once, counts kept in HBM, one cheap
-//                   classification per comparison
+//       k1w_pairs_wide   the wave form with 32-bit totals (more than 65 535 samples, two groups)
+//       k1w_group_counts + k1_classify: one-vs-rest over more than two groups (:375-390) -- every group counted once
+//                   (the wave form's loop, once per group and item), counts kept in HBM, one cheap classification per
+//                   comparison;  k1w_pairs_multi: the recounting form of that above 65 535 genes
+//       k1_pairs, k1_pairs_wide, k1_group_counts: the workgroup forms of round 2 (REO_K1_WAVE=0; more than two groups
+//                   without shared counts; more than two groups with more than 65 535 samples)
 //   K2  k2_tally    class table x reference mask -> per-gene tallies   (:403)
 //       (delta form: the same launch updates the counters from the rows of the genes whose mask bit changed)
 //   K3  k3_*        McCullagh test, trimmed std, normal p, BH, new mask, loop control (:404-425,225-259): the
