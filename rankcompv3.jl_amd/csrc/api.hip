@@ -284,6 +284,11 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->device = device;
     c->seed = seed;
     if (const char *e = getenv("REO_K1_WAVE")) c->k1_wave = (e[0] != '0');
+    if (const char *e = getenv("REO_K1_HALF")) c->k1_half = (e[0] != '0');
+    {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->n_cus = n;
+    }
     if (const char *e = getenv("REO_SPIN_WAIT")) c->spin_wait = (e[0] != '0');
     if (const char *e = getenv("REO_CHECK_HOOK_TABLE")) c->check_hook_table = (e[0] != '0');
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');

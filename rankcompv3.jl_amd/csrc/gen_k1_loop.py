@@ -35,12 +35,14 @@ def a_word(k):
 
 
 class Loop:
-    def __init__(self, nb, ties, name, lshl_add=True, opts=(), ri=RI):
+    def __init__(self, nb, ties, name, lshl_add=True, opts=(), ri=RI, std=False):
         # opts: timing experiments only (tools/k1w_probe.hip) -- never set for the library's loops
         self.nb, self.ties, self.name, self.opts = nb, ties, name, set(opts)
         # big: more than 16 planes (more than 65 535 genes).  Five pos quads per gene and block, P [nblk][5][Gp]; edge rows
         # of 8 uint4 (20 words used, plane k in word k: the generator places the registers, no skew needed), A [nblk][Gp][8].
-        self.ri = ri                       # gene rows per item (16: the four-waves-per-SIMD experiment of tools/k1w_probe.hip)
+        self.ri = ri                       # gene rows per item: 32; 16 with std = the half-height items of a launch's last round
+                                           # (same registers as the 32-row form, 32 counts); 16 without = the four-waves-per-SIMD
+                                           # experiment of tools/k1w_probe.hip (128 registers)
         self.big = nb > 16
         assert not (self.big and ties)
         self.rj = 2 if ties else 4
@@ -69,7 +71,7 @@ class Loop:
             assert self.vtop <= 256 - 8, self.vtop
             for a in self.A:   # pos plane k in bank k % 4, edge plane k in bank (A + k) % 4
                 assert a % 2 == 0 and a % 4 != 0
-        elif self.ri == 16:   # 128 registers: 32 counts, the two addresses in the unused 16th word of the pos planes (NB <= 15)
+        elif self.ri == 16 and not std:   # 128 registers: 32 counts, the two addresses in the unused 16th word of the pos planes (NB <= 15)
             assert nb <= 15 and not ties
             self.P = 8 + 32
             self.A = [self.P + 64]
@@ -372,11 +374,13 @@ VARIANTS = [(12, False), (15, False), (16, False), (17, False), (18, False)]   #
 def main():
     print("// GENERATED by gen_k1_loop.py -- do not edit; see that file for the schedule.")
     print("typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));")
+    print("typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));")
     for nb, ties in VARIANTS:
-        lp = Loop(nb, ties, f"k1_loop_nb{nb}_{'ties' if ties else 'free'}")
-        lp.generate()
-        print()
-        print(lp.cxx())
+        for ri in (32, 16):   # 16: half-height items (the last, partly filled round of a launch), name suffix _h
+            lp = Loop(nb, ties, f"k1_loop_nb{nb}_{'ties' if ties else 'free'}{'' if ri == 32 else '_h'}", ri=ri, std=True)
+            lp.generate()
+            print()
+            print(lp.cxx())
 
 
 if __name__ == "__main__":

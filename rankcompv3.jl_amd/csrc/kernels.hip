@@ -4,6 +4,7 @@
 //                   4 bit planes per ordered pair      (src/RankCompV3.jl:363-392)
 //                   wave form (round 3, the default for two groups): one wave per workgroup, the count loop a generated,
 //                   hand-scheduled asm statement (gen_k1_loop.py -> k1_loop_gen.inc), up to 262 143 genes
+//                   (an item = 32 gene rows x 256 genes x one side; the items of a launch's last round as two 16-row halves)
 //       k1w_pairs_wide   the wave form with 32-bit totals (more than 65 535 samples, two groups)
 //       k1w_group_counts + k1_classify: one-vs-rest over more than two groups (:375-390) -- every group counted once
 //                   (the wave form's loop, once per group and item), counts kept in HBM, one cheap classification per
@@ -339,7 +340,16 @@ __device__ __forceinline__ void emit_gene(const K1Args &a, int i0, int j, int bi
     }
     if (j < a.G) {  // mirror: pair (j, i) is in state 2 - state(i, j)
         uint32_t *row = a.table + (static_cast<size_t>(j) * kPlanes + pl) * a.Wp + (i0 >> 5);
-        if (!diag) {
+        if (RI == 16) {  // a half-height item owns one 16-bit half of the word (the other half: its twin, or nobody)
+            const int half = (i0 >> 4) & 1;
+            if (!diag) {
+                reinterpret_cast<uint16_t *>(row)[half] = static_cast<uint16_t>(wH);
+                reinterpret_cast<uint16_t *>(row + a.Wp)[half] = static_cast<uint16_t>(wL);
+            } else {
+                if (wH) atomicOr(row, wH << (16 * half));
+                if (wL) atomicOr(row + a.Wp, wL << (16 * half));
+            }
+        } else if (!diag) {
             row[0] = wH; row[a.Wp] = wL;
         } else {
             if (wH) atomicOr(row, wH);
@@ -463,34 +473,37 @@ __device__ __forceinline__ void k1_loop(u32x16 &c0, u32x16 &c1, u32x16 &c2, u32x
     else k1_loop_nb18_free(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);                 //  the big plane layout)
 }
 
-// Tie-rich data (two band edges per pair): the SAME loop runs twice per item, against the lo planes (n_gt) and then
-// against the hi planes (n_ge); the first pass's 64 count registers wait in the wave's private segment (16 stores and
-// loads per item).  Two chains per pair inside one loop would halve the genes per lane, i.e. double the LDS reads per
-// bit op -- the round-2 form, whose LDS pipe was busy 45 % of the cycles.
-// More than 65 535 genes (NB = 17, 18): the big plane layout of transform.hip (five pos quads per gene and block, edge
-// rows of 8 uint4), 180 registers, two waves per SIMD.
-template <int NB, bool TIES>
-__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
+// the same for a half-height item (16 gene rows, 8 packed count registers per gene: the _h loops)
+template <int NB>
+__device__ __forceinline__ void k1_loop(u32x8 &c0, u32x8 &c1, u32x8 &c2, u32x8 &c3, const void *pb, uint32_t ps, const void *ab,
+                                        uint32_t as, uint32_t nblk, uint32_t poff, uint32_t aoff, uint32_t lds)
 {
-    constexpr int RI = kTileI, RJ = kRJ, NE = TIES ? 2 : 1;
+    if (NB == 12) k1_loop_nb12_free_h(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+    else if (NB == 15) k1_loop_nb15_free_h(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+    else if (NB == 16) k1_loop_nb16_free_h(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+    else if (NB == 17) k1_loop_nb17_free_h(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+    else k1_loop_nb18_free_h(c0, c1, c2, c3, pb, ps, ab, ab, as, nblk, poff, aoff, lds);
+}
+
+// One item of k1w_pairs: RI = 32 gene rows from i0, or a half-height item of 16 (the items of a launch's last, partly filled
+// round are dealt as two halves each, launch_k1: the launch then ends half an item's time earlier).
+template <int NB, bool TIES, int RI>
+__device__ __forceinline__ void k1w_item(const K1Args &a, uint4 *ring, int i0, int jw, int side, unsigned long long t_begin)
+{
+    constexpr int RJ = kRJ, NE = TIES ? 2 : 1;
     constexpr bool BIG = NB > 16;
     constexpr int LQ = BIG ? 5 : 4, ROWB = BIG ? 128 : 64;  // pos quads per block; bytes of an edge row
-    __shared__ uint4 ring[2 * RI * ROWB / 16];  // two slots of one block's tile operand: 2 x 2 KB (4 KB)
-    const unsigned long long t_begin = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-    const uint32_t item = a.items[blockIdx.x];  // side << 31 | wave chunk << 16 | i-tile
-    const int i0 = __builtin_amdgcn_readfirstlane(static_cast<int>(item & 0xFFFFu) * RI);
-    const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((item >> 16) & 0x7FFFu) * (64 * RJ));
-    const int side = __builtin_amdgcn_readfirstlane(static_cast<int>(item >> 31));
+    typedef typename std::conditional<RI == 32, u32x16, u32x8>::type Counts;
     const int lane = threadIdx.x, jl = jw + lane, bi = i0 >> 6;
     const int bb = side ? a.tb : a.cb, be = side ? a.te : a.ce;
-    u32x16 gt0, gt1, gt2, gt3;                    // n_gt of the lane's four genes: packed, rows 2h and 2h+1
+    Counts gt0, gt1, gt2, gt3;                    // n_gt of the lane's four genes: packed, rows 2h and 2h+1
     uint32_t park[TIES ? RJ * (RI / 2) : 1];      // n_ge (tie-rich data): the first pass's counts wait in the private segment
     unsigned long long t_loop = 0, t_emit = 0;
     if (a.stamps) t_loop = __builtin_amdgcn_s_memrealtime();
     if (be > bb) {
         const char *pb = reinterpret_cast<const char *>(a.P) + static_cast<size_t>(bb) * LQ * a.Gp * 16;
         const size_t aoff = (static_cast<size_t>(bb) * a.Gp + i0) * ROWB;
-        const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[0]));
+        const uint32_t lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring));
         // ONE copy of the loop's code for both passes; nothing but the parked counts (memory) lives across the second pass
 #pragma clang loop unroll(disable)
         for (int e = 0; e < NE; ++e) {
@@ -517,8 +530,8 @@ __global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
     // unrolled form (41 KB beside a 20 KB count loop)
 #pragma clang loop unroll(disable)
     for (int r = 0; r < RJ; ++r) {
-        const u32x16 cur = gt0;
-        u32x16 cge = 0;
+        const Counts cur = gt0;
+        Counts cge = 0;
         if (TIES) {
 #pragma unroll
             for (int h = 0; h < RI / 2; ++h) cge[h] = park[r * (RI / 2) + h];  // (dynamic r: the array stays in memory)
@@ -542,6 +555,32 @@ __global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
     if (a.stamps && lane == 0) {
         unsigned long long *st = a.stamps + static_cast<size_t>(blockIdx.x) * 4;
         st[0] = t_begin; st[1] = t_loop; st[2] = t_emit; st[3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// Tie-rich data (two band edges per pair): the SAME loop runs twice per item, against the lo planes (n_gt) and then
+// against the hi planes (n_ge); the first pass's 64 count registers wait in the wave's private segment (16 stores and
+// loads per item).  Two chains per pair inside one loop would halve the genes per lane, i.e. double the LDS reads per
+// bit op -- the round-2 form, whose LDS pipe was busy 45 % of the cycles.
+// More than 65 535 genes (NB = 17, 18): the big plane layout of transform.hip (five pos quads per gene and block, edge
+// rows of 8 uint4), 180 registers, two waves per SIMD.
+template <int NB, bool TIES>
+__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
+{
+    constexpr int RI = kTileI, RJ = kRJ;
+    constexpr int ROWB = NB > 16 ? 128 : 64;
+    __shared__ uint4 ring[2 * RI * ROWB / 16];  // two slots of one block's tile operand: 2 x 2 KB (4 KB)
+    const unsigned long long t_begin = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    // item: side << 31 | wave chunk << 16 | half-height << 15 | which half << 14 | i-tile
+    const uint32_t item = a.items[blockIdx.x];
+    const int jw = __builtin_amdgcn_readfirstlane(static_cast<int>((item >> 16) & 0x7FFFu) * (64 * RJ));
+    const int side = __builtin_amdgcn_readfirstlane(static_cast<int>(item >> 31));
+    const int tile0 = static_cast<int>(item & 0x3FFFu) * RI;
+    if (__builtin_amdgcn_readfirstlane(static_cast<int>(item & 0x8000u))) {
+        const int i0 = __builtin_amdgcn_readfirstlane(tile0 + ((item & 0x4000u) ? RI / 2 : 0));
+        k1w_item<NB, TIES, RI / 2>(a, ring, i0, jw, side, t_begin);
+    } else {
+        k1w_item<NB, TIES, RI>(a, ring, __builtin_amdgcn_readfirstlane(tile0), jw, side, t_begin);
     }
 }
 
@@ -1070,6 +1109,9 @@ __global__ void k_decode(const uint32_t *__restrict__ table, int Wp, int i0, int
 // Consistency of a class table that came through an exchange: a pair is in at most one of the states L / H on each side,
 // nothing sits on the diagonal or past the last gene.  One wave per row; flag[0] |= 1 on a violation.  (A caller-supplied
 // collective that delivers wrong words would otherwise hand the iteration passes tallies that break their invariants.)
+// diagnostic (REO_K1_STAMPS): one s_memrealtime mark on the stream's timeline, before and after the pair kernel
+__global__ void k_time_mark(unsigned long long *out) { if (threadIdx.x == 0) *out = __builtin_amdgcn_s_memrealtime(); }
+
 __global__ __launch_bounds__(256) void k_check_table(const uint32_t *__restrict__ table, int G, int Wp, int32_t *__restrict__ flag)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -3023,7 +3065,8 @@ int32_t launch_k1(reo_ctx *c, int k)
         // until the geometry changes.  (Group counts: one item per tile and chunk, all groups' blocks.)
         const int CW = 64 * RJ, QW = Q * (CJ / CW);
         const uint32_t nsides = wave ? 2u : 1u;
-        const uint64_t key[4] = {static_cast<uint64_t>(c->G) << 32 | static_cast<uint32_t>(c->Gp), static_cast<uint64_t>(RJ) << 32 | static_cast<uint32_t>(Q),
+        const bool halves = wave && !wide && c->k1_half;  // k1w_pairs only: its last round's items are dealt as two halves each
+        const uint64_t key[4] = {static_cast<uint64_t>(c->G) << 32 | static_cast<uint32_t>(c->Gp), static_cast<uint64_t>(halves ? 1 : 0) << 48 | static_cast<uint64_t>(RJ) << 32 | static_cast<uint32_t>(Q),
                                  static_cast<uint64_t>(c->world) << 32 | static_cast<uint32_t>(c->rank),
                                  static_cast<uint64_t>(nsides) << 56 | static_cast<uint64_t>(units.size()) << 24 |
                                      static_cast<uint64_t>(wave ? std::max(a.ce - a.cb, a.te - a.tb) : c->goff32[c->ngroups] / 32)};
@@ -3071,6 +3114,22 @@ int32_t launch_k1(reo_ctx *c, int k)
             for (size_t k = 0; k < per; ++k)
                 for (auto &l : lists)
                     if (k < l.size()) items.push_back(l[k]);
+            // All items take the same time, so the resident waves (slots) work through the list in rounds; when the last
+            // round fills at most half of the slots, its items are dealt as two half-height items each (rows 0-15 and 16-31
+            // of the tile: bit 15 set, bit 14 = which half) and the launch ends half an item's time earlier -- 0.45 of a round
+            // out of 16.45 at config 3; a shard of one eighth of the tiles has 2.06 rounds.  Both halves of an item stay
+            // on the item's XCD (the tail is a multiple of 8 items).
+            if (halves && !items.empty()) {
+                const size_t slots = static_cast<size_t>(c->n_cus) * 4 * (big ? 2 : 3);
+                const size_t left = items.size() % slots;
+                if (left > 0 && left <= slots / 2) {
+                    const size_t n = std::min(items.size(), (left + 7) / 8 * 8);
+                    const std::vector<uint32_t> tail(items.end() - static_cast<ptrdiff_t>(n), items.end());
+                    items.resize(items.size() - n);
+                    for (uint32_t half = 0; half < 2; ++half)
+                        for (uint32_t x : tail) items.push_back(x | 0x8000u | (half ? 0x4000u : 0u));
+                }
+            }
             if ((rc = c->k1_items.ensure(std::max<size_t>(items.size(), 1)))) return rc;
             if (!items.empty()) {
                 REO_HIP_CHECK(hipMemcpyAsync(c->k1_items.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -3080,12 +3139,13 @@ int32_t launch_k1(reo_ctx *c, int k)
             std::memcpy(c->k1_items_key, key, sizeof key);
         }
         a.items = c->k1_items.p;
-        if (getenv("REO_K1_STAMPS")) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), std::max<size_t>(c->k1_items_n, 1) * 4 * sizeof(unsigned long long)));
+        if (getenv("REO_K1_STAMPS")) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), (std::max<size_t>(c->k1_items_n, 1) * 4 + 2) * sizeof(unsigned long long)));
     }
     REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
     if (units.empty()) return REO_OK;
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
     c->last_k1_shared = shared ? 1 : 0;
+    if (a.stamps) k_time_mark<<<1, 64, 0, c->stream>>>(a.stamps + c->k1_items_n * 4);
     tic(c, 1);
     switch (plane_bits(c->G)) {
     case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems, wide); break;
@@ -3095,9 +3155,10 @@ int32_t launch_k1(reo_ctx *c, int k)
     default: launch_big_pairs<18>(c, a, shared, multi, plane_elems, wide); break;
     }
     toc(c);
+    if (a.stamps) k_time_mark<<<1, 64, 0, c->stream>>>(a.stamps + c->k1_items_n * 4 + 1);
     REO_HIP_CHECK(hipGetLastError());
     if (a.stamps) {  // diagnostic: where an item's time goes (100 MHz marks)
-        std::vector<unsigned long long> h(c->k1_items_n * 4);
+        std::vector<unsigned long long> h(c->k1_items_n * 4 + 2);
         REO_HIP_CHECK(hipMemcpyAsync(h.data(), a.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));
         double pro = 0, loop = 0, emit = 0;
@@ -3110,6 +3171,28 @@ int32_t launch_k1(reo_ctx *c, int k)
         const double n = static_cast<double>(c->k1_items_n) * 100.0;  // marks per microsecond
         fprintf(stderr, "[reo] K1 wave items %zu: prologue %.2f us, count loop %.2f us, classification %.2f us per item; first start to last end %.3f ms\n",
                 c->k1_items_n, pro / n, loop / n, emit / n, static_cast<double>(t1 - t0) / 1e5);
+        fprintf(stderr, "[reo]   a launch before it ended %.1f us before the first item began; one after it began %.1f us after the last item ended\n",
+                static_cast<double>(static_cast<long long>(t0 - h[c->k1_items_n * 4])) / 100.0, static_cast<double>(static_cast<long long>(h[c->k1_items_n * 4 + 1] - t1)) / 100.0);
+        // the launch in 24 slices of time: items in flight (average) and the count loop's duration of the items that started in the slice
+        constexpr int kSl = 24;
+        const double span = static_cast<double>(t1 - t0) + 1.0;
+        double busy[kSl] = {}, dur[kSl] = {};
+        size_t started[kSl] = {};
+        for (size_t i = 0; i < c->k1_items_n; ++i) {
+            const double b = static_cast<double>(h[4 * i] - t0), e = static_cast<double>(h[4 * i + 3] - t0);
+            const int s0 = static_cast<int>(b / span * kSl);
+            started[s0]++; dur[s0] += static_cast<double>(h[4 * i + 2] - h[4 * i + 1]);
+            for (int s = s0; s < kSl; ++s) {
+                const double lo = span * s / kSl, hi = span * (s + 1) / kSl;
+                if (e <= lo) break;
+                busy[s] += (std::min(e, hi) - std::max(b, lo)) / (hi - lo);
+            }
+        }
+        fprintf(stderr, "[reo]   items in flight by slice:");
+        for (int s = 0; s < kSl; ++s) fprintf(stderr, " %.0f", busy[s]);
+        fprintf(stderr, "\n[reo]   loop us of items started in slice:");
+        for (int s = 0; s < kSl; ++s) fprintf(stderr, " %.0f", started[s] ? dur[s] / static_cast<double>(started[s]) / 100.0 : 0.0);
+        fprintf(stderr, "\n");
         (void)hipFree(a.stamps);
     }
     return REO_OK;

@@ -1151,18 +1151,20 @@ def test_a_hook_that_delivers_wrong_words_is_refused(pkg):
 
 @pytest.mark.parametrize("family", ["t0", "t1"])
 def test_workgroup_form_of_the_pair_kernel_still_matches(pkg, oracle, monkeypatch, family):
-    """REO_K1_WAVE=0 selects round 2's workgroup form of K1 (kept for > 2 groups and as a cross-check): same table."""
-    G, S, seed = 2600, 96, 0x5EED0062
+    """REO_K1_WAVE=0 selects round 2's workgroup form of K1 (kept for > 2 groups and as a cross-check): same table.  So does
+    the wave form without half-height items (REO_K1_HALF=0; at this size the default deals every item as two halves)."""
+    G, S, seed = 2603, 96, 0x5EED0062
     X = (pkg.synth.t1_counts if family == "t1" else pkg.synth.t0_ranks)(G, S, seed)
     gid, lev = pkg.encode_groups(pkg.synth.groups(S))
     codes = []
-    for wave in ("1", "0"):
+    for wave, half in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("REO_K1_WAVE", wave)
+        monkeypatch.setenv("REO_K1_HALF", half)
         with pkg.Context(device=0, seed=seed) as ctx:
             ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
             ctx.build_pairs(0)
             codes.append(ctx.get_codes(0, G, 0, G))
-    assert np.array_equal(codes[0], codes[1])
+    assert np.array_equal(codes[0], codes[1]) and np.array_equal(codes[0], codes[2])
     thr = np.array([oracle.threshold(int((gid == 0).sum())), oracle.threshold(int((gid == 1).sum()))], dtype=np.int32)
     assert np.array_equal(codes[0], oracle.build_codes(X.astype(np.float64), gid, 2, 0, thr, seed))
 
