@@ -205,9 +205,10 @@ static int32_t init_state(reo_ctx *c, int32_t nref)
 }
 
 // Several shards (world > 1): every shard has built the class-table words of its own pair tiles and left the rest
-// zero; the bits are disjoint, so an integer sum over the shards IS the whole table.  One exchange per class table
-// (in-library RCCL all-reduce when a communicator is attached, else the caller's hook); after it every shard holds
-// the complete table and runs the iteration passes on its own, with no further collective.
+// zero; the shards' bits are disjoint.  One exchange per class table -- an all-gather of the shards' packed forward
+// words (in-library RCCL when a communicator is attached, else the caller's all-gather hook), or, with only a sum hook
+// set, an in-place sum of the whole tables (disjoint bits: the sum IS the table); after it every shard holds the
+// complete table and runs the iteration passes on its own, with no further collective.
 static int32_t exchange_table(reo_ctx *c)
 {
     c->table_complete = c->world <= 1;
