@@ -336,6 +336,7 @@ void reo_destroy(reo_ctx *c)
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
     c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
+    if (c->host_ref) (void)hipHostFree(c->host_ref);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -590,18 +591,33 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
                   "(the reference throws at src/RankCompV3.jl:411-413)", (long long)G, (long long)a, (long long)b);
         return REO_EINVAL;
     }
-    int32_t nref = 0;
-    if ((rc = upload_ref(c, ref0, 0, &nref))) return rc;
-    if ((rc = init_state(c, nref))) return rc;
     if ((rc = c->trace.ensure(2 * static_cast<size_t>(n_iter > 0 ? n_iter : 1)))) return rc;
     if ((rc = c->modes.ensure(static_cast<size_t>(n_iter > 0 ? n_iter : 1) + 64))) return rc;
     collect_timings(c);  // flush timers of earlier calls: the K2 timers below are matched to launches by order
-    REO_HIP_CHECK(hipMemsetAsync(c->result.p, 0, sizeof(double) * 15 * G, c->stream));  // zeros(r,15), :398
+    // mask and initial loop state through pinned host memory, and zeros(r,15) (:398), the K2 mode log and the histograms
+    // cleared, all in one launch (kernels.hip, k_iter_init)
+    if (c->host_ref_cap < static_cast<size_t>(G)) {
+        if (c->host_ref) (void)hipHostFree(c->host_ref);
+        c->host_ref = nullptr; c->host_ref_cap = 0;
+        REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_ref), static_cast<size_t>(c->Gp)));
+        c->host_ref_cap = static_cast<size_t>(c->Gp);
+    }
+    int32_t nref = 0;
+    for (int64_t i = 0; i < G; ++i) { c->host_ref[i] = ref0[i]; nref += ref0[i] != 0; }
+    {
+        IterState st;
+        memset(&st, 0, sizeof st);
+        st.nref = nref;
+        st.nref_prev = nref;
+        st.delta_cnt[0] = st.delta_cnt[1] = 0x7FFFFFFF;  // the first pass counts from scratch
+        st.need_full = 1;
+        st.raw_pass = -1;
+        *c->host_state = st;
+    }
+    if ((rc = launch_iter_init(c, c->host_ref, c->host_state))) return rc;
     c->it_pval_deg = pval_deg; c->it_padj_deg = padj_deg; c->it_n_iter = n_iter; c->it_n_conv = n_conv;
     c->it_a0 = static_cast<int>(a - 1); c->it_b0 = static_cast<int>(b - 1);
     c->k2_idx = 0;
-    REO_HIP_CHECK(hipMemsetAsync(c->modes.p, 0, c->modes.n * sizeof(int32_t), c->stream));
-    REO_HIP_CHECK(hipMemsetAsync(c->hist.p, 0, c->hist.n * sizeof(int32_t), c->stream));
     // The loop control of :400,418-424 lives in device memory (IterState): passes are enqueued in batches, every
     // kernel looks at the state and returns at once when its pass is not wanted (convergence, n_iter reached, the
     // other kind of pass is due), and the host reads the state once per batch.  Two kinds of pass (kernels.hip):

@@ -1141,6 +1141,36 @@ __global__ __launch_bounds__(256) void k_pack_ref(const uint8_t *__restrict__ by
     }
 }
 
+// Start of reo_identify_degs in ONE launch (it was a memset, two copies, k_pack_ref and three more memsets: seven stream
+// operations of 3 - 10 us each in front of the first pass): the caller's reference mask and the initial loop state are
+// read from pinned host memory, the mask goes to device memory as bytes (padded with zeros to Gp) and as bits, and the
+// result matrix, the K2 mode log and the BH-rank histograms are cleared.
+struct IterInitArgs {
+    const uint8_t *host_ref;    // pinned, G bytes
+    const uint32_t *host_state; // pinned, IterState
+    uint8_t *refbytes;
+    uint32_t *refbits, *state;
+    uint32_t *zero[3];
+    size_t zero_n[3];           // in 32-bit words
+    int G, Gp, state_words;
+};
+__global__ __launch_bounds__(256) void k_iter_init(IterInitArgs a)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;  // grid = Gp / 256
+    const uint8_t b = g < a.G ? a.host_ref[g] : 0;
+    a.refbytes[g] = b;
+    const unsigned long long m = __ballot(b != 0);
+    if ((threadIdx.x & 63) == 0) {
+        a.refbits[g >> 5] = static_cast<uint32_t>(m);
+        a.refbits[(g >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+    }
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < a.state_words) a.state[threadIdx.x] = a.host_state[threadIdx.x];
+    const size_t nthreads = static_cast<size_t>(gridDim.x) * 256;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (size_t i = static_cast<size_t>(g); i < a.zero_n[k]; i += nthreads) a.zero[k][i] = 0;
+}
+
 // ---------------------------------------------------------------------------
 // K2: one wave per gene row.  Streams the row's four planes (16 B per lane per
 // load, fully coalesced), ANDs with the reference mask and popcounts.  Raw
@@ -3287,6 +3317,20 @@ int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits)
 {
     k_pack_ref<<<c->Gp / 256, 256, 0, c->stream>>>(d_bytes, c->Gp, d_bits);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+int32_t launch_iter_init(reo_ctx *c, const uint8_t *host_ref, const IterState *host_state)
+{
+    IterInitArgs a;
+    a.host_ref = host_ref; a.host_state = reinterpret_cast<const uint32_t *>(host_state);
+    a.refbytes = c->refbytes[0].p; a.refbits = c->refbits[0].p; a.state = reinterpret_cast<uint32_t *>(c->state.p);
+    a.zero[0] = reinterpret_cast<uint32_t *>(c->result.p); a.zero_n[0] = static_cast<size_t>(c->G) * 15 * 2;
+    a.zero[1] = reinterpret_cast<uint32_t *>(c->modes.p); a.zero_n[1] = c->modes.n;
+    a.zero[2] = reinterpret_cast<uint32_t *>(c->hist.p); a.zero_n[2] = c->hist.n;
+    a.G = static_cast<int>(c->G); a.Gp = c->Gp; a.state_words = static_cast<int>(sizeof(IterState) / 4);
+    k_iter_init<<<c->Gp / 256, 256, 0, c->stream>>>(a);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

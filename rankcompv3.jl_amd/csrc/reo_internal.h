@@ -229,6 +229,8 @@ struct reo_ctx {
     int k2_idx = 0;                     // K2 launches of the running call
     bool it_no_light = false;           // the running call has given up on light passes (two light batches in a row completed no pass)
     reo::IterState *host_state = nullptr;  // pinned
+    uint8_t *host_ref = nullptr;           // pinned: the caller's reference mask on its way to the device (reo_identify_degs)
+    size_t host_ref_cap = 0;
 
     // timing
     bool profiling = false;
@@ -255,6 +257,7 @@ int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
 int32_t launch_check_table(reo_ctx *c, int *bad);  // consistency of an exchanged class table (kernels.hip, k_check_table)
 int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
+int32_t launch_iter_init(reo_ctx *c, const uint8_t *host_ref, const IterState *host_state);  // mask + loop state from pinned host memory, clears
 int32_t launch_tally(reo_ctx *c, int nref);
 int32_t launch_full_pass(reo_ctx *c, bool replay);
 int32_t launch_light_persistent(reo_ctx *c);
