@@ -160,7 +160,15 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     typename sorter::storage_type &storage = *reinterpret_cast<typename sorter::storage_type *>(smem);
     const int t = threadIdx.x;
     const int c = blockIdx.x;  // one sample per workgroup; its three output rows are whole lines of its own
-    if (c >= S) return;
+    if (c >= S) {  // one workgroup per padding slot too (slots[S ..]): rows of zeros -- lo = hi = 0 is below no position
+        const size_t o = static_cast<size_t>(slots[c]) * Gp;
+        for (int q = t; q < Gp / 8; q += 1024) {
+            reinterpret_cast<uint4 *>(pos + o)[q] = uint4{0, 0, 0, 0};
+            reinterpret_cast<uint4 *>(lo + o)[q] = uint4{0, 0, 0, 0};
+            reinterpret_cast<uint4 *>(hi + o)[q] = uint4{0, 0, 0, 0};
+        }
+        return;
+    }
     const T *col = X + static_cast<int64_t>(colmap[c]) * ld;
     const int slot = slots[c];
     int32_t *anytie = flags + 1;
@@ -249,10 +257,11 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
             if (i >= G) continue;
             const uint32_t l = hist[at(key[e])], h = static_cast<int>(key[e]) + 1 < nbin ? hist[at(key[e] + 1)] : static_cast<uint32_t>(G);
             tied |= h - l > 1u;
-            prow[i] = static_cast<uint16_t>(l + arrival[e]);  // (rows of padded genes were zeroed by the caller)
+            prow[i] = static_cast<uint16_t>(l + arrival[e]);
             lrow[i] = static_cast<uint16_t>(l);
             hrow[i] = static_cast<uint16_t>(h);
         }
+        for (int g = G + t; g < Gp; g += 1024) { prow[g] = 0; lrow[g] = 0; hrow[g] = 0; }  // padded genes are below no band edge
         if (tied && *anytie == 0) atomicOr(anytie, 1);
         return;
     }
@@ -341,6 +350,7 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
                 lrow[i] = static_cast<uint16_t>(l);
                 hrow[i] = static_cast<uint16_t>(h);
             }
+            for (int g = G + t; g < Gp; g += 1024) { prow[g] = 0; lrow[g] = 0; hrow[g] = 0; }  // padded genes are below no band edge
             if (tied && *anytie == 0) atomicOr(anytie, 1);
             return;
         }
@@ -524,7 +534,7 @@ int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d
                                  kCountingPath<T> ? sizeof(uint32_t) * (kWideWords + 32) + sizeof(uint16_t) * static_cast<size_t>(c->Gp) : size_t(0)});
     // every time: the attribute belongs to the (function, device) pair and a process may use several devices
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    t_sample<T, IPT><<<static_cast<unsigned>(c->S), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
+    t_sample<T, IPT><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,  // (a workgroup per slot: samples, then padding)
                                                                             static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
@@ -559,14 +569,16 @@ int32_t transform_impl(reo_ctx *c)
         const int g = c->group_id[order[t]];
         slots[t] = c->goff32[g] + (t - c->goff[g]);
     }
+    for (int g = 0; g < c->ngroups; ++g)  // behind the samples: the padding slots of every group (t_sample zeroes their rows)
+        for (int sl = c->goff32[g] + (c->goff[g + 1] - c->goff[g]); sl < c->goff32[g + 1]; ++sl) slots.push_back(sl);
     for (int g = 0; g <= c->ngroups; ++g) goff_blocks[g] = c->goff32[g] / 32;
 
     // scratch lives in the context (grow-only): hipMalloc/hipFree per call cost milliseconds
     DevBuf<int32_t> &d_order = c->t_order, &d_flags = c->t_flags;
     int32_t rc;
-    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(6)) || (rc = c->t_slots.ensure(S))) return rc;
+    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(6)) || (rc = c->t_slots.ensure(slots.size()))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
-    REO_HIP_CHECK(hipMemcpyAsync(c->t_slots.p, slots.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+    REO_HIP_CHECK(hipMemcpyAsync(c->t_slots.p, slots.data(), sizeof(int32_t) * slots.size(), hipMemcpyHostToDevice, st));
     REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
     unsigned long long *d_varbits = reinterpret_cast<unsigned long long *>(d_flags.p + 2);
     if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
@@ -580,10 +592,8 @@ int32_t transform_impl(reo_ctx *c)
         if ((rc = c->t_pos16.ensure(n)) || (rc = c->t_lo16.ensure(n)) || (rc = c->t_hi16.ensure(n)) ||
             (rc = c->pos.ensure(nq)) || (rc = c->lo.ensure(nq)) || (rc = c->hi.ensure(nq)))
             return rc;
-        // rows of padding slots and (segmented path) padded genes: below no band edge
-        REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));
-        REO_HIP_CHECK(hipMemsetAsync(c->t_lo16.p, 0, n * sizeof(uint16_t), st));
-        REO_HIP_CHECK(hipMemsetAsync(c->t_hi16.p, 0, n * sizeof(uint16_t), st));
+        // (rows of padding slots and padded genes must read as zero, below no band edge: t_sample writes them itself; the
+        //  segmented path clears the three row sets first, below)
     } else {
         if ((rc = c->t_pos32.ensure(n)) || (rc = c->t_lo32.ensure(n)) || (rc = c->t_hi32.ensure(n)) ||
             (rc = c->pos.ensure(static_cast<size_t>(nblk) * Gp * 5)) || (rc = c->lo.ensure(static_cast<size_t>(nblk) * Gp * 8)) ||
@@ -596,10 +606,14 @@ int32_t transform_impl(reo_ctx *c)
         REO_HIP_CHECK(hipMemsetAsync(c->hi.p, 0, static_cast<size_t>(nblk) * Gp * 8 * sizeof(uint4), st));
     }
     const T *X = static_cast<const T *>(c->dX);
-    auto finish = [&](int has_ties) -> int32_t {
+    auto slice = [&]() -> int32_t {
         if (big) t_slice_big<<<dim3(Gp / 256, nblk), 256, 0, st>>>(c->t_pos32.p, c->t_lo32.p, c->t_hi32.p, Gp, c->pos.p, c->lo.p, c->hi.p);
         else t_slice<<<dim3(Gp / 512, nblk), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p);
         REO_HIP_CHECK(hipGetLastError());
+        return REO_OK;
+    };
+    auto finish = [&](int has_ties, bool sliced) -> int32_t {
+        if (!sliced) { const int32_t rs = slice(); if (rs) return rs; }
         c->has_ties = has_ties;
         c->transformed = true;
         return REO_OK;
@@ -614,6 +628,9 @@ int32_t transform_impl(reo_ctx *c)
         else if (G <= 24 * 1024) rc = launch_sample<T, 24>(c, X, d_order.p, d_flags.p);
         else rc = launch_sample<T, 32>(c, X, d_order.p, d_flags.p);
         if (rc) return rc;
+        // the slicing is enqueued before the host looks at the flags (it runs while the host wakes up; if the flags send
+        // the data to the segmented path it is simply done again)
+        if ((rc = slice())) return rc;
         int32_t fl[6];
         REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, sizeof fl, hipMemcpyDeviceToHost, st));
         REO_HIP_CHECK(hipStreamSynchronize(st));
@@ -624,10 +641,12 @@ int32_t transform_impl(reo_ctx *c)
         }
         if (!fl[4]) {
             c->transform_in_lds = 1;
-            return finish(fl[1]);
+            return finish(fl[1], true);
         }
         // some sample has keys wider than 31 bits: start over with the segmented sort
         REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
+    }
+    if (!big) {  // the segmented path writes the genes of the samples only: padding slots and padded genes read as zero
         REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));
         REO_HIP_CHECK(hipMemsetAsync(c->t_lo16.p, 0, n * sizeof(uint16_t), st));
         REO_HIP_CHECK(hipMemsetAsync(c->t_hi16.p, 0, n * sizeof(uint16_t), st));
@@ -683,7 +702,7 @@ int32_t transform_impl(reo_ctx *c)
                   "src/RankCompV3.jl:601)");
         return REO_EINVAL;
     }
-    return finish(flags[1]);
+    return finish(flags[1], false);
 }
 
 }  // namespace
