@@ -467,8 +467,8 @@ int32_t reo_get_thresholds(reo_ctx *c, int32_t *m)
     return REO_OK;
 }
 
-// transform + this context's share of the pair tiles, finished on return; no exchange
-static int32_t build_local(reo_ctx *c, int32_t k)
+// transform + this context's share of the pair tiles; no exchange
+static int32_t enqueue_local(reo_ctx *c, int32_t k)
 {
     int32_t rc = use(c);
     if (rc) return rc;
@@ -477,7 +477,14 @@ static int32_t build_local(reo_ctx *c, int32_t k)
     if (k < 0 || k >= c->ngroups) { set_error("comparison %d outside [0,%d)", k, c->ngroups); return REO_EINVAL; }
     if ((rc = c->table.ensure(static_cast<size_t>(c->G) * kPlanes * c->Wp))) return rc;
     c->built_k = -1;
-    if ((rc = launch_k1(c, k))) return rc;
+    return launch_k1(c, k);
+}
+
+// ... finished on return (shards: the pack and the exchange follow)
+static int32_t build_local(reo_ctx *c, int32_t k)
+{
+    const int32_t rc = enqueue_local(c, k);
+    if (rc) return rc;
     REO_HIP_CHECK(stream_wait(c));
     return REO_OK;
 }
@@ -489,6 +496,17 @@ int32_t reo_build_pairs(reo_ctx *c, int32_t k)
         if ((rc = multi_build_pairs(c, k, build_local))) return rc;
     } else {
         if (c && c->comm_dead) { set_error("the communicator of this context was aborted after an earlier failure: attach a new one (reo_comm_init_rank)"); return REO_ECOMM; }
+        if (c && !c->comm && c->world <= 1 && !c->ag && !c->ar) {
+            // one GPU, nothing to exchange: the pair kernel is left running.  Every later call works on the same stream, so
+            // reo_identify_degs queues its first passes behind it without a host round trip in between; an asynchronous
+            // failure of the kernel surfaces at the next wait (REO_EHIP); the stage timers are collected by the next call
+            // that reads them.
+            if ((rc = enqueue_local(c, k))) return rc;
+            c->table_complete = true;
+            c->t_ms[5] += 1.0;
+            c->built_k = k;
+            return REO_OK;
+        }
         // a rank that fails here must not leave its peers waiting inside the collective: it aborts its communicator
         // (a failing caller-supplied hook has to do the same with its own)
         if ((rc = build_local(c, k))) { if (c && c->comm && c->world > 1) comm_abort(c); return rc; }
@@ -593,7 +611,10 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     }
     if ((rc = c->trace.ensure(2 * static_cast<size_t>(n_iter > 0 ? n_iter : 1)))) return rc;
     if ((rc = c->modes.ensure(static_cast<size_t>(n_iter > 0 ? n_iter : 1) + 64))) return rc;
-    collect_timings(c);  // flush timers of earlier calls: the K2 timers below are matched to launches by order
+    // flush K2 timers of earlier calls (reo_tally): the ones below are matched to launches by order.  Timers of the pair
+    // stage stay pending -- waiting for them here would put a host round trip between the pair kernel and the first pass.
+    for (const auto &pr : c->pending)
+        if (pr.first == 2) { collect_timings(c); break; }
     // mask and initial loop state through pinned host memory, and zeros(r,15) (:398), the K2 mode log and the histograms
     // cleared, all in one launch (kernels.hip, k_iter_init)
     if (c->host_ref_cap < static_cast<size_t>(G)) {

@@ -3084,9 +3084,11 @@ int32_t launch_k1(reo_ctx *c, int k)
     c->k1_cj = CJ; c->k1_q = Q;
     a.n_units = static_cast<int>(units.size()); a.Q = Q;
     if ((rc = c->unit_map.ensure(std::max<size_t>(units.size(), 1)))) return rc;
-    if (!units.empty()) {
+    if (!units.empty() && (c->unit_map.p != c->unit_map_uploaded || units != c->unit_map_host)) {  // (the same geometry as last time: already there)
         REO_HIP_CHECK(hipMemcpyAsync(c->unit_map.p, units.data(), units.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `units` is a local: the copy must have read it before any return below
+        c->unit_map_host = units;
+        c->unit_map_uploaded = c->unit_map.p;
     }
     a.unit_map = c->unit_map.p;
     a.items = nullptr; a.stamps = nullptr;

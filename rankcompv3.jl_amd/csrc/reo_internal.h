@@ -164,6 +164,8 @@ struct reo_ctx {
     reo::DevBuf<unsigned char> t_temp;
     reo::DevBuf<int32_t> t_order, t_flags, t_slots;
     reo::DevBuf<uint32_t> unit_map;  // K1 work units: panel << 16 | i-range
+    std::vector<uint32_t> unit_map_host;          // what unit_map holds (launch_k1 uploads only a different list)
+    const uint32_t *unit_map_uploaded = nullptr;  // ... and into which allocation
     reo::DevBuf<uint32_t> k1_items;  // wave form of K1: one work item per workgroup (side << 31 | wave chunk << 16 | i-tile)
     size_t k1_items_n = 0;
     uint64_t k1_items_key[4] = {0, 0, 0, 0};  // geometry the list was made for
