@@ -138,7 +138,10 @@ int32_t reo_threshold(int32_t sample_size, double pval_reo);
 /* REO table build for comparison k (group k vs every other sample; with two
  * groups the reference only runs k = 0, :387-389): replaces the pair loop
  * src/RankCompV3.jl:363-392.  Runs the per-sample rank/band transform and the
- * pair-compare kernel and leaves the 4-bit class table in HBM. */
+ * pair-compare kernel and leaves the 4-bit class table in HBM.  The input matrix has been read when the call
+ * returns.  On one GPU with nothing to exchange the pair kernel may still be running then: every later call on the
+ * context is ordered behind it (one stream), and an asynchronous failure of the kernel is reported by the next call
+ * that waits (REO_EHIP).  With shards (several GPUs, hooks) the call returns after the exchange has finished. */
 int32_t reo_build_pairs(reo_ctx *ctx, int32_t k);
 
 /* Parity hook: deterministic per-pair per-group counts for the ordered pairs
