@@ -577,13 +577,20 @@ int32_t transform_impl(reo_ctx *c)
     DevBuf<int32_t> &d_order = c->t_order, &d_flags = c->t_flags;
     int32_t rc;
     if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(6)) || (rc = c->t_slots.ensure(slots.size()))) return rc;
-    REO_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
-    REO_HIP_CHECK(hipMemcpyAsync(c->t_slots.p, slots.data(), sizeof(int32_t) * slots.size(), hipMemcpyHostToDevice, st));
+    if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
+    // sample order, slots and group offsets depend on the group labels only: uploaded when they (or the buffers) change
+    if (order != c->t_order_host || slots != c->t_slots_host || goff_blocks != c->goff_blocks_host || d_order.p != c->t_meta_ptr[0] ||
+        c->t_slots.p != c->t_meta_ptr[1] || c->goff_dev.p != c->t_meta_ptr[2]) {
+        REO_HIP_CHECK(hipMemcpyAsync(d_order.p, order.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, st));
+        REO_HIP_CHECK(hipMemcpyAsync(c->t_slots.p, slots.data(), sizeof(int32_t) * slots.size(), hipMemcpyHostToDevice, st));
+        REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff_blocks.data(), sizeof(int32_t) * (c->ngroups + 1),
+                                     hipMemcpyHostToDevice, st));
+        REO_HIP_CHECK(hipStreamSynchronize(st));  // the sources are locals
+        c->t_order_host = order; c->t_slots_host = slots; c->goff_blocks_host = goff_blocks;
+        c->t_meta_ptr[0] = d_order.p; c->t_meta_ptr[1] = c->t_slots.p; c->t_meta_ptr[2] = c->goff_dev.p;
+    }
     REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
     unsigned long long *d_varbits = reinterpret_cast<unsigned long long *>(d_flags.p + 2);
-    if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
-    REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff_blocks.data(), sizeof(int32_t) * (c->ngroups + 1),
-                                 hipMemcpyHostToDevice, st));
 
     const bool big = G > 65535;  // 32-bit positions and gene indices, the big plane layout
     const size_t n = static_cast<size_t>(S32) * Gp;            // numbers per intermediate row set
