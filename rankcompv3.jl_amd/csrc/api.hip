@@ -156,6 +156,9 @@ static int32_t ensure_transform(reo_ctx *c)
     if (c->transformed) return REO_OK;
     c->Gp = static_cast<int>((c->G + kGenePad - 1) / kGenePad) * kGenePad;  // every lane's genes exist
     c->Wp = c->Gp / 32;
+    c->table_prezeroed = false;
+    int32_t rc = c->table.ensure(static_cast<size_t>(c->G) * kPlanes * c->Wp);  // (the transform queues its clearing, see transform.hip)
+    if (rc) return rc;
     return run_transform(c);
 }
 
@@ -336,6 +339,8 @@ void reo_destroy(reo_ctx *c)
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
     c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
+    if (c->host_flags) (void)hipHostFree(c->host_flags);
+    if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
     if (c->host_ref) (void)hipHostFree(c->host_ref);
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -3173,7 +3173,8 @@ int32_t launch_k1(reo_ctx *c, int k)
         a.items = c->k1_items.p;
         if (getenv("REO_K1_STAMPS")) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), (std::max<size_t>(c->k1_items_n, 1) * 4 + 2) * sizeof(unsigned long long)));
     }
-    REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
+    if (!c->table_prezeroed) REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
+    c->table_prezeroed = false;
     if (units.empty()) return REO_OK;
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
     c->last_k1_shared = shared ? 1 : 0;

@@ -167,6 +167,9 @@ struct reo_ctx {
     std::vector<uint32_t> unit_map_host;          // what unit_map holds (launch_k1 uploads only a different list)
     std::vector<int32_t> t_order_host, t_slots_host, goff_blocks_host;  // what t_order / t_slots / goff_dev hold (transform: uploaded when they change)
     const int32_t *t_meta_ptr[3] = {nullptr, nullptr, nullptr};
+    int32_t *host_flags = nullptr;       // pinned: the transform's flags on their way to the host
+    hipEvent_t ev_flags = nullptr;       // ... and the point of the stream at which they have arrived
+    bool table_prezeroed = false;        // the transform has already queued the clearing of the class table (behind its flags copy)
     const uint32_t *unit_map_uploaded = nullptr;  // ... and into which allocation
     reo::DevBuf<uint32_t> k1_items;  // wave form of K1: one work item per workgroup (side << 31 | wave chunk << 16 | i-tile)
     size_t k1_items_n = 0;

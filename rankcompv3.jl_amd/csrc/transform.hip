@@ -638,9 +638,18 @@ int32_t transform_impl(reo_ctx *c)
         // the slicing is enqueued before the host looks at the flags (it runs while the host wakes up; if the flags send
         // the data to the segmented path it is simply done again)
         if ((rc = slice())) return rc;
-        int32_t fl[6];
-        REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, sizeof fl, hipMemcpyDeviceToHost, st));
-        REO_HIP_CHECK(hipStreamSynchronize(st));
+        // The host waits for the flags only (an event behind their copy into pinned memory); behind that event the clearing
+        // of the class table is already queued, so the GPU has work while the host wakes up and launches the pair kernel.
+        if (!c->host_flags) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t)));
+        if (!c->ev_flags) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming));
+        int32_t *fl = c->host_flags;
+        REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        REO_HIP_CHECK(hipEventRecord(c->ev_flags, st));
+        if (c->table.p && c->table.n >= static_cast<size_t>(c->G) * 4 * c->Wp) {
+            REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * 4 * c->Wp * sizeof(uint32_t), st));
+            c->table_prezeroed = true;
+        }
+        REO_HIP_CHECK(hipEventSynchronize(c->ev_flags));
         if (fl[0]) {
             set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
                       "src/RankCompV3.jl:601)");
