@@ -652,6 +652,10 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // sorting passes, or a run of light passes; small problems sort every pass.
     // (more than 65 535 genes: sorting passes only -- the light passes keep per-workgroup lists and sums for at most 256
     //  workgroups of 256 genes)
+    {
+        const char *e = getenv("REO_STATE_MIRROR");
+        c->state_mirror = c->light_mode != 2 && !(e && e[0] == '0');
+    }
     bool small = G < c->light_min_g || c->light_mode == 0 || G > 65535;
     c->it_no_light = G > 65535;  // (the device must know as well: a sorting pass that left need_full clear would wait for light passes nobody enqueues)
     int passes = 0, seen_need_full = 1, light_batches = 0, idle_light = 0, idle_any = 0;  // idle_light: light batches in a row that completed no pass
@@ -673,7 +677,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
             if ((rc = launch_light_batch(c, nlight))) return rc;
         }
         toc(c);
-        REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
+        if (!c->state_mirror) REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
         REO_HIP_CHECK(stream_wait(c));
         if (getenv("REO_DEBUG_PASSES"))
             fprintf(stderr, "batch: %d sorting + %d light launches, passes %d -> %d, need_full %d, done %d, last_full %d, changed genes in front of the next pass %d\n", nfull, nlight,

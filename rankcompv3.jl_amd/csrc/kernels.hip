@@ -1343,6 +1343,8 @@ struct IterArgs {
     int32_t *clist; int band;    // light passes: genes near the BH cut listed by kl_rank ([2][kListStride]); half width of "near" in ranks
     int window, light_min_g;     // light passes: ranks on either side of a quantile that its window is made to hold; smallest G that uses them
     unsigned long long *stamps;  // diagnostic builds (-DREO_STAMPS): s_memrealtime marks of workgroup 0, else unused
+    IterState *host_st;          // pinned host memory: the kernels that end a pass or a batch mirror what the host reads of IterState
+                                 // there (passes, done, need_full, last_full, delta_cnt), so no copy is queued behind a batch; null: no mirror
 };
 
 #ifdef REO_STAMPS
@@ -1887,6 +1889,11 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
         a.scal[5] = va - wa_lo; a.scal[6] = wa_hi - va; a.scal[7] = vb - wb_lo; a.scal[8] = wb_hi - vb;
     }
     a.st->need_full = (over || !ok) ? 1 : 0;
+    if (a.host_st) {  // (this thread wrote every one of these fields, here or in publish_mask)
+        IterState *h = a.host_st;
+        h->passes = t + 1; h->done = a.st->done; h->need_full = (over || !ok) ? 1 : 0; h->last_full = 1;
+        h->delta_cnt[(t + 1) & 1] = a.st->delta_cnt[(t + 1) & 1];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2449,6 +2456,11 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
             st->delta_cnt[r.t & 1] = r.dcnt;
             if (r.ran) st->last_full = 0;
             if (stepped) { a.scal[1] = win[0]; a.scal[2] = win[1]; a.scal[3] = win[2]; a.scal[4] = win[3]; }
+            if (a.host_st) {
+                IterState *h = a.host_st;
+                h->passes = r.t; h->done = r.done; h->need_full = r.need_full; h->delta_cnt[r.t & 1] = r.dcnt;
+                if (r.ran) h->last_full = 0;
+            }
         }
         return;
     }
@@ -3374,6 +3386,7 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     //  launches would wait for light passes that nobody enqueues)
     a.window = c->light_window; a.light_min_g = (c->it_no_light || c->light_mode == 0) ? 0x7FFFFFFF : c->light_min_g;
     a.stamps = reinterpret_cast<unsigned long long *>(c->scal.p + 32);
+    a.host_st = c->state_mirror ? c->host_state : nullptr;  // (hipHostMalloc memory: the same address on the device)
     return a;
 }
 

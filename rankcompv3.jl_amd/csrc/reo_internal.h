@@ -236,6 +236,7 @@ struct reo_ctx {
     int k2_idx = 0;                     // K2 launches of the running call
     bool it_no_light = false;           // the running call has given up on light passes (two light batches in a row completed no pass)
     reo::IterState *host_state = nullptr;  // pinned
+    bool state_mirror = false;             // the kernels write what the host reads of IterState straight into host_state (REO_STATE_MIRROR=0: a copy per batch)
     uint8_t *host_ref = nullptr;           // pinned: the caller's reference mask on its way to the device (reo_identify_degs)
     size_t host_ref_cap = 0;
 
