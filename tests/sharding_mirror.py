@@ -1,5 +1,5 @@
-"""Python mirror of the pair-tile ownership rule of libreo_hip.so (launch_k1 in
-csrc/kernels.hip) and of the linear algebra of its tallies, so that the
+"""TEST INFRASTRUCTURE (not part of the product package): Python mirror of the pair-tile ownership rule of libreo_hip.so
+(launch_k1 in csrc/kernels.hip) and of the linear algebra of its tallies, so that the
 multi-GPU protocol can be exercised without a GPU.
 
 G is sharded by work unit: the upper triangle of the gene x gene pair matrix is

@@ -8,6 +8,8 @@ import os
 import zlib
 
 import numpy as np
+
+import sharding_mirror
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -366,7 +368,7 @@ def test_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle, exchange, wo
                 ctx.build_pairs(0)          # no exchange configured yet: the shard's own part of the table
                 info = ctx.info()
                 got = ctx.get_codes(0, G, 0, G)
-                mask = pkg.sharding.owned_pair_mask(G, info["sample_slots"], ties, rank, world)
+                mask = sharding_mirror.owned_pair_mask(G, info["sample_slots"], ties, rank, world)
                 off = ~np.eye(G, dtype=bool)
                 assert np.array_equal(got[mask], code[mask])
                 assert (got[off & ~mask] == 4).all()
@@ -485,13 +487,13 @@ def test_shared_group_counts_equal_recounting(pkg, oracle, family, monkeypatch):
                 ctx.set_matrix(X); ctx.set_groups(gid, C); ctx.compute_thresholds(0.05); ctx.set_shard(rank, 2)
                 ctx.build_pairs(1); ctx.build_pairs(k)
                 tot = tot + _shard_raw(pkg, ctx, ref0, G)
-        assert np.array_equal(pkg.sharding.derive_tallies(tot, ref0), out["1", k][1])
+        assert np.array_equal(sharding_mirror.derive_tallies(tot, ref0), out["1", k][1])
 
 
 def _shard_raw(pkg, ctx, ref0, G):
     """raw counters of one shard's partial class table (codes it does not own decode as 'unstable/unstable')."""
     code = ctx.get_codes(0, G, 0, G)
-    return pkg.sharding.raw_counters(code, ref0)
+    return sharding_mirror.raw_counters(code, ref0)
 
 
 def test_host_matrix_view_with_leading_dimension(pkg, oracle):
