@@ -39,6 +39,7 @@ for world in (1, 2, 4, 8):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             ctx.set_matrix_device(Xd.data_ptr(), G, S, G, "i64"); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
             ctx.build_pairs(0)
+            torch.cuda.synchronize()   # (one GPU, no exchange: the call returns with the pair kernel still running)
             t1 = time.perf_counter()
             if world == 1:   # the passes are replicated: identical on every rank for every N -- and they must never see the
                 res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, 128, 0)   # garbage table of the stand-in exchange
