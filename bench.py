@@ -9,6 +9,10 @@ makes the convergence test of src/RankCompV3.jl:419 never true, i.e. exactly 128
 the run with the reference's default n_conv = 5 is reported beside it as `converged`, and the tie-rich family (count
 data: two comparisons per pair and sample) as `tie_rich`.
 
+Two more blocks ride on the same line: `float64` (the same shape as Float64 input: the reference's other eltype, ranked
+through the 0.1 tie band) and `config4` (BASELINE config 4, 30 000 x 4 000 -- the shape BASELINE.json names for the
+1/2/4/8-GPU scaling -- forced and converging run, K1 roofline, per-rank stage times when N > 1).
+
 `dtype` is "u16": the pair kernel compares 16-bit sorted positions, bit-sliced over 32-sample blocks (v_bitop3_b32
 borrow chains + v_bcnt_u32_b32); the tallies are integer popcounts and the per-gene statistics fp64.
 `scaling` is "strong": with N GPUs the same 20k x 1k problem is split over the ranks (pair tiles; one RCCL all-gather
@@ -72,6 +76,8 @@ def main() -> None:
     ap.add_argument("--n-iter", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tie-rich", action="store_true")
+    ap.add_argument("--no-float64", action="store_true", help="skip the Float64-input block")
+    ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE config 4 block (30 000 x 4 000)")
     ap.add_argument("--cpu-genes", type=int, default=8000)
     ap.add_argument("--debug-gloo-one-gpu", action="store_true",
                     help="debug only: every rank uses cuda:0 and the table exchange goes through gloo via the host")
@@ -146,15 +152,16 @@ def main() -> None:
                     ctx.comm_init_rank(box[0], rank, world)
         return ctx
 
-    def run_family(family: str, steps: int, warmup: int, n_conv_list):
-        gen = pkg.synth.t0_ranks if family == "t0" else pkg.synth.t1_counts
-        X = gen(G, S, seed)                                   # Int64, like Matrix(df_expr) of count data
+    def run_family(family: str, steps: int, warmup: int, n_conv_list, G=G, S=S, seed=seed, gid=gid, ref0=ref0):
+        gen = {"t0": pkg.synth.t0_ranks, "t1": pkg.synth.t1_counts, "float": pkg.synth.float_expr}[family]
+        X = gen(G, S, seed)                                   # Int64, like Matrix(df_expr) of count data (Float64: log-like expression)
         Xd = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)  # (S, G) row-major == G x S column-major, ld = G
         torch.cuda.synchronize()
         ctx = make_ctx()
+        dt_name = "f64" if X.dtype == np.float64 else "i64"
 
         def step(n_conv: int):
-            ctx.set_matrix_device(Xd.data_ptr(), G, S, G, "i64")
+            ctx.set_matrix_device(Xd.data_ptr(), G, S, G, dt_name)
             ctx.set_groups(gid, len(lev))
             ctx.compute_thresholds(0.01)
             ctx.build_pairs(0)
@@ -190,13 +197,13 @@ def main() -> None:
     value = units * args.steps / dt
     share = info["tiles_owned"] / max(info["tiles_total"], 1)
 
-    def k1_roofline(tm_, info_, ties: bool):
+    def k1_roofline(tm_, info_, ties: bool, G=G, S=S):
         k1_ms = tm_["k1_ms"] / max(tm_["k1_launches"], 1)
         share_ = info_["tiles_owned"] / max(info_["tiles_total"], 1)
         # algorithmic bytes: K1 reads G*S*2 B of 16-bit positions and writes the 4-bit class table
         k1_bytes = (G * S * 2 + G * G / 2) * share_
         peak = valu_peak(plane_bits(G), ties)
-        rate = units * share_ / (k1_ms * 1e-3)
+        rate = (G * (G - 1) // 2) * S * share_ / (k1_ms * 1e-3)
         return {"bound": "valu", "achieved": rate / 1e12, "peak": peak / 1e12, "unit": "Tcmp/s", "frac": rate / peak,
                 "peak_definition": "256 CU x 4 SIMD x 2.4 GHz x 2048 comparisons per (2*bits+4)%s cycles, bits=%d" % (" x 2" if ties else "", plane_bits(G)),
                 "hbm_achieved_GBps": k1_bytes / (k1_ms * 1e-3) / 1e9, "hbm_frac": k1_bytes / (k1_ms * 1e-3) / HBM_PEAK,
@@ -261,6 +268,54 @@ def main() -> None:
                            "ms_per_step": dt1 / st * 1e3, "value": units * st / dt1, "k1_ms": r1["ms_per_launch"], "frac": r1["frac"],
                            "peak": r1["peak"], "achieved": r1["achieved"], "kernel": r1["kernel"], "steps": st,
                            "traffic": traffic_tie[0], "traffic_source": traffic_tie[1]}
+
+    def per_rank(tm_, info_, steps_):
+        """what every rank did in a block, gathered (N > 1 only)"""
+        if world == 1 and not force_comm:
+            return None
+        mine = {"rank": rank, "k1_ms": tm_["k1_ms"] / steps_, "tiles_owned": info_["tiles_owned"], "tiles_total": info_["tiles_total"],
+                "exchange_ms_per_build": tm_["exchange_ms"] / steps_, "transform_ms": tm_["transform_ms"] / steps_, "iter_ms": tm_["iter_ms"] / steps_}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        return allr
+
+    if not args.no_float64 and args.family == "t0":
+        # the reference's other input type (Matrix(df_expr) of Float64, :652): the same shape with log-like expression values,
+        # ranked through the 0.1 band of is_greater (:72) -- every pair needs both band edges (the tie-rich pair kernel)
+        st = max(3, args.steps // 4)
+        _, (ff,), infof = run_family("float", st, 1, [0])
+        dtf, itf, trf, tmf, _ = ff
+        rf = k1_roofline(tmf, infof, bool(infof["has_ties"]))
+        out["float64"] = {"workload": f"synthetic {G} x {S} Float64 (log2(1 + counts) + jitter: values closer than 0.1 apart are ties, :72), "
+                                      f"n_iter={args.n_iter}, n_conv=0", "ms_per_step": dtf / st * 1e3, "value": units * st / dtf, "iterations": itf,
+                          "transform_ms": tmf["transform_ms"] / st, "k1_ms": rf["ms_per_launch"], "iter_ms": tmf["iter_ms"] / st,
+                          "frac": rf["frac"], "kernel": rf["kernel"], "steps": st, "transform_in_lds": infof["transform_in_lds"],
+                          "final_trace": list(trf[-1]) if trf else None}
+
+    if not args.no_config4 and args.family == "t0" and (G, S) == (20000, 1000):
+        # BASELINE config 4 (30 000 x 4 000, the shape BASELINE.json names for the 1/2/4/8-GPU scaling): the same step on
+        # it -- forced 128 passes and the converging run -- for every N; its pair stage is 19-20 ms on one GPU, so the
+        # replicated pass stage weighs a sixth of the step instead of half
+        G4, S4, seed4 = 30000, 4000, 0x5EED0004
+        gid4, _lev4 = pkg.encode_groups(pkg.synth.groups(S4))
+        ref4 = pkg.synth.ref_mask(G4, 3000, seed4)
+        st4 = max(2, args.steps // 5)
+        _, (f4, c4), info4 = run_family("t0", st4, 1, [0, 5], G=G4, S=S4, seed=seed4, gid=gid4, ref0=ref4)
+        dt4, it4, tr4, tm4, _ = f4
+        dt4c, it4c, tr4c, tm4c, _ = c4
+        units4 = (G4 * (G4 - 1) // 2) * S4
+        r4 = k1_roofline(tm4, info4, bool(info4["has_ties"]), G=G4, S=S4)
+        out["config4"] = {"workload": f"BASELINE config 4: synthetic {G4} genes x {S4} samples (T0 family, Int64 input), 2 groups, ref_gene_max=3000, "
+                                      f"n_iter={args.n_iter}, n_conv=0 (exactly {it4} iterations); pair tiles over {world} GPU(s)",
+                          "value": units4 * st4 / dt4, "unit": "comparisons/s", "ms_per_step": dt4 / st4 * 1e3, "steps": st4, "iterations": it4,
+                          "converged": {"value": units4 * st4 / dt4c, "ms_per_step": dt4c / st4 * 1e3, "n_conv": 5, "iterations": it4c,
+                                        "final_trace": list(tr4c[-1]) if tr4c else None},
+                          "stages_ms_per_step": {k: tm4[k] / st4 for k in ("transform_ms", "k1_ms", "k2_full_ms", "iter_ms", "exchange_ms")},
+                          "roofline": r4, "final_trace": list(tr4[-1]) if tr4 else None,
+                          "thresholds": [pkg._ffi.threshold(S4 // 2), pkg._ffi.threshold(S4 - S4 // 2)]}
+        pr4 = per_rank(tm4, info4, st4)
+        if pr4:
+            out["config4"]["ranks"] = pr4
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oracle = ge.load_oracle()

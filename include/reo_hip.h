@@ -19,7 +19,15 @@
  *     the call and no host pointer is retained after return; outputs are
  *     caller-allocated.
  *   - a context is single-owner (not thread-safe); distinct contexts may be
- *     used from distinct threads.  All calls block until their work is done.
+ *     used from distinct threads.  Every call blocks until its outputs are in
+ *     the caller's arrays and its inputs have been read.  ONE exception:
+ *     on one GPU with nothing to exchange reo_build_pairs returns with the
+ *     pair kernel still running (see there); all work of a context is ordered
+ *     on one stream, so later calls need no synchronisation by the caller, a
+ *     host timer around reo_build_pairs alone measures the launch only, and an
+ *     asynchronous failure of that kernel is reported (REO_EHIP) by the next
+ *     call that waits, which also drops the class table so that a retry
+ *     rebuilds it.
  *   - matrices are column-major (the layout Julia hands over at :652).
  */
 #ifndef REO_HIP_H

@@ -236,7 +236,11 @@ class Context:
 
     def set_allreduce(self, fn) -> None:
         """fn(dev_ptr: int, count: int, stream: int) -> None: sum int32[count] (the class table) in place across
-        shards, ordered on the HIP stream `stream` (see include/reo_hip.h)."""
+        shards, ordered on the HIP stream `stream` (see include/reo_hip.h).  None removes the hook."""
+        if fn is None:
+            check(self._L.reo_set_allreduce(self._h, ALLREDUCE_FN(), None))
+            return
+
         def _cb(ptr, count, stream, _user):
             try:
                 fn(int(ptr), int(count), int(stream or 0))
@@ -252,7 +256,11 @@ class Context:
     def set_allgather(self, fn) -> None:
         """fn(send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream: int) -> None: gather `bytes_per_rank` bytes of
         every shard's `send` into `recv + shard * bytes_per_rank` on every shard, ordered on the HIP stream `stream`
-        (the cheaper form of the table exchange, see include/reo_hip.h)."""
+        (the cheaper form of the table exchange, see include/reo_hip.h).  None removes the hook."""
+        if fn is None:
+            check(self._L.reo_set_allgather(self._h, ALLGATHER_FN(), None))
+            return
+
         def _cb(send, recv, nbytes, stream, _user):
             try:
                 fn(int(send), int(recv), int(nbytes), int(stream or 0))

@@ -105,6 +105,18 @@ static hipError_t stream_wait(reo_ctx *c)
     }
 }
 
+// The wait of a call that may be the first to see an asynchronous failure of the pair kernel (reo_build_pairs returns with
+// it in flight on one GPU): the table cannot be trusted then, and a retry must rebuild it.
+static int32_t wait_or_drop_table(reo_ctx *c)
+{
+    const hipError_t e = stream_wait(c);
+    if (e == hipSuccess) return REO_OK;
+    c->built_k = -1;
+    c->table_complete = false;
+    set_error("a kernel queued on this context failed: %s (the class table was dropped: call reo_build_pairs again)", hipGetErrorString(e));
+    return REO_EHIP;
+}
+
 static int32_t use(reo_ctx *c)
 {
     if (!c) { set_error("null context"); return REO_EINVAL; }
@@ -244,6 +256,24 @@ static int32_t exchange_table(reo_ctx *c)
     return REO_OK;
 }
 
+// what the pass kernels report through IterState.fault (kernels.hip: kFaultBarrier, kFaultTallies)
+static int32_t pass_fault(reo_ctx *c)
+{
+    const int32_t f = c->host_state ? c->host_state->fault : 0;
+    if (!f) return REO_OK;
+    if (f == kFaultTallies) {
+        set_error("the iteration passes met tallies that no class table can produce (a gene pair in two states at once): the table in "
+                  "this context is not what reo_build_pairs makes -- an exchange hook delivered wrong words and the scan of its "
+                  "table was switched off (REO_CHECK_HOOK_TABLE=0)");
+        c->built_k = -1;  // nothing may run on this table again
+        c->table_complete = false;
+    } else {
+        set_error("the persistent iteration kernel gave up at a grid barrier (a workgroup did not arrive within its bound); "
+                  "REO_LIGHT=1 runs the same passes as separate launches");
+    }
+    return REO_EHIP;
+}
+
 static int32_t need_complete_table(reo_ctx *c)
 {
     if (c->built_k < 0) { set_error("no class table: call reo_build_pairs first"); return REO_EINVAL; }
@@ -301,6 +331,11 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->light_window = light_window(); c->light_min_g = light_min_genes();
     if (const char *e = getenv("REO_LIGHT_WINDOW")) c->light_window = std::max(1, std::min(31, atoi(e)));  // 2 W + 1 <= 64 window members
     if (const char *e = getenv("REO_LIGHT_MIN_G")) c->light_min_g = std::max(64, atoi(e));
+    // (every switch is read here, once: no getenv on the paths a step takes)
+    if (const char *e = getenv("REO_STATE_MIRROR")) c->state_mirror_wanted = (e[0] != '0');
+    c->debug_passes = getenv("REO_DEBUG_PASSES") != nullptr;
+    c->debug_stamps = getenv("REO_DEBUG_STAMPS") != nullptr;
+    c->k1_stamps = getenv("REO_K1_STAMPS") != nullptr;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return REO_EHIP; }
     // The light passes keep their BH-rank histogram as one partial per XCD, updated by atomics that stay in that XCD's L2.
@@ -337,7 +372,7 @@ void reo_destroy(reo_ctx *c)
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
+    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->check_flag.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     if (c->host_flags) (void)hipHostFree(c->host_flags);
     if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
@@ -500,7 +535,7 @@ int32_t reo_build_pairs(reo_ctx *c, int32_t k)
     if (c && !c->peers.empty()) {
         if ((rc = multi_build_pairs(c, k, build_local))) return rc;
     } else {
-        if (c && c->comm_dead) { set_error("the communicator of this context was aborted after an earlier failure: attach a new one (reo_comm_init_rank)"); return REO_ECOMM; }
+        if (c && c->comm_dead && c->world > 1) { set_error("the communicator of this context was aborted after an earlier failure: attach a new one (reo_comm_init_rank)"); return REO_ECOMM; }
         if (c && !c->comm && c->world <= 1 && !c->ag && !c->ar) {
             // one GPU, nothing to exchange: the pair kernel is left running.  Every later call works on the same stream, so
             // reo_identify_degs queues its first passes behind it without a host round trip in between; an asynchronous
@@ -652,10 +687,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // sorting passes, or a run of light passes; small problems sort every pass.
     // (more than 65 535 genes: sorting passes only -- the light passes keep per-workgroup lists and sums for at most 256
     //  workgroups of 256 genes)
-    {
-        const char *e = getenv("REO_STATE_MIRROR");
-        c->state_mirror = c->light_mode != 2 && !(e && e[0] == '0');
-    }
+    c->state_mirror = c->light_mode != 2 && c->state_mirror_wanted;
     bool small = G < c->light_min_g || c->light_mode == 0 || G > 65535;
     c->it_no_light = G > 65535;  // (the device must know as well: a sorting pass that left need_full clear would wait for light passes nobody enqueues)
     int passes = 0, seen_need_full = 1, light_batches = 0, idle_light = 0, idle_any = 0;  // idle_light: light batches in a row that completed no pass
@@ -678,16 +710,12 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         }
         toc(c);
         if (!c->state_mirror) REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
-        REO_HIP_CHECK(stream_wait(c));
-        if (getenv("REO_DEBUG_PASSES"))
+        if ((rc = wait_or_drop_table(c))) return rc;
+        if (c->debug_passes)
             fprintf(stderr, "batch: %d sorting + %d light launches, passes %d -> %d, need_full %d, done %d, last_full %d, changed genes in front of the next pass %d\n", nfull, nlight,
                     passes, c->host_state->passes, c->host_state->need_full, c->host_state->done, c->host_state->last_full,
                     c->host_state->delta_cnt[c->host_state->passes & 1]);
-        if (c->host_state->fault) {
-            set_error("the persistent iteration kernel gave up at a grid barrier (a workgroup did not arrive within its bound); "
-                      "REO_LIGHT=1 runs the same passes as separate launches");
-            return REO_EHIP;
-        }
+        if ((rc = pass_fault(c))) return rc;
         idle_any = c->host_state->passes == passes ? idle_any + 1 : 0;
         if (idle_any >= 4) {  // no kind of batch completes a pass any more: an error of the loop control, never a reason to spin
             set_error("the iteration made no progress in four batches of launches (passes %d, need_full %d): loop control fault", passes, c->host_state->need_full);
@@ -717,7 +745,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         c->k2_modes.assign(c->k2_idx, 0);
         REO_HIP_CHECK(hipMemcpyAsync(c->k2_modes.data(), c->modes.p, sizeof(int32_t) * nk2, hipMemcpyDeviceToHost, c->stream));
     }
-    if (getenv("REO_DEBUG_STAMPS")) {  // diagnostic builds (-DREO_STAMPS): marks of workgroup 0 in the last light launches, 10 ns units
+    if (c->debug_stamps) {  // diagnostic builds (-DREO_STAMPS): marks of workgroup 0 in the last light launches, 10 ns units
         unsigned long long st[24];
         REO_HIP_CHECK(hipMemcpy(st, c->scal.p + 32, sizeof st, hipMemcpyDeviceToHost));
         if (c->light_mode == 2) {
@@ -733,9 +761,9 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     }
     if (iters_run) *iters_run = passes;
     REO_HIP_CHECK(hipMemcpyAsync(result, c->result.p, sizeof(double) * 15 * G, hipMemcpyDeviceToHost, c->stream));
-    REO_HIP_CHECK(stream_wait(c));
+    if ((rc = wait_or_drop_table(c))) return rc;
     collect_timings(c);
-    return REO_OK;
+    return pass_fault(c);  // (the replay, too, derives every gene's tallies)
 }
 
 int32_t reo_mccullagh(reo_ctx *c, const int32_t *cont, int64_t n, double *out)

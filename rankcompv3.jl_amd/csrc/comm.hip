@@ -178,6 +178,13 @@ int32_t multi_build_pairs(reo_ctx *lead, int32_t k, int32_t (*build_local)(reo_c
     std::vector<reo_ctx *> all{lead};
     all.insert(all.end(), lead->peers.begin(), lead->peers.end());
     const int world = static_cast<int>(all.size());
+    // after comm_abort every communicator is gone while world stays above 1: answer before any work or NCCL group starts
+    if (world > 1 && !lead->multi_one_device)
+        for (reo_ctx *c : all)
+            if (c->comm_dead || !c->comm) {
+                set_error("the communicators of this multi-GPU context were aborted after an earlier failure: destroy it and create a new one");
+                return REO_ECOMM;
+            }
     std::vector<int32_t> rcs(all.size(), REO_OK);
     std::vector<std::string> errs(all.size());
     std::vector<std::thread> th;

@@ -1353,6 +1353,15 @@ struct IterArgs {
 #define STAMP(a, k) do { } while (0)
 #endif
 
+// A gene's tallies broke their invariant: tell the host (both copies of the state: the one it copies and the pinned
+// mirror it reads).  Any thread may call this; the word only ever goes from 0 to a code, and no kernel of the passes
+// branches on it, so the plain stores race with nothing.
+__device__ __forceinline__ void raise_fault(const IterArgs &a, int code)
+{
+    a.st->fault = code;
+    if (a.host_st) a.host_st->fault = code;
+}
+
 // scal[]: 0 se of the last pass; 1..4 quantile windows wa_lo wa_hi wb_lo wb_hi for the next light pass;
 // 5..8 their half widths (value units) around the exact quantiles
 constexpr int kCandMax = 64;     // candidates per quantile window (one per lane of the wave that sorts them)
@@ -1436,19 +1445,31 @@ __global__ void k_mccullagh(const int32_t *__restrict__ cont, int64_t n, double 
     for (int t = 0; t < 5; ++t) out[i * 5 + t] = o[t];
 }
 
-// one gene: raw counters -> 9 tallies (:403)
-__device__ __forceinline__ void tallies_of(const int32_t *__restrict__ raw, bool in_ref, int nref, int i, int32_t (&c)[9])
+// one gene: raw counters (registers) -> 9 tallies (:403).  Returns false when a tally is negative.  Five of the nine are
+// differences of counters, which a class table keeps non-negative because a pair holds ONE state per side; a table that
+// breaks this (only a caller's exchange hook can deliver one, and reo_build_pairs scans what a hook delivers) would give
+// McCullagh's formulas R > n: log of a negative number, NaN delta1 -- and NaN is what the rank searches of the sorting
+// path cannot take (round 3's GPU fault: k3_abs_rank stored sorted_p[G + r]).  With nine non-negative
+// tallies 0 <= R1 <= a, 0 <= R2 <= d, a, d >= b >= 0 hold by construction and every number below is finite, so the
+// callers replace the statistics of a gene that fails by those of an empty table and raise IterState.fault.
+__device__ __forceinline__ bool tallies_from(const int4 &r0, const int4 &r1, int total, int32_t (&c)[9])
 {
-    const int4 r0 = reinterpret_cast<const int4 *>(raw)[2 * i], r1 = reinterpret_cast<const int4 *>(raw)[2 * i + 1];
     const int cLt = r0.x, cHt = r0.y, tLt = r0.z, tHt = r0.w, LL = r1.x, LH = r1.y, HL = r1.z, HH = r1.w;
-    const int total = nref - (in_ref ? 1 : 0);  // the diagonal is never set (:363,385)
     c[0] = LL; c[2] = LH; c[6] = HL; c[8] = HH;
     c[1] = cLt - LL - LH;
     c[7] = cHt - HL - HH;
     c[3] = tLt - LL - HL;
     c[5] = tHt - LH - HH;
     c[4] = total - (cLt + cHt + c[3] + c[5]);
+    return (c[0] | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7] | c[8]) >= 0;  // (no sign bit anywhere)
 }
+
+__device__ __forceinline__ bool tallies_of(const int32_t *__restrict__ raw, bool in_ref, int nref, int i, int32_t (&c)[9])
+{
+    const int4 r0 = reinterpret_cast<const int4 *>(raw)[2 * i], r1 = reinterpret_cast<const int4 *>(raw)[2 * i + 1];
+    return tallies_from(r0, r1, nref - (in_ref ? 1 : 0), c);  // the diagonal is never set (:363,385)
+}
+
 
 // stand-alone form for reo_tally (tallies only)
 __global__ __launch_bounds__(256) void k3_tallies(const int32_t *__restrict__ raw, const uint8_t *__restrict__ refbytes, int nref, int G,
@@ -1475,9 +1496,13 @@ __global__ __launch_bounds__(256) void k3_derive(IterArgs a)
     }
     if (i >= a.G) return;
     int32_t c[9];
-    tallies_of(a.raw, a.refbytes[cur][i] != 0, nref, i, c);
-    double o[5];
-    mccullagh3<true>(c, o);
+    const bool ok = tallies_of(a.raw, a.refbytes[cur][i] != 0, nref, i, c);
+    double o[5] = {1.0, 0.0, 0.0, 0.0, 0.0};
+    if (ok) mccullagh3<true>(c, o);
+    if (!ok || !(fabs(o[1]) < INFINITY)) {  // (the second test cannot fire on non-negative tallies: belt and braces)
+        o[0] = 1.0; o[1] = o[2] = o[3] = o[4] = 0.0;
+        raise_fault(a, kFaultTallies);
+    }
     const size_t Gs = a.G;
     double *result = a.result;
     result[i] = o[0];
@@ -1667,7 +1692,9 @@ __global__ __launch_bounds__(kMergeThreads) void k3_merge_rank(IterArgs a, int n
     for (int o = kMergeLanes >> 1; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
     bool in = false;
     if (sub == 0 && gene < G) {
-        const int rank = p + count;
+        // (a permutation of 0..G-1 whenever every delta1 is finite, which k3_derive sees to; the clamp keeps the three
+        //  stores below inside their allocations whatever the values are)
+        const int rank = min(p + count, G - 1);
         a.rank_s[gene] = rank;
         a.sorted_d[rank] = v;
         if ((rank & 63) == 0) a.sorted_spl[rank >> 6] = v;  // packed splitters for k3_abs_rank
@@ -1753,6 +1780,11 @@ __global__ __launch_bounds__(256) void k3_abs_rank(IterArgs a, int npart)
     } else {        // larger |w|: w < v or w > -v
         rank = lbv + (G - ubn) + (r - lbv);
     }
+    // rank is a permutation of 0..G-1 when sorted_d is sorted and v is one of its (finite) elements.  Whatever the three
+    // searches return otherwise -- a NaN v fails every comparison: all three counts 0, rank = G + r, the out-of-bounds
+    // store of round 3's fault -- the clamp keeps this store, and k3_finalize's sorted_p[rank_a[i]] and tail[rank >> 10],
+    // inside their allocations.
+    rank = min(max(rank, 0), G - 1);
     a.rank_a[i] = rank;
     const double p = normal_p(v, se);
     a.result[i] = p;
@@ -2486,13 +2518,11 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     }
     if (i < G) {
         int32_t c[9];
-        const int total = r.nref - (inref ? 1 : 0);  // the diagonal is never set (:363,385)
-        c[0] = r1.x; c[2] = r1.y; c[6] = r1.z; c[8] = r1.w;
-        c[1] = r0.x - r1.x - r1.y; c[7] = r0.y - r1.z - r1.w; c[3] = r0.z - r1.x - r1.z; c[5] = r0.w - r1.y - r1.w;
-        c[4] = total - (r0.x + r0.y + c[3] + c[5]);
-        double out[5];
-        mccullagh3<false>(c, out);
+        const bool tok = tallies_from(r0, r1, r.nref - (inref ? 1 : 0), c);  // the diagonal is never set (:363,385)
+        double out[5] = {1.0, 0.0, 0.0, 0.0, 0.0};
+        if (tok) mccullagh3<false>(c, out);
         v = out[1];
+        if (!tok || !(fabs(v) < INFINITY)) { v = 0.0; raise_fault(a, kFaultTallies); }
         if (!TAIL) STAMP(a, 4);
         a.result[11 * static_cast<size_t>(G) + i] = v;
 #pragma unroll
@@ -2653,7 +2683,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned *bar, unsigned nwg, unsign
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull || __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fault, kFaultBarrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
             }
@@ -2699,7 +2729,7 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
     double d1 = 0.0, p = 1.0, se = 0.0;
     int own_rank = 0;
     unsigned gen = 0;
-    bool windows_moved = false;
+    bool windows_moved = false, tally_fault = false;
     while (true) {
         const int par = r.t & 1;
         LightCnt *lc = &ls->slot[par].lc;
@@ -2715,13 +2745,11 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
                 r1.x += d[4]; r1.y += d[5]; r1.z += d[6]; r1.w += d[7];
             }
             int32_t c[9];
-            const int total = r.nref - (inref ? 1 : 0);  // the diagonal is never set (:363,385)
-            c[0] = r1.x; c[2] = r1.y; c[6] = r1.z; c[8] = r1.w;
-            c[1] = r0.x - r1.x - r1.y; c[7] = r0.y - r1.z - r1.w; c[3] = r0.z - r1.x - r1.z; c[5] = r0.w - r1.y - r1.w;
-            c[4] = total - (r0.x + r0.y + c[3] + c[5]);
-            double out[5];
-            mccullagh3<false>(c, out);
+            const bool tok = tallies_from(r0, r1, r.nref - (inref ? 1 : 0), c);  // the diagonal is never set (:363,385)
+            double out[5] = {1.0, 0.0, 0.0, 0.0, 0.0};
+            if (tok) mccullagh3<false>(c, out);
             d1 = out[1];
+            if (!tok || !(fabs(d1) < INFINITY)) { d1 = 0.0; tally_fault = true; }
             stc<true>(hist + i, 0);  // this parity's histogram: last read two passes ago
             belowA = d1 < win[0]; inA = !belowA && d1 <= win[1];
             belowB = d1 < win[2]; inB = !belowB && d1 <= win[3];
@@ -2846,6 +2874,7 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
         if (!r.active) break;
     }
     // ---------------- hand the state back to the launches that follow
+    if (tally_fault) raise_fault(a, kFaultTallies);  // (after the last barrier: the barriers poll the same word to leave early)
     if (live) {
         int4 *o = reinterpret_cast<int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
         o[0] = r0; o[1] = r1;
@@ -3183,9 +3212,11 @@ int32_t launch_k1(reo_ctx *c, int k)
             std::memcpy(c->k1_items_key, key, sizeof key);
         }
         a.items = c->k1_items.p;
-        if (getenv("REO_K1_STAMPS")) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), (std::max<size_t>(c->k1_items_n, 1) * 4 + 2) * sizeof(unsigned long long)));
+        if (c->k1_stamps) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), (std::max<size_t>(c->k1_items_n, 1) * 4 + 2) * sizeof(unsigned long long)));
     }
-    if (!c->table_prezeroed) REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, c->table.n * sizeof(uint32_t), c->stream));
+    // (every reader of the table -- the passes, the pack, a sum hook's element count, the scan of a hook's table -- works on
+    //  G * kPlanes * Wp words, which is also what the transform's early clear covers; a grow-only buffer may be larger)
+    if (!c->table_prezeroed) REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * kPlanes * c->Wp * sizeof(uint32_t), c->stream));
     c->table_prezeroed = false;
     if (units.empty()) return REO_OK;
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
@@ -3307,14 +3338,13 @@ int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
 int32_t launch_check_table(reo_ctx *c, int *bad)
 {
     *bad = 0;
-    DevBuf<int32_t> flag;
-    int32_t rc = flag.ensure(1);
+    int32_t rc = c->check_flag.ensure(1);  // (kept in the context: an allocation per build would put a device-wide hipFree on the exchange path)
     if (rc) return rc;
-    REO_HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(int32_t), c->stream));
+    REO_HIP_CHECK(hipMemsetAsync(c->check_flag.p, 0, sizeof(int32_t), c->stream));
     const int G = static_cast<int>(c->G);
-    k_check_table<<<(G + 3) / 4, 256, 0, c->stream>>>(c->table.p, G, c->Wp, flag.p);
+    k_check_table<<<(G + 3) / 4, 256, 0, c->stream>>>(c->table.p, G, c->Wp, c->check_flag.p);
     int32_t h = 0;
-    REO_HIP_CHECK(hipMemcpyAsync(&h, flag.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    REO_HIP_CHECK(hipMemcpyAsync(&h, c->check_flag.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));
     *bad = h;
     return REO_OK;

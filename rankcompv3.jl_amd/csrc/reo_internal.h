@@ -38,9 +38,11 @@ struct IterState {
     int32_t raw_pass;  // the tally counters hold the tallies of this pass (-1: none)
     int32_t nref_prev; // nref of the last executed pass (for recomputing its outputs)
     int32_t last_full; // the last executed pass ran on the sorting path: every output column is in place
-    int32_t fault;     // the persistent light kernel gave up at a grid barrier (bounded spin expired)
+    int32_t fault;     // 0, or why the passes cannot be trusted (codes below); api.hip answers REO_EHIP
     int32_t pad[3];
 };
+constexpr int kFaultBarrier = 1;   // the persistent light kernel gave up at a grid barrier (bounded spin expired)
+constexpr int kFaultTallies = 2;   // a gene's tallies broke their invariant: not a class table (kernels.hip, tallies_from)
 
 // Light passes as two launches per pass (kernels.hip, kl_head / kl_rank): the loop state of one batch of launches as an
 // append-only log, so that no kernel reads a word that another workgroup of the same launch writes.  rec[b] = the state
@@ -202,6 +204,7 @@ struct reo_ctx {
     // owner = index % world), pack and gather buffers
     std::vector<uint32_t> units_all_host;
     reo::DevBuf<uint32_t> units_all, xsend, xrecv;
+    reo::DevBuf<int32_t> check_flag;    // [1] verdict of k_check_table (kernels.hip, launch_check_table)
 
     // iteration state
     reo::DevBuf<uint32_t> refbits[2];   // [Wp]
@@ -236,6 +239,8 @@ struct reo_ctx {
     int k2_idx = 0;                     // K2 launches of the running call
     bool it_no_light = false;           // the running call has given up on light passes (two light batches in a row completed no pass)
     reo::IterState *host_state = nullptr;  // pinned
+    bool state_mirror_wanted = true;       // REO_STATE_MIRROR=0 (read once, in reo_create, like every other switch)
+    bool debug_passes = false, debug_stamps = false, k1_stamps = false;  // REO_DEBUG_PASSES, REO_DEBUG_STAMPS, REO_K1_STAMPS (diagnostics)
     bool state_mirror = false;             // the kernels write what the host reads of IterState straight into host_state (REO_STATE_MIRROR=0: a copy per batch)
     uint8_t *host_ref = nullptr;           // pinned: the caller's reference mask on its way to the device (reo_identify_degs)
     size_t host_ref_cap = 0;

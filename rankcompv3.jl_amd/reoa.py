@@ -108,9 +108,11 @@ def pseudobulk_group(values: np.ndarray, n_pseudo: int, g_name: str, seed: int, 
 
 def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: int = 0, n_pseudo: int = 0,
             use_hk_genes: str = "yes", hk_file: str | None = None, gene_name_type: str = "ENSEMBL",
-            ref_gene_max: int = 3000, ref_gene_min: int = 100, seed: int = 0, sums=host_sums):
+            ref_gene_max: int = 3000, ref_gene_min: int = 100, seed: int = 0, sums=host_sums, align_meta: bool = False):
     """Everything `reoa` does before `identify_degs` (:565-651).  Returns a dict with the expression
-    matrix (genes x samples), the sample table (Name, Group), gene names, group levels and the reference mask."""
+    matrix (genes x samples), the sample table (Name, Group), gene names, group levels and the reference mask.
+    `align_meta` (not in the reference): look every expression column's group up by sample name instead of taking the
+    meta rows in their own order, which is what the reference does (:653) and the default here."""
     import pandas as pd
     if not (os.path.isfile(fn_expr) and os.path.isfile(fn_meta)):  # :565
         raise ArgumentError(f"{fn_expr}, or {fn_meta}, does not exist or is not a regular file.")
@@ -152,18 +154,33 @@ def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: 
     else:
         data_cols = list(expr.columns[1:])  # expr[:, 2:end], :614
         data = expr[data_cols].to_numpy()
-        by_name = dict(zip(meta["Name"], meta["Group"]))
         sample_names = data_cols
-        # the reference passes meta.Group as it stands (:653): it assumes the meta rows are in column order
-        sample_groups = list(meta["Group"]) if list(meta["Name"]) == data_cols else [by_name.get(c) for c in data_cols]
-        if any(g is None for g in sample_groups):
-            raise ArgumentError("Expression matrix has sample columns that the meta data does not describe")
+        sample_groups = None  # from the meta rows, below (:613,619-624,653)
     data = np.asarray(data)
     all_names = list(sample_names)
     s_inds = (data > 0).sum(axis=0) > min_profiles  # :618
     data = data[:, s_inds]
     sample_names = [n for n, k in zip(sample_names, s_inds) if k]
-    sample_groups = [g for g, k in zip(sample_groups, s_inds) if k]
+    if sample_groups is not None:
+        sample_groups = [g for g, k in zip(sample_groups, s_inds) if k]
+    else:
+        # meta_group = meta minus the rows whose FIRST column names a dropped profile (:619-624), and identify_degs gets
+        # meta_group.Group as it stands (:653): row t of the meta table labels column t of the matrix, whatever the names
+        # say.  A meta table in another order than the columns therefore mislabels samples in the reference; this build
+        # does the same and says so (align_meta=True looks the groups up by name instead).
+        dropped = set(all_names) - set(sample_names)
+        kept = meta[~meta.iloc[:, 0].isin(dropped)]
+        if align_meta:
+            by_name = dict(zip(meta["Name"], meta["Group"]))
+            sample_groups = [by_name.get(c) for c in sample_names]
+            if any(g is None for g in sample_groups):
+                raise ArgumentError("Expression matrix has sample columns that the meta data does not describe")
+        else:
+            sample_groups = list(kept["Group"])
+            if list(kept["Name"]) != sample_names:
+                log.warning("WARN: the rows of the meta table are not in the order of the expression matrix's columns; like the "
+                            "reference (src/RankCompV3.jl:653) the group of row t labels column t.  Pass align_meta=True to "
+                            "match samples by name instead.")
     inds = (data > 0).sum(axis=1) > min_features  # :626
     gene_names = [n for n, k in zip(gene_names, inds) if k]
     data = data[inds, :]
@@ -176,8 +193,14 @@ def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: 
     ref = random_ref()
     if use_hk_genes == "yes":  # :636-650
         hk = hk_file or os.environ.get("REO_HK_FILE")
+        if hk is None:  # the reference's default: hk_gene_file/HK_genes_info.tsv of its own checkout (:546)
+            for root in (os.environ.get("REO_REFERENCE_DIR"), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))):
+                cand = os.path.join(root, "hk_gene_file", "HK_genes_info.tsv") if root else None
+                if cand and os.path.isfile(cand):
+                    hk = cand
+                    break
         if hk is None:
-            log.warning("no house-keeping gene table given (hk_file= / REO_HK_FILE): the reference reads its bundled "
+            log.warning("no house-keeping gene table given (hk_file= / REO_HK_FILE / REO_REFERENCE_DIR): the reference reads its bundled "
                         "hk_gene_file/HK_genes_info.tsv here (src/RankCompV3.jl:546,641-649), a data asset that is not shipped with "
                         "this build.  Using the random reference set instead (what the reference does when fewer than "
                         "ref_gene_min house-keeping genes match); pass use_hk_genes=\"no\" to silence this.")
@@ -240,10 +263,11 @@ def reoa(fn_expr: str = "fn_expr.txt", fn_meta: str = "fn_meta.txt", *, expr_thr
          min_features: int = 0, pval_reo: float = 0.01, pval_deg: float = 1.0, padj_deg: float = 0.05,
          n_pseudo: int = 0, use_hk_genes: str = "yes", hk_file: str | None = None, gene_name_type: str = "ENSEMBL",
          ref_gene_max: int = 3000, ref_gene_min: int = 100, n_iter: int = 128, n_conv: int = 5, work_dir: str = "./",
-         use_testdata: str = "no", seed: int = 0, device: int = -1, testdata_dir: str | None = None):
+         use_testdata: str = "no", seed: int = 0, device: int = -1, testdata_dir: str | None = None, align_meta: bool = False):
     """reoa(fn_expr, fn_meta; kwargs...) -- src/RankCompV3.jl:536-555.  `expr_threshold` is accepted and
     unused, as in the reference (:539).  Extra keywords: `seed` (the reference's RNG is unseeded),
-    `device`, `testdata_dir` (where fn_expr.txt / fn_meta.txt of the reference's test/ directory live)."""
+    `device`, `testdata_dir` (where fn_expr.txt / fn_meta.txt of the reference's test/ directory live), `align_meta`
+    (match samples to meta rows by name; the reference and the default take the meta rows in their own order, :653)."""
     work_dir = os.path.abspath(work_dir)
     if use_testdata == "yes":  # :559-562
         d = testdata_dir or os.environ.get("REO_TESTDATA_DIR") or os.path.join(
@@ -259,7 +283,7 @@ def reoa(fn_expr: str = "fn_expr.txt", fn_meta: str = "fn_meta.txt", *, expr_thr
 
     prep = prepare(fn_expr, fn_meta, min_profiles=min_profiles, min_features=min_features, n_pseudo=n_pseudo,
                    use_hk_genes=use_hk_genes, hk_file=hk_file, gene_name_type=gene_name_type,
-                   ref_gene_max=ref_gene_max, ref_gene_min=ref_gene_min, seed=seed, sums=gpu_sums)
+                   ref_gene_max=ref_gene_max, ref_gene_min=ref_gene_min, seed=seed, sums=gpu_sums, align_meta=align_meta)
     run = run_identify_degs(prep["data"], prep["sample_groups"], prep["gene_names"], pval_reo, pval_deg, padj_deg,
                             prep["ref"], n_iter, n_conv, seed=seed, device=device)  # :652-662
     for p, (d, n) in enumerate(run.trace):

@@ -1151,6 +1151,50 @@ def test_a_hook_that_delivers_wrong_words_is_refused(pkg):
             ctx.tally(pkg.synth.ref_mask(G, 300, seed))   # still no complete table
 
 
+@pytest.mark.parametrize("garbage", ["ones", "random"])
+def test_passes_on_an_inconsistent_table_answer_an_error_not_a_fault(pkg, oracle, monkeypatch, garbage):
+    """Round 3's GPU memory fault, as a regression test: with the scan of a hook's table switched off
+    (REO_CHECK_HOOK_TABLE=0, a timing knob) the iteration passes get a table in which pairs hold two states.  The
+    tallies derived from its counters go negative, McCullagh's logarithms would give NaN, and a NaN delta1 made
+    k3_abs_rank store sorted_p[G + r].  The pass kernels now refuse such tallies (IterState.fault ->
+    REO_EHIP), keep delta1 finite and clamp every rank; the context drops the table and works again after a rebuild."""
+    import torch
+    monkeypatch.setenv("REO_CHECK_HOOK_TABLE", "0")
+    monkeypatch.setenv("REO_LIGHT_MIN_G", "64")
+    G, S, seed, world = 5000, 64, 0x5EED0071, 2
+    X = pkg.synth.t0_ranks(G, S, seed)
+    gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+    ref0 = pkg.synth.ref_mask(G, 600, seed)
+    dev = torch.device("cuda", 0)
+
+    def gather(send, recv, nbytes, stream):
+        torch.cuda.ExternalStream(stream, device=dev).synchronize()
+        dst = torch.as_tensor(pkg.dist._RawDevBytes(recv, nbytes * world), device=dev)
+        if garbage == "ones":
+            dst.fill_(0xFF)
+        else:
+            gen = torch.Generator(device=dev); gen.manual_seed(7)
+            dst.copy_(torch.randint(0, 256, (nbytes * world,), dtype=torch.uint8, device=dev, generator=gen))
+        torch.cuda.synchronize()
+
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+        ctx.set_shard(1, world)
+        ctx.set_allgather(gather)
+        ctx.build_pairs(0)   # not scanned: accepted
+        with pytest.raises(pkg.ReoError, match="no class table can produce"):
+            ctx.identify_degs(ref0, 1.0, 0.05, 12, 0)
+        with pytest.raises(pkg.ReoError, match="no class table"):
+            ctx.identify_degs(ref0, 1.0, 0.05, 12, 0)   # the table was dropped
+        ctx.set_shard(0, 1)
+        ctx.set_allgather(None)
+        ctx.build_pairs(0)
+        res, it, tr = ctx.identify_degs(ref0, 1.0, 0.05, 12, 0)
+    exp, eit, etr = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.01, 1.0, 0.05, ref0, 12, 0, seed)
+    assert it == eit and tr == etr
+    _check_result(res, exp)
+
+
 @pytest.mark.parametrize("family", ["t0", "t1"])
 def test_workgroup_form_of_the_pair_kernel_still_matches(pkg, oracle, monkeypatch, family):
     """REO_K1_WAVE=0 selects round 2's workgroup form of K1 (kept for > 2 groups and as a cross-check): same table.  So does

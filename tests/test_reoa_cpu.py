@@ -160,6 +160,42 @@ def test_df_meta_keeps_the_meta_files_own_row_and_column_order(R, tmp_path):
     e = _write(tmp_path, "e.tsv", "gene\ts1\ts2\ts3\ts4\nA\t1\t0\t3\t4\nB\t1\t0\t5\t6\nC\t2\t0\t1\t1\n")
     m = _write(tmp_path, "m.tsv", "sample\tgrp\tbatch\ns4\ty\tb2\ns2\tx\tb2\ns1\tx\tb1\ns3\ty\tb1\n")
     p = R.prepare(e, m, use_hk_genes="no")            # s2 has no expressed gene: dropped by the profile filter
-    assert p["sample_names"] == ["s1", "s3", "s4"] and p["sample_groups"] == ["x", "y", "y"]
+    # like the reference (:653) the groups are the meta rows' in THEIR order -- row t labels column t, names unchecked --
+    # so this meta table mislabels s1 and s4 there and here (a warning says so) ...
+    assert p["sample_names"] == ["s1", "s3", "s4"] and p["sample_groups"] == ["y", "x", "y"]
     assert list(p["meta"].columns) == ["Name", "Group", "batch"]
     assert p["meta"]["Name"].tolist() == ["s4", "s1", "s3"] and p["meta"]["batch"].tolist() == ["b2", "b1", "b1"]
+    # ... and align_meta=True (this build's extra) matches by sample name instead
+    q = R.prepare(e, m, use_hk_genes="no", align_meta=True)
+    assert q["sample_names"] == ["s1", "s3", "s4"] and q["sample_groups"] == ["x", "y", "y"]
+    assert q["meta"]["Name"].tolist() == ["s4", "s1", "s3"]
+
+
+def test_meta_rows_in_another_order_warn_and_fewer_rows_than_columns_fail(R, pkg, tmp_path, caplog):
+    """:653 hands meta_group.Group to identify_degs as it stands; a meta table that describes fewer profiles than the matrix has
+    columns fails there with DimensionMismatch (:355)."""
+    import logging
+    e = _write(tmp_path, "e.tsv", "gene\ts1\ts2\ts3\ts4\nA\t1\t2\t3\t4\nB\t1\t1\t5\t6\n")
+    m = _write(tmp_path, "m.tsv", "sample\tgrp\ns2\tx\ns1\ty\ns3\tx\ns4\ty\n")
+    with caplog.at_level(logging.WARNING):
+        p = R.prepare(e, m, use_hk_genes="no")
+    assert p["sample_groups"] == ["x", "y", "x", "y"] and any("not in the order" in r.message for r in caplog.records)
+    m2 = _write(tmp_path, "m2.tsv", "sample\tgrp\ns1\tx\ns3\ty\n")   # s2, s4 undescribed: 2 labels for 4 columns
+    p2 = R.prepare(e, m2, use_hk_genes="no")
+    assert len(p2["sample_groups"]) == 2 and p2["data"].shape[1] == 4
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.run_identify_degs(p2["data"], p2["sample_groups"], p2["gene_names"], 0.01, 1.0, 0.05, p2["ref"], 1, 1)  # (fails before any GPU call)
+
+
+def test_hk_table_is_found_in_a_reference_checkout(R, tmp_path, monkeypatch):
+    """use_hk_genes="yes" without hk_file: REO_HK_FILE, then hk_gene_file/HK_genes_info.tsv under REO_REFERENCE_DIR (:546)."""
+    genes = [f"ENSG{i:05d}" for i in range(200)]
+    rows = "\n".join(f"{g}\t" + "\t".join(str((i * 7 + s) % 11 + 1) for s in range(4)) for i, g in enumerate(genes))
+    e = _write(tmp_path, "e.tsv", "Name\ts1\ts2\ts3\ts4\n" + rows + "\n")
+    m = _write(tmp_path, "m.tsv", "Name\tGroup\ns1\tx\ns2\tx\ns3\ty\ns4\ty\n")
+    (tmp_path / "ref" / "hk_gene_file").mkdir(parents=True)
+    (tmp_path / "ref" / "hk_gene_file" / "HK_genes_info.tsv").write_text("Name\tENSEMBL\n" + "\n".join(f"n{i}\t{g}" for i, g in enumerate(genes[:120])) + "\n")
+    monkeypatch.delenv("REO_HK_FILE", raising=False)
+    monkeypatch.setenv("REO_REFERENCE_DIR", str(tmp_path / "ref"))
+    p = R.prepare(e, m)
+    assert p["ref"].sum() == 120 and p["ref"][:120].all()
