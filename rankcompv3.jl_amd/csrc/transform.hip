@@ -17,6 +17,7 @@
 // PLANES over blocks of 32 samples (t_slice), because [pos_j < lo_i] for 32 samples at once is a borrow chain
 // of one v_bitop3_b32 per bit.  Every group is padded to whole 32-sample blocks; padding samples have
 // lo = hi = 0, which no position is below.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -155,9 +156,7 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
                                                  uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
                                                  uint16_t *__restrict__ hi, int32_t *__restrict__ flags)
 {
-    using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typename sorter::storage_type &storage = *reinterpret_cast<typename sorter::storage_type *>(smem);
     const int t = threadIdx.x;
     const int c = blockIdx.x;  // one sample per workgroup; its three output rows are whole lines of its own
     if (c >= S) {  // one workgroup per padding slot too (slots[S ..]): rows of zeros -- lo = hi = 0 is below no position
@@ -198,11 +197,11 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     diff = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) diff |= red[w];
-    __syncthreads();  // red is part of the sort's storage
+    __syncthreads();  // red is overwritten by the histogram
     const unsigned begin_bit = diff ? static_cast<unsigned>(__builtin_ctzll(diff)) : 0u;
     const unsigned nbits = diff ? 64u - static_cast<unsigned>(__builtin_clzll(diff)) - begin_bit : 1u;
-    if (nbits > 31) {  // workgroup-uniform
-        if (t == 0) atomicOr(flags + 4, 1);
+    if (nbits > 31) {  // workgroup-uniform: t_sample_wide ranks keys of any width
+        if (t == 0) atomicOr(flags + 5, 1);
         return;
     }
     const uint32_t mask = (1u << nbits) - 1u;
@@ -354,76 +353,283 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
             if (tied && *anytie == 0) atomicOr(anytie, 1);
             return;
         }
-        __syncthreads();  // a crowded bucket: the radix sort below starts from scratch in the same LDS
     }
-    uint32_t k[IPT];
-    uint16_t v[IPT];
-#pragma unroll
-    for (int e = 0; e < IPT; ++e) {
-        const int i = e * 1024 + t;
-        if (i < G) { k[e] = static_cast<uint32_t>((kKeep ? kk[e] : Codec<T>::enc(col[i])) >> begin_bit) & mask; v[e] = static_cast<uint16_t>(i); }
-        else { k[e] = 1u << nbits; v[e] = 0xFFFFu; }
+    // anything else -- keys wider than 24 bits, a crowded lossy bucket, Float64 (whose band is not an equality) -- is ranked
+    // by t_sample_wide below: the caller launches it when this flag comes back
+    if (t == 0) atomicOr(flags + 5, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// t_sample_wide: ranking by SAMPLE-SPLITTER BUCKETS for keys of any width and any distribution -- Float64 input with the
+// reference's 0.1 band (/root/reference/src/RankCompV3.jl:72), Int64 keys that vary in more than 24 bits, and samples whose
+// compressed histogram (t_sample) met a crowded bucket.  One workgroup per sample, no sort of the genes, no library call:
+//   1. 1024 of the sample's order-preserving 64-bit codes (every G/1024-th gene; the largest is replaced by the column's
+//      maximum) are sorted in LDS (bitonic, one key per thread): the SPLITTERS.  Buckets follow the data's own density --
+//      an arithmetic bucket function cannot: log-expression is a spike of zeros a thousand octaves below a few octaves of
+//      values.  Splitter s owns SUB + 1 buckets: the codes strictly between splitters s - 1 and s, cut into SUB equal pieces
+//      of the code interval (16 below 20 481 genes: one or two genes per bucket), and the codes EQUAL to splitter s (a
+//      heavily repeated value is in the sample, so its copies sit in a bucket of their own and are never scanned);
+//   2. a histogram of the buckets (binary search among the splitters; the returned count is the gene's slot inside its
+//      bucket), exclusive prefix sums;
+//   3. every gene leaves 16 bits of its code (its offset inside the bucket's interval, scaled to 16 bits) and its index at
+//      its slot (LDS, bucket order);
+//   4. every question the transform asks is a RANK QUERY "how many genes have a code below c": the prefix sum of c's
+//      bucket + a scan of that bucket's members (16-bit compares; a member that agrees with c in all 16 bits has its whole
+//      key fetched from the column, unless the interval is narrower than 2^16 codes).  pos = rank of the gene's own
+//      code (equal codes in slot order), lo = rank of the lowest code still tied with it, hi = rank just past the
+//      highest.  For Int64 the tie is equality and all three come out of the scan of the gene's own bucket.  For Float64
+//      the two band edges are found in CODE space with the reference's own predicate abs(x - y) < 0.1 in fp64:
+//      fl(x - y) is monotone in y, so the tied codes are an interval around the gene's code; start at x -+ 0.1, gallop,
+//      bisect (two or three evaluations unless x - 0.1 cancels to something tiny).  Exact, like the band search in the
+//      sorted keys that it replaces.
+// Never gives up: a crowded bucket only costs its own members a longer scan.  Arrival slot, bucket and the 16 offset bits are
+// parked in the gene's pos / lo / hi rows between the phases (a thread reads back what it wrote itself).
+// flags: 0 non-finite input, 1 some tie.
+#ifdef REO_STAMPS
+#define TSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(flags + 8)[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+constexpr int kSplit1 = 1024;                 // splitters (= threads)
+template <int IPT> constexpr int kWideLogSub = IPT <= 20 ? 4 : (IPT <= 24 ? 3 : 2);   // sub-buckets per splitter interval (what fits the LDS beside 4 B per gene)
+
+// bytes of LDS in front of the two per-gene arrays: splitters + 16 wave maxima, NB bins (skewed) + end word + wave totals; 16-byte aligned
+__host__ __device__ constexpr size_t wide_lds_head(size_t nb) { return (8 * (kSplit1 + 16) + 4 * (nb + (nb >> 5) + 1 + 17) + 15) / 16 * 16; }
+
+template <class T>
+__device__ __forceinline__ bool code_tied(uint64_t c, T x) { return Codec<T>::tie(Codec<T>::dec(c), x); }
+
+// smallest code <= cx that is tied with x (DOWN) / largest code >= cx that is (UP): the band of x in code space
+template <bool UP>
+__device__ __forceinline__ uint64_t band_edge_code(double x, uint64_t cx)
+{
+    uint64_t g = Codec<double>::enc(UP ? x + 0.1 : x - 0.1);
+    if (UP ? g < cx : g > cx) g = cx;
+    // invariant of both branches: `in` is tied, `out` is not (or is the end of the code space), in between unknown
+    uint64_t in, out;
+    if (code_tied<double>(g, x)) {  // walk away from cx while the codes stay tied
+        in = g;
+        uint64_t step = 1;
+        while (true) {
+            const bool room = UP ? (in <= ~0ULL - step) : (in >= step);
+            if (!room) { out = UP ? ~0ULL : 0ULL; if (code_tied<double>(out, x)) return out; break; }
+            const uint64_t n = UP ? in + step : in - step;
+            if (!code_tied<double>(n, x)) { out = n; break; }
+            in = n; step <<= 1;
+        }
+    } else {  // walk towards cx (which is tied with itself) until a code is tied
+        out = g;
+        uint64_t step = 1;
+        while (true) {
+            const uint64_t dist = UP ? out - cx : cx - out;
+            if (step >= dist) { in = cx; break; }
+            const uint64_t n = UP ? out - step : out + step;
+            if (code_tied<double>(n, x)) { in = n; break; }
+            out = n; step <<= 1;
+        }
     }
-    sorter().sort(k, v, storage, 0, nbits + 1);  // blocked: item e of thread t is sorted position t * IPT + e
-    __syncthreads();
-    uint32_t *skey = reinterpret_cast<uint32_t *>(smem);
+    while ((UP ? out - in : in - out) > 1) {
+        const uint64_t mid = UP ? in + (out - in) / 2 : out + (in - out) / 2;
+        if (code_tied<double>(mid, x)) in = mid; else out = mid;
+    }
+    return in;
+}
+
+template <class T, int LOGSUB>
+__global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
+                                                      const int32_t *__restrict__ slots, int G, int Gp, int S,
+                                                      uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
+                                                      uint16_t *__restrict__ hi, int32_t *__restrict__ flags)
+{
+    constexpr int SUB = 1 << LOGSUB, PER = SUB + 1, NB = kSplit1 * PER;   // per splitter: SUB pieces of the interval below it + its equality bucket
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *spl = reinterpret_cast<unsigned long long *>(smem);   // [1024] sorted splitters; [1024..1039] wave maxima
+    uint32_t *hist = reinterpret_cast<uint32_t *>(spl + kSplit1 + 16);         // [NB] bins, skewed by one word in 32; then one end word
+    uint32_t *wtot = hist + NB + (NB >> 5) + 1;                               // 16 wave totals
+    uint16_t *rem = reinterpret_cast<uint16_t *>(smem + wide_lds_head(NB));   // [Gp] by slot: 16 bits of the code's offset inside its bucket
+    uint16_t *gen = rem + Gp;                                                 // [Gp] by slot: the gene
+    auto at = [](uint32_t b) { return b + (b >> 5); };
+    const int t = threadIdx.x;
+    const int c = blockIdx.x;
+    if (c >= S) {  // one workgroup per padding slot too: rows of zeros -- lo = hi = 0 is below no position
+        const size_t o = static_cast<size_t>(slots[c]) * Gp;
+        for (int q = t; q < Gp / 8; q += 1024) {
+            reinterpret_cast<uint4 *>(pos + o)[q] = uint4{0, 0, 0, 0};
+            reinterpret_cast<uint4 *>(lo + o)[q] = uint4{0, 0, 0, 0};
+            reinterpret_cast<uint4 *>(hi + o)[q] = uint4{0, 0, 0, 0};
+        }
+        return;
+    }
+    const T *col = X + static_cast<int64_t>(colmap[c]) * ld;
+    const size_t orow = static_cast<size_t>(slots[c]) * Gp;
+    uint16_t *prow = pos + orow, *lrow = lo + orow, *hrow = hi + orow;
+    int32_t *anytie = flags + 1;
+    // ---- 1. the column's maximum, non-finite values; the sample, sorted
+    TSTAMP(0);
+    uint64_t kmax = 0;
+    bool bad = false;
+#pragma unroll 8
+    for (int i = t; i < G; i += 1024) {   // (eight loads in flight: the column comes from HBM here)
+        const T x = col[i];
+        bad |= !Codec<T>::finite(x);
+        const uint64_t k = Codec<T>::enc(x);
+        kmax = k > kmax ? k : kmax;
+    }
 #pragma unroll
-    for (int e = 0; e < IPT; ++e) skey[t * IPT + e] = k[e];
+    for (int o = 32; o > 0; o >>= 1) { const uint64_t b = __shfl_xor(kmax, o, 64); kmax = b > kmax ? b : kmax; }
+    if ((t & 63) == 0) spl[kSplit1 + (t >> 6)] = kmax;
+    if (__ballot(bad) != 0 && (t & 63) == 0) atomicOr(flags, 1);
+    for (int b = t; b < NB + (NB >> 5) + 1; b += 1024) hist[b] = 0;
     __syncthreads();
-    const uint64_t base = key0 & ~(static_cast<uint64_t>(mask) << begin_bit);
-    auto value = [&](uint32_t kk) { return Codec<T>::dec(base | (static_cast<uint64_t>(kk) << begin_bit)); };
-    uint32_t band[IPT];  // l | (h + 1) << 16
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint64_t b = spl[kSplit1 + w]; kmax = b > kmax ? b : kmax; }
+    TSTAMP(1);
+    {
+        // thread t's sample: gene floor(t G / 1024) (repeats when G < 1024: equal splitters leave empty buckets between them)
+        uint64_t v = t == kSplit1 - 1 ? kmax : Codec<T>::enc(col[static_cast<int>((static_cast<int64_t>(t) * G) >> 10)]);
+        // bitonic sort, one key per thread: distances below 64 inside the wave, the others through LDS
+        for (int k = 2; k <= kSplit1; k <<= 1) {
+            const bool up = (t & k) == 0;
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                uint64_t pv;
+                if (j >= 64) {
+                    __syncthreads();
+                    spl[t] = v;
+                    __syncthreads();
+                    pv = spl[t ^ j];
+                } else {
+                    pv = __shfl_xor(v, j, 64);
+                }
+                const bool keep_min = ((t & j) == 0) == up;
+                const bool take = keep_min ? pv < v : pv > v;
+                v = take ? pv : v;
+            }
+        }
+        __syncthreads();
+        spl[t] = v;
+    }
+    __syncthreads();
+    // A code k <= kmax: lb = number of splitters below it (10 steps).  It equals splitter lb (bucket lb PER + SUB: one
+    // value only) or lies strictly between splitters lb - 1 and lb, in piece ((k - from) >> sh) of that interval; r16 = the
+    // next 16 bits of its offset; exact: bucket and r16 are the whole code.
+    auto locate = [&](uint64_t k, uint32_t &bucket, uint32_t &r16, bool &exact) {
+        int lb = 0;
+#pragma unroll
+        for (int s = kSplit1 / 2; s > 0; s >>= 1) lb += spl[lb + s - 1] < k ? s : 0;
+        const uint64_t to = spl[lb];
+        if (to == k) { bucket = lb * PER + SUB; r16 = 0; exact = true; return; }
+        const uint64_t from = lb ? spl[lb - 1] : 0ULL, width = to - from, o = k - from;   // 0 < o < width
+        const int bits = 64 - __builtin_clzll(width);
+        const int sh = bits > LOGSUB ? bits - LOGSUB : 0;
+        bucket = lb * PER + static_cast<uint32_t>(o >> sh);
+        const int rs = sh > 16 ? sh - 16 : 0;
+        r16 = static_cast<uint32_t>((o & ((1ULL << sh) - 1ULL)) >> rs);
+        exact = sh <= 16;
+    };
+    TSTAMP(2);
+    // ---- 2. histogram; arrival slot (+ `exact` in bit 15), bucket and r16 parked in the pos / lo / hi rows
+#pragma unroll 2
+    for (int i = t; i < G; i += 1024) {
+        const uint64_t k = Codec<T>::enc(col[i]);
+        uint32_t b, r; bool ex;
+        locate(k, b, r, ex);
+        prow[i] = static_cast<uint16_t>(atomicAdd(&hist[at(b)], 1u) | (ex ? 0x8000u : 0u));   // (a slot is below 32 768)
+        lrow[i] = static_cast<uint16_t>(b);
+        hrow[i] = static_cast<uint16_t>(r);
+    }
+    __syncthreads();
+    TSTAMP(3);
+    {   // exclusive prefix sums of the bins, in place: thread t owns the PER bins of splitter t
+        uint32_t cnt[PER], tot = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { cnt[u] = hist[at(t * PER + u)]; tot += cnt[u]; }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += up; }
+        if ((t & 63) == 63) wtot[t >> 6] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot;
+        for (int w = 0; w < (t >> 6); ++w) run += wtot[w];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { hist[at(t * PER + u)] = run; run += cnt[u]; }
+        if (t == kSplit1 - 1) hist[at(NB)] = static_cast<uint32_t>(G);
+    }
+    __syncthreads();
+    TSTAMP(4);
+    // ---- 3. members into bucket order
+#pragma unroll 4
+    for (int i = t; i < G; i += 1024) {
+        const uint32_t sl = hist[at(lrow[i])] + (prow[i] & 0x7FFFu);
+        rem[sl] = hrow[i];
+        gen[sl] = static_cast<uint16_t>(i);
+    }
+    __syncthreads();
+    // number of genes whose code is below cq (le: below or equal)
+    auto rank_of = [&](uint64_t cq, bool le) -> uint32_t {
+        if (cq > kmax) return static_cast<uint32_t>(G);
+        uint32_t b, cr; bool exact;
+        locate(cq, b, cr, exact);
+        const uint32_t s0 = hist[at(b)], s1 = hist[at(b + 1)];
+        if (b % PER == SUB) return le ? s1 : s0;   // an equality bucket: every member is cq
+        uint32_t n = 0;
+        for (uint32_t q = s0; q < s1; ++q) {
+            const uint32_t r = rem[q];
+            if (r < cr) ++n;
+            else if (r == cr) {
+                if (exact) n += le ? 1u : 0u;
+                else { const uint64_t k = Codec<T>::enc(col[gen[q]]); n += (k < cq || (le && k == cq)) ? 1u : 0u; }
+            }
+        }
+        return s0 + n;
+    };
+    // ---- 4. pos, lo, hi of every gene
+    TSTAMP(5);
     bool tied = false;
+#pragma unroll 1
+    for (int i = t; i < G; i += 1024) {
+        const T x = col[i];
+        const uint64_t k = Codec<T>::enc(x);
+        const uint32_t b = lrow[i], mr = hrow[i], pk = prow[i], s0 = hist[at(b)], s1 = hist[at(b + 1)], me = s0 + (pk & 0x7FFFu);
+        const bool exact = (pk & 0x8000u) != 0;
+        uint32_t l, h, p;
+        if (b % PER == SUB) {  // one value: slot order
+            l = s0; h = s1; p = me;
+        } else {
+            // members with smaller offset bits sort before this gene; members with the SAME 16 bits are equal when the bucket is
+            // narrower than 2^16 codes, else their whole keys decide: their slots are collected first and the keys fetched
+            // together (one round trip to the column in L2, not one per member -- repeated values are common in expression data)
+            uint32_t smaller = 0, equal = 1, before = 0, amb[4], namb = 0;
+            for (uint32_t q = s0; q < s1; ++q) {
+                const uint32_t r = rem[q];
+                smaller += r < mr ? 1u : 0u;
+                if (r == mr && q != me) {
+                    if (exact) { ++equal; before += q < me ? 1u : 0u; }
+                    else if (namb < 4) amb[namb++] = q;
+                    else { const uint64_t kq = Codec<T>::enc(col[gen[q]]); smaller += kq < k ? 1u : 0u; equal += kq == k ? 1u : 0u; before += (kq == k && q < me) ? 1u : 0u; }
+                }
+            }
+            if (namb) {
+                uint64_t kq[4];
 #pragma unroll
-    for (int e = 0; e < IPT; ++e) {
-        const int p = t * IPT + e;
-        band[e] = 0;
-        if (p >= G) continue;
-        const T x = value(k[e]);
-        int l = p, h = p;
-        if (p > 0 && Codec<T>::tie(value(skey[p - 1]), x)) {
-            int a = 0, b = p - 1;  // tie holds at b; first tied position
-            while (a < b) {
-                const int m = (a + b) >> 1;
-                if (Codec<T>::tie(value(skey[m]), x)) b = m; else a = m + 1;
+                for (int u = 0; u < 4; ++u) kq[u] = u < static_cast<int>(namb) ? Codec<T>::enc(col[gen[amb[u]]]) : 0ULL;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < static_cast<int>(namb)) { smaller += kq[u] < k ? 1u : 0u; equal += kq[u] == k ? 1u : 0u; before += (kq[u] == k && amb[u] < me) ? 1u : 0u; }
             }
-            l = a;
+            l = s0 + smaller; h = l + equal; p = l + before;
         }
-        if (p + 1 < G && Codec<T>::tie(value(skey[p + 1]), x)) {
-            int a = p + 1, b = G - 1;  // tie holds at a; last tied position
-            while (a < b) {
-                const int m = (a + b + 1) >> 1;
-                if (Codec<T>::tie(value(skey[m]), x)) a = m; else b = m - 1;
-            }
-            h = a;
+        if constexpr (std::is_same<T, double>::value) {  // the band is wider than the equal values: two more rank queries
+            l = rank_of(band_edge_code<false>(x, k), false);
+            h = rank_of(band_edge_code<true>(x, k), true);
         }
-        tied |= (l != p) | (h != p);
-        band[e] = static_cast<uint32_t>(l) | (static_cast<uint32_t>(h + 1) << 16);
+        tied |= h - l > 1u;
+        prow[i] = static_cast<uint16_t>(p);
+        lrow[i] = static_cast<uint16_t>(l);
+        hrow[i] = static_cast<uint16_t>(h);
     }
+    for (int g = G + t; g < Gp; g += 1024) { prow[g] = 0; lrow[g] = 0; hrow[g] = 0; }  // padded genes are below no band edge
     if (tied && *anytie == 0) atomicOr(anytie, 1);
-    __syncthreads();  // every search in skey is done: the space becomes lo16 / hi16 indexed by gene
-    constexpr bool kStagePos = IPT <= 24;  // 6 bytes of LDS per gene fit beside nothing else up to 25 600 genes
-    uint16_t *lo16 = reinterpret_cast<uint16_t *>(smem), *hi16 = lo16 + Gp, *pos16 = hi16 + Gp;
-    for (int g = G + t; g < Gp; g += 1024) { lo16[g] = 0; hi16[g] = 0; if (kStagePos) pos16[g] = 0; }  // padded genes are below no band edge
-    uint16_t *prow = pos + static_cast<size_t>(slot) * Gp;
-#pragma unroll
-    for (int e = 0; e < IPT; ++e) {
-        const int p = t * IPT + e;
-        if (p >= G) continue;
-        const int g = v[e];
-        lo16[g] = static_cast<uint16_t>(band[e] & 0xFFFFu);
-        hi16[g] = static_cast<uint16_t>(band[e] >> 16);
-        if (kStagePos) pos16[g] = static_cast<uint16_t>(p);
-        else prow[g] = static_cast<uint16_t>(p);
-    }
-    __syncthreads();
-    uint4 *lrow = reinterpret_cast<uint4 *>(lo + static_cast<size_t>(slot) * Gp);
-    uint4 *hrow = reinterpret_cast<uint4 *>(hi + static_cast<size_t>(slot) * Gp);
-    for (int q = t; q < Gp / 8; q += 1024) {
-        lrow[q] = reinterpret_cast<const uint4 *>(lo16)[q];
-        hrow[q] = reinterpret_cast<const uint4 *>(hi16)[q];
-        if (kStagePos) reinterpret_cast<uint4 *>(prow)[q] = reinterpret_cast<const uint4 *>(pos16)[q];
-    }
+    TSTAMP(6);
 }
 
 // 16-bit rows -> bit planes over 32-sample blocks.  One thread per (pair of genes, block): reads the genes' 32 numbers
@@ -528,16 +734,45 @@ __global__ __launch_bounds__(256) void t_slice_big(const uint32_t *__restrict__ 
 template <class T, int IPT>
 int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
 {
-    using sorter = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint16_t>;
-    const size_t lds = std::max({sizeof(typename sorter::storage_type), static_cast<size_t>(IPT <= 24 ? 6 : 4) * c->Gp,
-                                 kCountingPath<T> ? sizeof(uint32_t) * kCountWords + 64 : size_t(0),
-                                 kCountingPath<T> ? sizeof(uint32_t) * (kWideWords + 32) + sizeof(uint16_t) * static_cast<size_t>(c->Gp) : size_t(0)});
+    const size_t lds = std::max({sizeof(uint32_t) * kCountWords + 64,
+                                 sizeof(uint32_t) * (kWideWords + 32) + sizeof(uint16_t) * static_cast<size_t>(c->Gp)});
     // every time: the attribute belongs to the (function, device) pair and a process may use several devices
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     t_sample<T, IPT><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,  // (a workgroup per slot: samples, then padding)
                                                                             static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
+}
+
+template <class T, int IPT>
+int32_t launch_sample_wide(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
+{
+    constexpr int LOGSUB = kWideLogSub<IPT>;
+    constexpr size_t NB = static_cast<size_t>(kSplit1) * ((1 << LOGSUB) + 1);
+    const size_t lds = wide_lds_head(NB) + sizeof(uint16_t) * 2 * static_cast<size_t>(c->Gp);
+    REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample_wide<T, LOGSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    t_sample_wide<T, LOGSUB><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
+                                                                                    static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
+// the in-LDS ranking of every sample: the histogram forms for Int64 (t_sample), the bucket form for everything else
+template <class T>
+int32_t launch_lds_ranking(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags, bool wide)
+{
+    const int64_t G = c->G;
+    if (!wide) {
+        if constexpr (kCountingPath<T>) {
+            if (G <= 8 * 1024) return launch_sample<T, 8>(c, X, d_order, d_flags);
+            if (G <= 20 * 1024) return launch_sample<T, 20>(c, X, d_order, d_flags);
+            if (G <= 24 * 1024) return launch_sample<T, 24>(c, X, d_order, d_flags);
+            return launch_sample<T, 32>(c, X, d_order, d_flags);
+        }
+    }
+    if (G <= 20 * 1024) return launch_sample_wide<T, 20>(c, X, d_order, d_flags);
+    if (G <= 24 * 1024) return launch_sample_wide<T, 24>(c, X, d_order, d_flags);
+    return launch_sample_wide<T, 32>(c, X, d_order, d_flags);
 }
 
 struct SegOff {
@@ -576,7 +811,7 @@ int32_t transform_impl(reo_ctx *c)
     // scratch lives in the context (grow-only): hipMalloc/hipFree per call cost milliseconds
     DevBuf<int32_t> &d_order = c->t_order, &d_flags = c->t_flags;
     int32_t rc;
-    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(6)) || (rc = c->t_slots.ensure(slots.size()))) return rc;
+    if ((rc = d_order.ensure(S)) || (rc = d_flags.ensure(32)) || (rc = c->t_slots.ensure(slots.size()))) return rc;
     if ((rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
     // sample order, slots and group offsets depend on the group labels only: uploaded when they (or the buffers) change
     if (order != c->t_order_host || slots != c->t_slots_host || goff_blocks != c->goff_blocks_host || d_order.p != c->t_meta_ptr[0] ||
@@ -626,41 +861,49 @@ int32_t transform_impl(reo_ctx *c)
         return REO_OK;
     };
 
-    // first choice: every sample sorted inside one workgroup's LDS (t_sample)
-    const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort (A/B tests)
+    // first choice: every sample ranked inside one workgroup's LDS -- t_sample's histograms for Int64 keys of at most 24
+    // varying bits, t_sample_wide's buckets for everything else (Float64; wider keys; a crowded lossy bucket)
+    const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort; "wide": never the histogram forms (A/B tests)
     c->transform_in_lds = 0;
     if (G <= 32 * 1024 && !(env && env[0] == 's')) {
-        if (G <= 8 * 1024) rc = launch_sample<T, 8>(c, X, d_order.p, d_flags.p);
-        else if (G <= 20 * 1024) rc = launch_sample<T, 20>(c, X, d_order.p, d_flags.p);
-        else if (G <= 24 * 1024) rc = launch_sample<T, 24>(c, X, d_order.p, d_flags.p);
-        else rc = launch_sample<T, 32>(c, X, d_order.p, d_flags.p);
-        if (rc) return rc;
-        // the slicing is enqueued before the host looks at the flags (it runs while the host wakes up; if the flags send
-        // the data to the segmented path it is simply done again)
-        if ((rc = slice())) return rc;
-        // The host waits for the flags only (an event behind their copy into pinned memory); behind that event the clearing
-        // of the class table is already queued, so the GPU has work while the host wakes up and launches the pair kernel.
         if (!c->host_flags) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t)));
         if (!c->ev_flags) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming));
         int32_t *fl = c->host_flags;
-        REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        REO_HIP_CHECK(hipEventRecord(c->ev_flags, st));
-        if (c->table.p && c->table.n >= static_cast<size_t>(c->G) * 4 * c->Wp) {
-            REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * 4 * c->Wp * sizeof(uint32_t), st));
-            c->table_prezeroed = true;
+        bool wide = !kCountingPath<T> || (env && env[0] == 'w');
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((rc = launch_lds_ranking<T>(c, X, d_order.p, d_flags.p, wide))) return rc;
+            // the slicing is enqueued before the host looks at the flags (it runs while the host wakes up; if the flags send
+            // the data elsewhere it is simply done again)
+            if ((rc = slice())) return rc;
+            // The host waits for the flags only (an event behind their copy into pinned memory); behind that event the clearing
+            // of the class table is already queued, so the GPU has work while the host wakes up and launches the pair kernel.
+            REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            REO_HIP_CHECK(hipEventRecord(c->ev_flags, st));
+            if (!c->table_prezeroed && c->table.p && c->table.n >= static_cast<size_t>(c->G) * 4 * c->Wp) {
+                REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * 4 * c->Wp * sizeof(uint32_t), st));
+                c->table_prezeroed = true;
+            }
+            REO_HIP_CHECK(hipEventSynchronize(c->ev_flags));
+            if (fl[0]) {
+                set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
+                          "src/RankCompV3.jl:601)");
+                return REO_EINVAL;
+            }
+            if (c->debug_stamps && wide) {  // diagnostic builds (-DREO_STAMPS): marks of workgroup 0 of t_sample_wide, 10 ns units
+                unsigned long long stv[8];
+                REO_HIP_CHECK(hipMemcpy(stv, d_flags.p + 8, sizeof stv, hipMemcpyDeviceToHost));
+                fprintf(stderr, "stamps t_sample_wide (max + flags, sample sort, histogram, prefix sums, scatter, ranks):");
+                for (int k = 1; k <= 6; ++k) fprintf(stderr, " %lld", (long long)(stv[k] - stv[k - 1]));
+                fprintf(stderr, "  (x 10 ns)\n");
+            }
+            if (!fl[4] && !fl[5]) {
+                c->transform_in_lds = wide ? 2 : 1;
+                return finish(fl[1], true);
+            }
+            REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
+            if (wide || fl[4]) break;  // a crowded bucket of different values: the segmented sort
+            wide = true;               // some sample needs the bucket form: all of them take it
         }
-        REO_HIP_CHECK(hipEventSynchronize(c->ev_flags));
-        if (fl[0]) {
-            set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
-                      "src/RankCompV3.jl:601)");
-            return REO_EINVAL;
-        }
-        if (!fl[4]) {
-            c->transform_in_lds = 1;
-            return finish(fl[1], true);
-        }
-        // some sample has keys wider than 31 bits: start over with the segmented sort
-        REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
     }
     if (!big) {  // the segmented path writes the genes of the samples only: padding slots and padded genes read as zero
         REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));

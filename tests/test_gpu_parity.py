@@ -534,8 +534,9 @@ def _counts_blocks(pkg, X, gid, ngroups, blocks, seed=3):
 
 @pytest.mark.parametrize("G", [8192, 8193, 20480, 20481, 24576, 24577, 32768, 32769])
 def test_transform_in_lds_and_segmented_agree_at_the_size_limits(pkg, oracle, G, monkeypatch):
-    """The per-sample LDS sort (<= 32 768 genes, <= 31 varying key bits) and the device-wide segmented sort
-    must give the same counts, and the oracle's, on both sides of every items-per-thread limit."""
+    """The per-sample ranking in LDS (<= 32 768 genes) and the device-wide segmented sort must give the same counts,
+    and the oracle's, on both sides of every items-per-thread limit -- for the histogram forms (Int64 counts) and for
+    the bucket form (the same data as Float64, REO_TRANSFORM=wide for the integers)."""
     S, seed = 11, 0x5EED0013
     X = pkg.synth.t1_counts(G, S, seed)
     gid = np.array([0, 1, 0, 1, 1, 0, 0, 1, 0, 1, 1], dtype=np.int32)
@@ -547,34 +548,97 @@ def test_transform_in_lds_and_segmented_agree_at_the_size_limits(pkg, oracle, G,
     b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
     assert info_b["transform_in_lds"] == 0
     Xf = X.astype(np.float64)
-    for blk, (ga, ea), (gb, eb) in zip(blocks, a, b):
+    monkeypatch.setenv("REO_TRANSFORM", "wide")
+    w, info_w = _counts_blocks(pkg, X, gid, 2, blocks)
+    assert info_w["transform_in_lds"] == (2 if G <= 32768 else 0)
+    monkeypatch.delenv("REO_TRANSFORM", raising=False)
+    f, info_f = _counts_blocks(pkg, np.log2(1.0 + Xf), gid, 2, blocks)   # a monotone map: ties stay equalities or widen into 0.1 bands
+    assert info_f["transform_in_lds"] == (2 if G <= 32768 else 0)
+    for blk, (ga, ea), (gb, eb), (gw, ew), (gf, ef) in zip(blocks, a, b, w, f):
         egt, eeq = oracle.pair_counts(Xf, gid, 2, *blk)
         assert np.array_equal(ga, gb) and np.array_equal(ea, eb)
         assert np.array_equal(ga, egt) and np.array_equal(ea, eeq)
+        assert np.array_equal(gw, egt) and np.array_equal(ew, eeq)
+        fgt, feq = oracle.pair_counts(np.log2(1.0 + Xf), gid, 2, *blk)
+        assert np.array_equal(gf, fgt) and np.array_equal(ef, feq)
 
 
 def test_transform_key_width_decides_the_path(pkg, oracle, monkeypatch):
-    """31 varying key bits still sort in LDS; 32 or more (wide integers, negative values, general
-    Float64) take the segmented sort; all of them match the oracle."""
+    """Int64 keys of at most 24 varying bits rank by histogram (transform_in_lds 1); wider integers, negative values and
+    Float64 by buckets (2); all of them match the oracle."""
     monkeypatch.delenv("REO_TRANSFORM", raising=False)
     rng = np.random.default_rng(99)
     G, S = 700, 12
     gid = np.array([0, 1] * 6, dtype=np.int32)
     cases = {
-        "31 bits": (rng.integers(0, 2 ** 31, (G, S), dtype=np.int64), 1),
-        "33 bits": (rng.integers(0, 2 ** 33, (G, S), dtype=np.int64), 0),
-        "negatives": (rng.integers(-50, 50, (G, S), dtype=np.int64), 0),
+        "24 bits": (rng.integers(0, 2 ** 24, (G, S), dtype=np.int64), 1),
+        "31 bits": (rng.integers(0, 2 ** 31, (G, S), dtype=np.int64), 2),
+        "33 bits": (rng.integers(0, 2 ** 33, (G, S), dtype=np.int64), 2),
+        "63 bits": (rng.integers(-2 ** 62, 2 ** 62, (G, S), dtype=np.int64), 2),
+        "negatives": (rng.integers(-50, 50, (G, S), dtype=np.int64), 2),
         "offset": (rng.integers(0, 1000, (G, S), dtype=np.int64) + (1 << 40), 1),   # high bits constant: still narrow
-        "floats": (rng.lognormal(2.0, 1.5, (G, S)), 0),
-        "float ranks": (rng.integers(0, 64, (G, S)).astype(np.float64) * 0.25, None),
+        "floats": (rng.lognormal(2.0, 1.5, (G, S)), 2),
+        "float ranks": (rng.integers(0, 64, (G, S)).astype(np.float64) * 0.25, 2),
     }
     for name, (X, want) in cases.items():
         X[5] = X[6]  # some exact ties
         (out,), info = _counts_blocks(pkg, X, gid, 2, [(0, G, 0, G)])
         if want is not None:
             assert info["transform_in_lds"] == want, name
+        if name == "63 bits":   # (the oracle takes Float64: integers this wide are not exactly representable -- compare with numpy)
+            gi = np.arange(0, G, 7)
+            egt = np.stack([(X[gi][:, None, gid == g] > X[None, :, gid == g]).sum(axis=2) for g in (0, 1)], axis=2)
+            eeq = np.stack([(X[gi][:, None, gid == g] == X[None, :, gid == g]).sum(axis=2) for g in (0, 1)], axis=2)
+            assert np.array_equal(out[0][gi], egt) and np.array_equal(out[1][gi], eeq), name
+            continue
         egt, eeq = oracle.pair_counts(np.asarray(X, dtype=np.float64), gid, 2, 0, G, 0, G)
         assert np.array_equal(out[0], egt) and np.array_equal(out[1], eeq), name
+
+
+@pytest.mark.parametrize("G", [700, 9000, 20000, 32768])
+def test_transform_bucket_ranking_of_float64(pkg, oracle, G, monkeypatch):
+    """t_sample_wide on Float64 (transform.hip): the 0.1 band of is_greater (:72) found in code space with the
+    reference's own predicate.  Samples built to hit its corners: many exact zeros (an equality bucket of one value),
+    values on both sides of x - y = 0.1 to the last ulp, x slightly above 0.1 (x - 0.1 cancels to something tiny),
+    negative values and signed zeros, denormals, a sample of one value, huge dynamic range, and ordinary
+    log-expression.  Against the oracle's literal comparator and against the segmented path."""
+    rng = np.random.default_rng(1000 + G)
+    S = 12
+    gid = np.array([0, 1] * 6, dtype=np.int32)
+    X = np.log2(1.0 + pkg.synth.t1_counts(G, S, 0x5EED0067).astype(np.float64)) + rng.uniform(0, 0.05, (G, S))
+    X[:, 1] = np.where(rng.random(G) < 0.3, 0.0, rng.lognormal(1.0, 1.0, G))              # 30 % exact zeros
+    base = rng.uniform(0.5, 8.0, G)
+    X[:, 2] = np.where(rng.random(G) < 0.5, base, np.nextafter(base + 0.1, np.where(rng.random(G) < 0.5, 0.0, 100.0)))
+    h = G // 4
+    X[: 2 * h, 2] = np.concatenate([base[:h], base[:h] + 0.1])                           # x and x + 0.1 both present: the band edge itself
+    X[:, 3] = 0.1 + rng.uniform(0, 1e-9, G) * (rng.random(G) < 0.5)                      # x - 0.1 cancels; plus exact 0.1
+    X[: G // 3, 3] = rng.uniform(0, 3e-10, G // 3)
+    X[:, 4] = rng.normal(0, 0.2, G); X[:5, 4] = [0.0, -0.0, 0.05, -0.05, 0.1]            # around zero, both signs
+    X[:, 5] = 5e-324 * rng.integers(0, 1000, G)                                          # denormals and zeros
+    X[:, 6] = 3.25                                                                        # one value
+    X[:, 7] = 10.0 ** rng.uniform(-300, 300, G) * rng.choice([-1.0, 1.0], G)              # 600 decades, both signs
+    X[:, 8] = np.round(rng.lognormal(0, 2, G), 1)                                         # a 0.1 grid: band edges meet grid values
+    blocks = [(0, 48, 0, 48), (G - 40, G, G - 40, G), (100, 124, G // 2, G // 2 + 64), (G // 4, G // 4 + 16, 0, 64)]
+    monkeypatch.delenv("REO_TRANSFORM", raising=False)
+    a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
+    assert info_a["transform_in_lds"] == 2
+    monkeypatch.setenv("REO_TRANSFORM", "segmented")
+    b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
+    assert info_b["transform_in_lds"] == 0
+    for blk, (ga, ea), (gb, eb) in zip(blocks, a, b):
+        egt, eeq = oracle.pair_counts(X, gid, 2, *blk)
+        assert np.array_equal(ga, egt) and np.array_equal(ea, eeq), blk
+        assert np.array_equal(gb, egt) and np.array_equal(eb, eeq), blk
+    # values a few hundred ulps apart next to one far outlier, and a column sorted by gene index: the splitters follow the data
+    Y = X.copy()
+    Y[:, 1] = 1.0 + rng.uniform(0, 1e-13, G)
+    Y[0, 1] = 1e6
+    Y[:, 2] = np.sort(X[:, 0])
+    monkeypatch.delenv("REO_TRANSFORM", raising=False)
+    (c,), info_c = _counts_blocks(pkg, Y, gid, 2, [blocks[0]])
+    assert info_c["transform_in_lds"] == 2
+    egt, eeq = oracle.pair_counts(Y, gid, 2, *blocks[0])
+    assert np.array_equal(c[0], egt) and np.array_equal(c[1], eeq)
 
 
 @pytest.mark.parametrize("G", [3000, 20000, 32768])
@@ -582,7 +646,7 @@ def test_transform_compressed_histogram_ranking(pkg, oracle, G, monkeypatch):
     """Integer keys with 16 to 24 varying bits rank by a histogram of a monotone compression of the key (transform.hip,
     t_sample): exact codes below 2^13, octave + mantissa above, ranks inside a lossy bucket by scanning its members.
     Values on octave boundaries, equal values inside lossy buckets, moderately crowded buckets (scanned) and crowded
-    ones (the sample then takes the radix sort) -- all against the oracle's counts and against the segmented path."""
+    ones (every sample then takes the bucket form, t_sample_wide) -- all against the oracle's counts and against the segmented path."""
     rng = np.random.default_rng(G)
     S = 12
     gid = np.array([0, 1] * 6, dtype=np.int32)
@@ -599,14 +663,19 @@ def test_transform_compressed_histogram_ranking(pkg, oracle, G, monkeypatch):
     blocks = [(0, 48, 0, 48), (0, 40, G // 50, G // 50 + 64), (G - 40, G, G - 40, G), (100, 124, 150, 214)]
     monkeypatch.delenv("REO_TRANSFORM", raising=False)
     a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
-    assert info_a["transform_in_lds"] == 1
+    assert info_a["transform_in_lds"] == 2      # sample 2's crowded bucket sends every sample to the bucket form (t_sample_wide)
+    X1 = X.copy(); X1[:, 2] = X[::-1, 3]        # without it: the compressed histogram ranks all samples
+    a1, info_a1 = _counts_blocks(pkg, X1, gid, 2, blocks)
+    assert info_a1["transform_in_lds"] == (1 if G == 3000 else 2)   # (at the larger sizes sample 1's crowded region passes the scan limit too)
     monkeypatch.setenv("REO_TRANSFORM", "segmented")
     b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
     Xf = X.astype(np.float64)
-    for blk, (ga, ea), (gb, eb) in zip(blocks, a, b):
+    for blk, (ga, ea), (gb, eb), (g1, e1) in zip(blocks, a, b, a1):
         egt, eeq = oracle.pair_counts(Xf, gid, 2, *blk)
         assert np.array_equal(ga, egt) and np.array_equal(ea, eeq), blk
         assert np.array_equal(ga, gb) and np.array_equal(ea, eb), blk
+        egt1, eeq1 = oracle.pair_counts(X1.astype(np.float64), gid, 2, *blk)
+        assert np.array_equal(g1, egt1) and np.array_equal(e1, eeq1), blk
 
 
 def test_plain_c_client_of_the_abi(pkg, oracle, tmp_path):
