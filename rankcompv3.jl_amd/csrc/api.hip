@@ -189,7 +189,7 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         (rc = c->state.ensure(1)) ||
         (rc = c->chunk_v.ensure(((G + kSortChunk - 1) / kSortChunk) * (kSortChunk + kSortChunk / 32))) ||
         (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (std::max<size_t>(65536, (G + kSortChunk - 1) / kSortChunk * kSortChunk) / 16 + 8))) ||
-        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(2 * kHistParts * ((G + 32767) / 32768 * 32768))) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->clist.ensure(2 * kListStride)) || (rc = c->scal.ensure(64)))
+        (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(3 * kHistParts * ((G + 32767) / 32768 * 32768))) || (rc = c->olist.ensure(2 * kOneStride)) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->clist.ensure(2 * kListStride)) || (rc = c->scal.ensure(64)))
         return rc;
     if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
     return REO_OK;
@@ -214,6 +214,7 @@ static int32_t init_state(reo_ctx *c, int32_t nref)
     st.delta_cnt[0] = st.delta_cnt[1] = 0x7FFFFFFF;  // the first pass counts from scratch
     st.need_full = 1;
     st.raw_pass = -1;
+    st.kstar = -1;
     *c->host_state = st;
     REO_HIP_CHECK(hipMemcpyAsync(c->state.p, c->host_state, sizeof st, hipMemcpyHostToDevice, c->stream));
     return REO_OK;
@@ -327,7 +328,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (const char *e = getenv("REO_CHECK_HOOK_TABLE")) c->check_hook_table = (e[0] != '0');
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
     if (const char *e = getenv("REO_LIGHT_BAND")) c->light_band = std::max(0, atoi(e));
-    if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
+    if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : (e[0] == '3' ? 3 : 1));
     c->light_window = light_window(); c->light_min_g = light_min_genes();
     if (const char *e = getenv("REO_LIGHT_WINDOW")) c->light_window = std::max(1, std::min(31, atoi(e)));  // 2 W + 1 <= 64 window members
     if (const char *e = getenv("REO_LIGHT_MIN_G")) c->light_min_g = std::max(64, atoi(e));
@@ -372,7 +373,7 @@ void reo_destroy(reo_ctx *c)
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
-    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->check_flag.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
+    c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->olist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->check_flag.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) (void)hipHostFree(c->host_state);
     if (c->host_flags) (void)hipHostFree(c->host_flags);
     if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
@@ -673,6 +674,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         st.delta_cnt[0] = st.delta_cnt[1] = 0x7FFFFFFF;  // the first pass counts from scratch
         st.need_full = 1;
         st.raw_pass = -1;
+        st.kstar = -1;
         *c->host_state = st;
     }
     if ((rc = launch_iter_init(c, c->host_ref, c->host_state))) return rc;
@@ -711,6 +713,15 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         toc(c);
         if (!c->state_mirror) REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
         if ((rc = wait_or_drop_table(c))) return rc;
+        if (c->debug_passes && nlight > 0 && c->light_mode == 3) {  // which check of the one-launch form ended the batch
+            static LightState hs;
+            if (hipMemcpy(&hs, c->lstate.p, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess)
+                for (int q = 1; q <= nlight; ++q)
+                    if (hs.slot[q].pad0[0] || q <= 3)
+                        fprintf(stderr, "  launch %d: why %d (1 window, 2 se left the bracket, 4 the histogram's cut left the band, 8 a list overflowed, 16 too many listed, 32 cut below the band), "
+                                "cut of the m_lo histogram %d, listed %d, surely inside %d, cut %d (band around %d), eta %.3g, se %.10g\n", q, hs.slot[q].pad0[0], hs.slot[q].pad0[1],
+                                hs.slot[q].pad0[2], hs.slot[q].pad0[3], hs.slot[q].pad0[4], hs.slot[q - 1].rec.kstar, hs.slot[q - 1].eta, hs.slot[q].se_base);
+        }
         if (c->debug_passes)
             fprintf(stderr, "batch: %d sorting + %d light launches, passes %d -> %d, need_full %d, done %d, last_full %d, changed genes in front of the next pass %d\n", nfull, nlight,
                     passes, c->host_state->passes, c->host_state->need_full, c->host_state->done, c->host_state->last_full,
@@ -748,7 +759,10 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     if (c->debug_stamps) {  // diagnostic builds (-DREO_STAMPS): marks of workgroup 0 in the last light launches, 10 ns units
         unsigned long long st[24];
         REO_HIP_CHECK(hipMemcpy(st, c->scal.p + 32, sizeof st, hipMemcpyDeviceToHost));
-        if (c->light_mode == 2) {
+        if (c->light_mode == 3) {
+            fprintf(stderr, "stamps kl_one (inputs back, se, cut, lists + mask step, changed rows, delta1, sums + windows, end):");
+            for (int k = 0; k <= 7; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[8]));
+        } else if (c->light_mode == 2) {
             fprintf(stderr, "stamps kl_persist, one pass (phase 1, barrier, phase 2, barrier, loads asked, cut, mask step):");
             for (int k = 1; k <= 7; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[0]));
         } else {

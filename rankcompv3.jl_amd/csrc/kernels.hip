@@ -1340,6 +1340,7 @@ struct IterArgs {
     int replay;                  // 1: recompute the outputs of the last executed pass from its tallies, change no state
     int k2_idx;                  // index of this k2_tally launch (for the stage timers)
     int xcc_local;               // light passes: the histogram atomics may stay in the XCD's L2 (reo_create's self-test passed)
+    int32_t *olist;              // one-launch light passes: [2][kOneStride] genes near the BH cut with their delta1, by workgroup
     int32_t *clist; int band;    // light passes: genes near the BH cut listed by kl_rank ([2][kListStride]); half width of "near" in ranks
     int window, light_min_g;     // light passes: ranks on either side of a quantile that its window is made to hold; smallest G that uses them
     unsigned long long *stamps;  // diagnostic builds (-DREO_STAMPS): s_memrealtime marks of workgroup 0, else unused
@@ -1824,7 +1825,7 @@ __global__ __launch_bounds__(1024) void k3_bh_local(IterArgs a)
 // control of :418-424 on the device-side iteration state.  Every thread of the grid (Gp threads) must call it.
 // Returns -1 except in thread 0 of the last workgroup, where it returns 1 when more genes changed than a tally
 // update can take (the next pass must scan the table) and 0 otherwise; that thread then sets st->need_full.
-__device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, bool ind)
+__device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, bool ind, bool in_cut)
 {
     IterState *st = a.st;
     const int cur = t & 1, nxt = 1 - cur;
@@ -1838,20 +1839,23 @@ __device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, boo
         const int at = basepos + __popcll(cm & ((1ULL << (threadIdx.x & 63)) - 1ULL));
         if (changed && at < kDeltaMax) a.delta_list[static_cast<size_t>(nxt) * a.Gp + at] = (static_cast<uint32_t>(i) << 1) | (ind ? 1u : 0u);
     }
-    const unsigned long long m = __ballot(ind);
-    __shared__ int wave_nn[4];
+    const unsigned long long m = __ballot(ind), mc = __ballot(in_cut);
+    __shared__ int wave_nn[4], wave_kc[4];
     if ((threadIdx.x & 63) == 0) {
         if (i < a.Gp) {
             a.refbits[nxt][i >> 5] = static_cast<uint32_t>(m);
             a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(m >> 32);
         }
         wave_nn[threadIdx.x >> 6] = __popcll(m);
+        wave_kc[threadIdx.x >> 6] = __popcll(mc);
     }
     __syncthreads();
     if (threadIdx.x != 0) return -1;
     // one atomic per workgroup, not per wave: serialised updates of one word were a third of this kernel
     const int nn_blk = wave_nn[0] + wave_nn[1] + wave_nn[2] + wave_nn[3];
     if (nn_blk) atomicAdd(&st->nn_acc, nn_blk);
+    const int kc_blk = wave_kc[0] + wave_kc[1] + wave_kc[2] + wave_kc[3];  // genes inside the BH cut: their number IS the cut (padj <= padj_deg <=> rank <= k*)
+    if (kc_blk) atomicAdd(&st->kcut_acc, kc_blk);
     __threadfence();
     const int tk = atomicAdd(&st->ticket, 1);
     if (tk != static_cast<int>(gridDim.x) - 1) return -1;
@@ -1869,6 +1873,8 @@ __device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, boo
         st->nref = nn;      // ref_gene_vec = inds, :424
     }
     st->last_full = 1;
+    st->kstar = atomicAdd(&st->kcut_acc, 0);  // the one-launch light passes centre their band on it
+    st->kcut_acc = 0;
     st->nn_acc = 0;
     st->ticket = 0;
     return atomicAdd(&st->delta_cnt[nxt], 0) > kDeltaMax ? 1 : 0;
@@ -1895,7 +1901,7 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    bool ind = false;
+    bool ind = false, in_cut = false;
     if (i < G) {
         const uint32_t r = a.rank_a[i];
         double q = a.sorted_p[r];
@@ -1903,10 +1909,11 @@ __global__ __launch_bounds__(256) void k3_finalize(IterArgs a)
         q = tl < q ? tl : q;
         q = q < 1.0 ? q : 1.0;
         a.result[static_cast<size_t>(G) + i] = q;
-        ind = !(a.result[i] <= a.pval_deg && q <= a.padj_deg);
+        in_cut = q <= a.padj_deg;
+        ind = !(a.result[i] <= a.pval_deg && in_cut);
     }
     if (a.replay) return;
-    const int over = publish_mask(a, t, i, ind);
+    const int over = publish_mask(a, t, i, ind, in_cut);
     if (over < 0) return;
     // quantile windows: the values kWindow ranks on either side of the slice bounds, kept as widths around the
     // exact quantiles so that a light pass can re-centre them on its own quantiles
@@ -2655,6 +2662,403 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
         if (threadIdx.x == 0) cl[blockIdx.x] = min(s_c, kListCap + 1);
     }
     STAMP(a, 23);
+}
+
+// ---------------------------------------------------------------------------
+// The light passes as ONE launch per pass (round 4; opt-in, REO_LIGHT=3: measured 24.0 us per pass against the 23.1 of the
+// two-launch form -- the launch it saves is paid back by the exact p-values of the listed genes, which now sit on the
+// critical path between se and the mask step; DESIGN.md has the marks).  A pass has two grid-wide dependencies
+// (all delta1 -> se; all BH ranks -> the cut), and the two-launch form above pays a launch for each.  Here the second
+// one is carried across the launch boundary TOGETHER with the first: launch b derives pass t (tallies, delta1, window
+// bookkeeping for se(t)) and, without knowing se(t), files every gene's p-value between two brackets -- the p-values under
+// se_lo = se(t-1) (1 - eta) and se_hi = se(t-1) (1 + eta); p is monotone in se, so whatever se(t) turns out to be inside
+// that interval, p_lo <= p <= p_hi and, the step-up rank m being monotone in p, m_lo <= m <= m_hi.  With the cut of
+// the pass before, k', and the band [k' - band, k' + band] a gene is then
+//   * surely inside the cut's reach (m_hi <= k' - band): counted, by workgroup, into n_sure;
+//   * surely outside (m_lo > k' + band);
+//   * or LISTED with its delta1 (a few dozen genes: those the bracket or the band cannot decide, and those whose mask bit
+//     contradicts the sure verdict),
+// and the histogram of m_lo (an upper bound of the true H(r) = #{m <= r}) is built as before.  Launch b + 1 then, in every
+// workgroup: se(t) from the windows (exact, as before); the check that it lies inside the bracket; the cut of the m_lo
+// histogram, which bounds the true cut from above and must not leave the band; the EXACT p and m of the listed genes
+// under se(t); H(r) = n_sure + #{listed: m <= r} for every r of the band -- exact there -- and with it the true cut
+// k* = max{r : H(r) >= r}; the new mask bits of the listed genes (nobody else's can change) and the change list; then
+// pass t + 1.  Any check that fails (se left the bracket, the cut left the band, a list overflowed) hands pass t to the
+// sorting path, exactly like a lost quantile window.  eta follows the drift of se: four times the last relative change,
+// between 2^-11 and 2^-6 (measured: the iteration settles into a short cycle with changes of 2e-4 .. 1.4e-3 per pass).
+// Buffers that one launch both reads (the other workgroups' results of the launch before) and writes (this pass's) are
+// double-buffered by launch parity (window members, block moments, lists) or come in three (the histogram: read, filled, cleared).
+constexpr double kEtaMin = 1.0 / 2048.0, kEtaMax = 1.0 / 64.0, kEta0 = 1.0 / 128.0;
+
+template <bool TAIL>
+__global__ __launch_bounds__(256) void kl_one(IterArgs a, LightState *ls, int b)
+{
+    const int G = a.G, Gp = a.Gp;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool live = i < G;
+    __shared__ uint32_t dl[kDeltaMax];
+    __shared__ int s_n, s_nn, s_nl, s_bad, s_c;
+    __shared__ uint4 dbuf[kDeltaMax * 8];
+    __shared__ double red[256];
+    __shared__ double sel[2][4];
+    __shared__ int wcnt[4][2];
+    __shared__ double lm_d[kOneListMax];     // listed genes of the mask step: delta1 ...
+    __shared__ int lm_m[kOneListMax];        // ... exact BH rank (G + 1: none) ...
+    __shared__ uint32_t lm_g[kOneListMax];   // ... gene | old bit << 31 | passes the p-value criterion << 30
+    __shared__ int wbest[4];
+    warm_kernargs<sizeof(IterArgs) + 16>();
+    if (!TAIL) STAMP(a, 8);
+    const int pb = (b + 1) & 1, pbuf = b & 1;              // parity of the launch before / of this one (lists, window members, block moments)
+    const int hb_prev = (b + 2) % 3, hb = b % 3, hb_next = (b + 1) % 3;   // histograms: read (filled by the launch before), filled here, cleared here
+    const int nrow = (G + 255) >> 8;
+    // ---- everything whose address does not depend on loaded data is requested first
+    LightRec r;
+    int hv[4][8];
+    int4 hx[kHistParts][2][2];
+    int4 le[kListPre];
+    int lcnt[kListPre];
+    int own_state = 0;
+    double d1prev = 0.0;
+    int4 r0 = make_int4(0, 0, 0, 0), r1 = make_int4(0, 0, 0, 0);
+    double win[4];
+    int cnt_a = 0, cnt_b = 0, below_a = 0, below_b = 0, sig = 0, nsure = 0;
+    double xw = 0.0, pn = 0.0, pm = 0.0, pq = 0.0, se_base_prev = 0.0, eta_prev = 0.0;
+    const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
+    if (b > 0) {
+        const int32_t *hist = a.hist + static_cast<size_t>(hb_prev) * kHistParts * a.hist_stride;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hv[e][u] = 0;
+#pragma unroll
+        for (int x = 0; x < kHistParts; ++x)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + (e * 256 + threadIdx.x) * 8);
+                hx[x][e][0] = hp[0]; hx[x][e][1] = hp[1];
+            }
+        const int32_t *ol = a.olist + static_cast<size_t>(pb) * kOneStride;
+#pragma unroll
+        for (int q = 0; q < kListPre; ++q) {
+            const int e = threadIdx.x + 256 * q, blk = e / kOneListCap;
+            le[q] = make_int4(0, 0, 0, 0); lcnt[q] = 0;
+            if (blk < nrow) { lcnt[q] = ol[blk]; le[q] = reinterpret_cast<const int4 *>(ol + 256)[e]; }
+        }
+        if (live) { own_state = a.mrank[i]; d1prev = a.result[11 * static_cast<size_t>(G) + i]; }
+        if (wave < 2) xw = a.cand[pb * 2 * kCandMax + wave * kCandMax + lane];
+        if (static_cast<int>(threadIdx.x) < nrow) { const double *pp = a.part + static_cast<size_t>(pb) * 768 + 3 * threadIdx.x; pn = pp[0]; pm = pp[1]; pq = pp[2]; }
+    }
+    if (!TAIL && live) {
+        const int4 *o = reinterpret_cast<const int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
+        r0 = o[0]; r1 = o[1];
+    }
+    if (b > 0) {
+        const LightSlot *ps = &ls->slot[b - 1];
+        r = ps->rec;
+        cnt_a = ps->lc.cnt_a; cnt_b = ps->lc.cnt_b;
+#pragma unroll
+        for (int q = 0; q < kSpread; ++q) { below_a += ps->lc.below_a[q][0]; below_b += ps->lc.below_b[q][0]; sig += ps->lc.sig[q][0]; nsure += ps->lc.nsure[q][0]; }
+        se_base_prev = ps->se_base; eta_prev = ps->eta;
+    }
+    if (!TAIL) STAMP(a, 0);
+    int n = 0;           // entries of dl: the genes whose mask bit changes in front of the pass derived here
+    bool inref = false;  // this thread's gene is in the reference set of that pass
+    bool stepped = false;
+    double se = 0.0, se_base = 0.0, eta = kEta0;
+    if (b == 0) {
+        const IterState *st = a.st;  // no light launch writes IterState except the TAIL
+        r.t = st->passes; r.nref = st->nref; r.nref_prev = st->nref_prev; r.done = st->done; r.need_full = st->need_full;
+        r.raw_pass = st->raw_pass; r.ran = 0; r.dcnt = st->delta_cnt[r.t & 1]; r.kstar = st->kstar;
+        r.active = (!r.done && r.t < a.n_iter && !r.need_full && r.kstar >= 0) ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) win[q] = a.scal[1 + q];
+        se_base = a.scal[0];
+        if (r.active) {
+            n = r.raw_pass == r.t ? 0 : min(r.dcnt, kDeltaMax);  // (need_full == 0 implies dcnt <= kDeltaMax)
+            if (static_cast<int>(threadIdx.x) < n) dl[threadIdx.x] = a.delta_list[static_cast<size_t>(r.t & 1) * Gp + threadIdx.x];
+            inref = live && a.refbytes[r.t & 1][i] != 0;
+            lds_barrier();
+        }
+    } else if (r.active) {
+        // ---- the end of pass r.t: se, the cut, the mask step (:409-424)
+        const int t = r.t, cur = t & 1, nxt = cur ^ 1;
+        double va = 0.0, vb = 0.0;
+        int why = 0;   // which check sent the pass to the sorting path (diagnostics: REO_DEBUG_PASSES)
+        bool ok = slice_std_vals(a, xw, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
+        ok = ok && (va + wd1 < vb - wd2);
+        if (!ok) why |= 1;
+        if (!(fabs(se - se_base_prev) <= 0.5 * eta_prev * se_base_prev)) { ok = false; why |= 2; }   // se left the bracket of the launch before
+        win[0] = va - wd0; win[1] = va + wd1; win[2] = vb - wd2; win[3] = vb + wd3;
+        se_base = se;
+        {   // the next bracket: eight times the last relative change of se, and never less than half the last bracket
+            const double drift = se_base_prev > 0.0 ? fabs(se / se_base_prev - 1.0) * 8.0 : kEta0;
+            eta = drift > 0.5 * eta_prev ? drift : 0.5 * eta_prev;
+            eta = eta < kEtaMin ? kEtaMin : (eta > kEtaMax ? kEtaMax : eta);
+        }
+        if (!TAIL) STAMP(a, 1);
+        // the cut of the m_lo histogram: an upper bound of the true cut
+        const int32_t *hist = a.hist + static_cast<size_t>(hb_prev) * kHistParts * a.hist_stride;
+#pragma unroll
+        for (int x = 0; x < kHistParts; ++x)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                hv[e][0] += hx[x][e][0].x; hv[e][1] += hx[x][e][0].y; hv[e][2] += hx[x][e][0].z; hv[e][3] += hx[x][e][0].w;
+                hv[e][4] += hx[x][e][1].x; hv[e][5] += hx[x][e][1].y; hv[e][6] += hx[x][e][1].z; hv[e][7] += hx[x][e][1].w;
+            }
+        if (sig > 4096) {  // (workgroup-uniform) the other two tiles, now
+#pragma unroll 1
+            for (int x = 0; x < kHistParts; ++x)
+#pragma unroll
+                for (int e = 2; e < 4; ++e) {
+                    const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + (e * 256 + threadIdx.x) * 8);
+                    const int4 h0 = hp[0], h1 = hp[1];
+                    hv[e][0] += h0.x; hv[e][1] += h0.y; hv[e][2] += h0.z; hv[e][3] += h0.w; hv[e][4] += h1.x; hv[e][5] += h1.y; hv[e][6] += h1.z; hv[e][7] += h1.w;
+                }
+        }
+        int carry = 0;
+        int k_hi = bh_cut4(hv, G, 0, carry);
+        if (sig > 8192) {  // (workgroup-uniform; rare) the tiles after the first four, four at a time
+            const int ntile = (min(G, sig) + 2047) / 2048;
+#pragma unroll 1
+            for (int tile0 = 4; tile0 < ntile; tile0 += 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hv[e][u] = 0;
+#pragma unroll 1
+                for (int x = 0; x < kHistParts; ++x)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if ((tile0 + e) * 2048 >= a.hist_stride) continue;  // (past the histogram: no such ranks)
+                        const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + ((tile0 + e) * 256 + threadIdx.x) * 8);
+                        const int4 h0 = hp[0], h1 = hp[1];
+                        hv[e][0] += h0.x; hv[e][1] += h0.y; hv[e][2] += h0.z; hv[e][3] += h0.w; hv[e][4] += h1.x; hv[e][5] += h1.y; hv[e][6] += h1.z; hv[e][7] += h1.w;
+                    }
+                k_hi = max(k_hi, bh_cut4(hv, G, tile0, carry));
+            }
+        }
+        const int K_in = r.kstar - a.band, K_out = min(r.kstar + a.band, G);   // the band the launch before sorted its genes by
+        if (k_hi > K_out) { ok = false; why |= 4; }
+        if (!TAIL) STAMP(a, 2);
+        // the listed genes: gathered into LDS first (a few dozen entries scattered over the workgroups' parts), then ONE round of
+        // exact p and m under se, an entry per thread
+        if (threadIdx.x == 0) { s_n = 0; s_nn = 0; s_nl = 0; s_bad = 0; }
+        lds_barrier();
+        {
+            bool bad = false;
+            auto take = [&](int cnt, const int4 &ent, int e) {
+                bad = bad || cnt > kOneListCap;
+                const bool have = (e % kOneListCap) < cnt;
+                const unsigned long long hm = __ballot(have);
+                if (hm) {  // wave-uniform
+                    int pos = 0;
+                    if (lane == 0) pos = atomicAdd(&s_nl, __popcll(hm));
+                    pos = __shfl(pos, 0, 64) + __popcll(hm & ((1ULL << lane) - 1ULL));
+                    if (have && pos < kOneListMax) { lm_g[pos] = static_cast<uint32_t>(ent.x); lm_d[pos] = __hiloint2double(ent.w, ent.z); }
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < kListPre; ++q) take(lcnt[q], le[q], threadIdx.x + 256 * q);
+            const int32_t *ol = a.olist + static_cast<size_t>(pb) * kOneStride;
+#pragma unroll 1
+            for (int e = threadIdx.x + 256 * kListPre; e < nrow * kOneListCap; e += 256) take(ol[e / kOneListCap], reinterpret_cast<const int4 *>(ol + 256)[e], e);
+            if (__ballot(bad) && lane == 0) s_bad = 1;
+        }
+        lds_barrier();
+        for (int j = threadIdx.x; j < min(s_nl, kOneListMax); j += 256) {
+            const double p = normal_p(lm_d[j], se);
+            lm_m[j] = bh_rank(p, G, a.padj_deg);
+            if (p <= a.pval_deg) lm_g[j] |= 0x40000000u;
+        }
+        lds_barrier();
+        const int nl = s_nl;
+        if (s_bad) { ok = false; why |= 8; }
+        if (nl > kOneListMax) { ok = false; why |= 16; }
+        // H(r) = n_sure + #{listed: m <= r} for the r of the band; the cut is the largest r with H(r) >= r
+        int kstar = 0;
+        {
+            const int rlo = max(K_in, 1), span = K_out - rlo + 1;   // (<= 2 band + 1 <= 255 candidates, one per thread)
+            int best = 0;
+            if (ok && static_cast<int>(threadIdx.x) < span) {
+                const int rr = rlo + threadIdx.x;
+                int h = nsure;
+                for (int j = 0; j < nl; ++j) h += lm_m[j] <= rr ? 1 : 0;
+                best = h >= rr ? rr : 0;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(best, o, 64); best = u > best ? u : best; }
+            if (lane == 0) wbest[wave] = best;
+            lds_barrier();
+            kstar = max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
+            if (ok && kstar == 0 && rlo > 1) { ok = false; why |= 32; }   // the cut lies below the band
+            if (span > 256) { ok = false; why |= 64; }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { int32_t *dg = ls->slot[b].pad0; dg[0] = why; dg[1] = k_hi; dg[2] = nl; dg[3] = nsure; dg[4] = kstar; }
+        if (!ok) {
+            r.active = 0; r.need_full = 1;  // pass r.t goes to the sorting path (its tallies are in place)
+        } else {
+            // the mask step: only listed genes can change their bit
+            for (int j = threadIdx.x; j < nl; j += 256) {
+                const uint32_t g = lm_g[j];
+                const uint32_t ob = g >> 31, nb = ((g & 0x40000000u) && lm_m[j] <= kstar) ? 0u : 1u;  // inds = .!(pval <= pval_deg .& padj <= padj_deg), :417
+                if (nb != ob) {
+                    const int at = atomicAdd(&s_n, 1);
+                    atomicAdd(&s_nn, nb ? 1 : -1);
+                    if (at < kDeltaMax) dl[at] = ((g & 0x3FFFFFFFu) << 1) | nb;
+                }
+            }
+            bool ind = false;
+            if (live) {
+                const int sv = own_state & 3;
+                if (sv == 2) {
+                    const double p = normal_p(d1prev, se);
+                    ind = !(p <= a.pval_deg && bh_rank(p, G, a.padj_deg) <= kstar);
+                } else ind = sv != 0;
+            }
+            if (i < Gp) a.refbytes[nxt][i] = ind ? 1 : 0;
+            const unsigned long long mk = __ballot(ind);
+            if (lane == 0 && i < Gp) { a.refbits[nxt][i >> 5] = static_cast<uint32_t>(mk); a.refbits[nxt][(i >> 5) + 1] = static_cast<uint32_t>(mk >> 32); }
+            lds_barrier();
+            const int chg = s_n, nn = r.nref + s_nn;  // sum(inds), :417-418: the old mask's count (r.nref) + added - removed
+            if (blockIdx.x == 0) {
+                if (threadIdx.x == 0) { a.trace[2 * t] = G - nn; a.trace[2 * t + 1] = nn; a.scal[0] = se; }
+                if (static_cast<int>(threadIdx.x) < min(chg, kDeltaMax)) a.delta_list[static_cast<size_t>(nxt) * Gp + threadIdx.x] = dl[threadIdx.x];
+            }
+            r.nref_prev = r.nref;
+            const int diff = r.nref - nn;
+            if ((diff < 0 ? -diff : diff) < a.n_conv) r.done = 1;  // :419-422
+            else r.nref = nn;                                      // :423-424
+            r.t = t + 1; r.ran = 1; r.dcnt = chg; r.kstar = kstar;
+            r.need_full = chg > kDeltaMax ? 1 : 0;
+            r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
+            inref = ind;
+            n = min(chg, kDeltaMax);
+            stepped = true;
+        }
+        if (!TAIL) STAMP(a, 3);
+    }
+    if (TAIL) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            IterState *st = a.st;
+            st->passes = r.t; st->nref = r.nref; st->nref_prev = r.nref_prev; st->done = r.done; st->need_full = r.need_full;
+            st->i_iter = r.t - (r.done ? 1 : 0);
+            st->raw_pass = r.raw_pass;
+            st->delta_cnt[r.t & 1] = r.dcnt;
+            st->kstar = r.kstar;
+            if (r.ran) st->last_full = 0;
+            if (stepped) { a.scal[1] = win[0]; a.scal[2] = win[1]; a.scal[3] = win[2]; a.scal[4] = win[3]; }
+            if (a.host_st) {
+                IterState *h = a.host_st;
+                h->passes = r.t; h->done = r.done; h->need_full = r.need_full; h->delta_cnt[r.t & 1] = r.dcnt;
+                if (r.ran) h->last_full = 0;
+            }
+        }
+        return;
+    }
+    if (r.active) r.raw_pass = r.t;  // the tallies of pass r.t are made below
+    LightSlot *sl = &ls->slot[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sl->rec = r; sl->se_base = se_base; sl->eta = eta; }
+    if (!r.active || static_cast<int>(blockIdx.x) * 256 >= G) return;
+    // ---- pass r.t: tallies from the changed rows, delta1, window bookkeeping, brackets, lists
+    LightCnt *lc = &sl->lc;
+    const double wa_lo = win[0], wa_hi = win[1], wb_lo = win[2], wb_hi = win[3];
+    double v = 0.0;
+    bool inner = false, inA = false, inB = false, belowA = false, belowB = false;
+    if (n) {  // (workgroup-uniform)
+        int d[kRaw];
+        delta_counts_block(a.table, a.Wp, dl, n, d, dbuf);
+        if (live) {
+            r0.x += d[0]; r0.y += d[1]; r0.z += d[2]; r0.w += d[3];
+            r1.x += d[4]; r1.y += d[5]; r1.z += d[6]; r1.w += d[7];
+            int4 *o = reinterpret_cast<int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
+            o[0] = r0; o[1] = r1;
+        }
+    }
+    STAMP(a, 4);
+    if (live) {
+        int32_t c[9];
+        const bool tok = tallies_from(r0, r1, r.nref - (inref ? 1 : 0), c);  // the diagonal is never set (:363,385)
+        double out[5] = {1.0, 0.0, 0.0, 0.0, 0.0};
+        if (tok) mccullagh3<false>(c, out);
+        v = out[1];
+        if (!tok || !(fabs(v) < INFINITY)) { v = 0.0; raise_fault(a, kFaultTallies); }
+        a.result[11 * static_cast<size_t>(G) + i] = v;
+#pragma unroll
+        for (int x = 0; x < kHistParts; ++x) a.hist[(static_cast<size_t>(hb_next) * kHistParts + x) * a.hist_stride + i] = 0;  // the histogram of the NEXT launch: last read by the launch before this one
+        belowA = v < wa_lo; inA = !belowA && v <= wa_hi;
+        belowB = v < wb_lo; inB = !belowB && v <= wb_hi;
+        inner = v > wa_hi && v < wb_lo;
+    }
+    STAMP(a, 5);
+    {
+        double nb, sum;
+        block_sum2_256(inner ? 1.0 : 0.0, inner ? v : 0.0, red, nb, sum);
+        const double mean = nb > 0.0 ? sum / nb : 0.0;
+        const double m2 = block_sum_256(inner ? (v - mean) * (v - mean) : 0.0, red);
+        if (threadIdx.x == 0) { double *pp = a.part + static_cast<size_t>(pbuf) * 768 + 3 * blockIdx.x; pp[0] = nb; pp[1] = mean; pp[2] = m2; }
+    }
+    const unsigned long long mA = __ballot(inA), mB = __ballot(inB), bA = __ballot(belowA), bB = __ballot(belowB);
+    int baseA = 0, baseB = 0;
+    if (lane == 0) {
+        if (mA) baseA = atomicAdd(&lc->cnt_a, __popcll(mA));
+        if (mB) baseB = atomicAdd(&lc->cnt_b, __popcll(mB));
+        wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
+    }
+    baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    double *cand = a.cand + pbuf * 2 * kCandMax;
+    if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) cand[at] = v; }
+    if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) cand[kCandMax + at] = v; }
+    if (threadIdx.x == 0) s_c = 0;
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
+        if (ba) spread_add(lc->below_a, ba, a.xcc_local);
+        if (bb) spread_add(lc->below_b, bb, a.xcc_local);
+    }
+    STAMP(a, 6);
+    // brackets of this gene's p-value and rank around se_base (the se of the pass before; this pass's is not known yet)
+    {
+        const double Gd = static_cast<double>(G);
+        const double p_lo = live ? normal_p(v, se_base * (1.0 - eta)) : 1.0, p_hi = live ? normal_p(v, se_base * (1.0 + eta)) : 1.0;
+        const int m_lo = live ? bh_rank(p_lo, G, a.padj_deg) : G + 1;
+        const int K_in = r.kstar - a.band, K_out = min(r.kstar + a.band, G);
+        const bool bh_in = K_in >= 1 && p_hi * (Gd / static_cast<double>(K_in)) <= a.padj_deg;   // m_hi <= K_in (the step-up rule's own expression)
+        const bool bh_out = m_lo > K_out;
+        const bool pd_pass = p_hi <= a.pval_deg, pd_fail = p_lo > a.pval_deg;
+        const bool bit_sure = bh_out || pd_fail || (bh_in && pd_pass);
+        const bool newbit = bh_out || pd_fail;   // (when sure) 1 = not a DEG: stays in / enters the reference set
+        const bool listed = live && (!(bh_in || bh_out) || !bit_sure || newbit != inref);
+        {   // the histogram of m_lo: one partial per XCD (atomics that stay in that XCD's L2), the hot bin once per wave
+            const unsigned long long first = __ballot(m_lo == 1), finite = __ballot(m_lo <= G), sure_in = __ballot(live && bh_in && !listed);
+            const bool lead1 = m_lo == 1 && lane == __ffsll(static_cast<long long>(first)) - 1;
+            if (a.xcc_local) {
+                int32_t *hist = a.hist + (static_cast<size_t>(hb) * kHistParts + xcc_id()) * a.hist_stride;
+                if (lead1) __hip_atomic_fetch_add(&hist[0], __popcll(first), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else if (m_lo >= 2 && m_lo <= G) __hip_atomic_fetch_add(&hist[m_lo - 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                int32_t *hist = a.hist + static_cast<size_t>(hb) * kHistParts * a.hist_stride;
+                if (lead1) atomicAdd(&hist[0], __popcll(first));
+                else if (m_lo >= 2 && m_lo <= G) atomicAdd(&hist[m_lo - 1], 1);
+            }
+            if (lane == 0 && finite) spread_add(lc->sig, __popcll(finite), a.xcc_local);
+            if (lane == 0 && sure_in) spread_add(lc->nsure, __popcll(sure_in), a.xcc_local);
+        }
+        if (live) a.mrank[i] = listed ? 2 : (newbit ? 1 : 0);
+        // the list of this workgroup: genes that the next launch decides exactly
+        const unsigned long long cm = __ballot(listed);
+        int pos = 0;
+        if (cm && lane == 0) pos = atomicAdd(&s_c, __popcll(cm));
+        pos = __shfl(pos, 0, 64) + __popcll(cm & ((1ULL << lane) - 1ULL));
+        int32_t *ol = a.olist + static_cast<size_t>(pbuf) * kOneStride;
+        if (listed && pos < kOneListCap)
+            reinterpret_cast<int4 *>(ol + 256)[blockIdx.x * kOneListCap + pos] =
+                make_int4(static_cast<int>(static_cast<uint32_t>(i) | (inref ? 0x80000000u : 0u)), 0, __double2loint(v), __double2hiint(v));
+        lds_barrier();
+        if (threadIdx.x == 0) ol[blockIdx.x] = min(s_c, kOneListCap + 1);
+    }
+    STAMP(a, 7);
 }
 
 // ---------------------------------------------------------------------------
@@ -3409,9 +3813,9 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     a.sorted_p = c->sorted_p.p; a.rank_s = c->rank_s.p; a.rank_a = c->rank_a.p;
     a.part = c->part.p; a.blockmin = c->blockmin.p; a.scal = c->scal.p;
     a.trace = c->trace.p; a.modes = nullptr;
-    a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / (2 * kHistParts)); a.mrank = c->mrank.p;
+    a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / (3 * kHistParts)); a.mrank = c->mrank.p;
     a.replay = replay; a.k2_idx = 0;
-    a.clist = c->clist.p; a.band = c->light_band; a.xcc_local = c->xcc_local;
+    a.clist = c->clist.p; a.olist = c->olist.p; a.band = c->light_band; a.xcc_local = c->xcc_local;
     // (no light passes -- switched off, or given up by the running call: the sorting path then leaves need_full set, else its
     //  launches would wait for light passes that nobody enqueues)
     a.window = c->light_window; a.light_min_g = (c->it_no_light || c->light_mode == 0) ? 0x7FFFFFFF : c->light_min_g;
@@ -3461,13 +3865,22 @@ int32_t launch_light_persistent(reo_ctx *c)
     return REO_OK;
 }
 
-// A batch of light passes in the two-launch form: nlight x (kl_head, kl_rank) and the tail that ends the last pass.
+// A batch of light passes in the two-launch form: nlight x (kl_head, kl_rank) and the tail that ends the last pass (the default),
+// or nlight launches of kl_one and its tail (REO_LIGHT=3).
 int32_t launch_light_batch(reo_ctx *c, int nlight)
 {
     const IterArgs a = iter_args(c, 0);
     const int nb = (a.G + 255) / 256, nbp = a.Gp / 256;  // (the head writes every mask byte, padding included)
     if (nlight < 1 || nlight > kLightBatch) { set_error("light batch of %d passes", nlight); return REO_EINVAL; }
     REO_HIP_CHECK(hipMemsetAsync(c->lstate.p, 0, static_cast<size_t>(nlight + 1) * sizeof(LightSlot), c->stream));  // the slots this batch writes
+    if (c->light_mode == 3) {
+        // launch b fills histogram b % 3 and clears (b + 1) % 3: the first one of a batch is cleared here
+        REO_HIP_CHECK(hipMemsetAsync(c->hist.p, 0, static_cast<size_t>(kHistParts) * a.hist_stride * sizeof(int32_t), c->stream));
+        for (int b = 0; b < nlight; ++b) kl_one<false><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, b);
+        kl_one<true><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, nlight);
+        REO_HIP_CHECK(hipGetLastError());
+        return REO_OK;
+    }
     // the first mask step of a batch reads all BH ranks (the launch before it had no cut to make a list around); later
     // ones read the list of genes near the cut
     for (int b = 0; b < nlight; ++b) {

@@ -39,7 +39,9 @@ struct IterState {
     int32_t nref_prev; // nref of the last executed pass (for recomputing its outputs)
     int32_t last_full; // the last executed pass ran on the sorting path: every output column is in place
     int32_t fault;     // 0, or why the passes cannot be trusted (codes below); api.hip answers REO_EHIP
-    int32_t pad[3];
+    int32_t kstar;     // the BH cut (number of genes with padj <= padj_deg) of the last executed pass (-1: unknown)
+    int32_t kcut_acc;  // running count for kstar (sorting path)
+    int32_t pad[1];
 };
 constexpr int kFaultBarrier = 1;   // the persistent light kernel gave up at a grid barrier (bounded spin expired)
 constexpr int kFaultTallies = 2;   // a gene's tallies broke their invariant: not a class table (kernels.hip, tallies_from)
@@ -66,12 +68,16 @@ constexpr int kHistParts = 8;   // partial histograms of the BH ranks, one per X
 constexpr int kSpread = 8;
 constexpr int kListCap = 16;   // genes near the BH cut that one workgroup of kl_rank can list
 constexpr int kListStride = 256 + 256 * kListCap * 2;  // int32 per parity: counts by workgroup, then (word, gene) pairs
+constexpr int kOneListCap = 16;   // one-launch form (kl_one): genes that one workgroup can list per pass ...
+constexpr int kOneListMax = 512;  // ... and that a mask step takes in all (more: the pass goes to the sorting path)
+constexpr int kOneStride = 256 + 256 * kOneListCap * 4;  // int32 per parity: counts by workgroup, then entries of 16 bytes (gene | bit << 31, 0, delta1)
 struct LightCnt {
     int32_t cnt_a, cnt_b;            // members of the two quantile windows (slot allocation: returned values)
     int32_t pad[30];
     int32_t below_a[kSpread][32];    // values below window A   ([k][0] used: one cache line per part)
     int32_t below_b[kSpread][32];
     int32_t sig[kSpread][32];        // genes with a finite BH rank
+    int32_t nsure[kSpread][32];      // one-launch form: genes outside the lists whose BH rank is surely within the cut's band
 };
 // everything the launches after pass b of a batch need of it: rec = the state in FRONT of pass b; the rest is made by
 // pass b itself.  Zeroed by the host in front of the batch.
@@ -80,7 +86,9 @@ struct LightSlot {
     int32_t bfail;      // pass b lost a quantile window: it is redone on the sorting path
     int32_t pad0[5];
     double wnext[4];    // quantile windows for the pass after pass b
-    double pad1[4];
+    double se_base;     // one-launch form: the se that launch b bracketed its genes' p-values around (the se of the pass before)
+    double eta;         // ... and the half width of the bracket, relative
+    double pad1[2];
     LightCnt lc;
 };
 struct LightState { LightSlot slot[kLightBatch + 2]; };
@@ -231,7 +239,9 @@ struct reo_ctx {
     int light_band = 32;                // REO_LIGHT_BAND (tests)
     int xcc_local = 0;                  // the per-XCD histogram atomics may stay in the XCD's L2 (checked once per context: kernels.hip, xcc_selftest)
     int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
-    int light_mode = 1;                 // 0 sorting passes only, 1 light passes as two launches each, 2 as one persistent launch (REO_LIGHT)
+    int light_mode = 1;                 // 0 sorting passes only, 1 light passes as two launches each (the default), 2 as one persistent launch,
+                                        // 3 as ONE launch each (round 4: measured slower, 24.0 against 23.1 us per pass; opt-in) (REO_LIGHT)
+    reo::DevBuf<int32_t> olist;         // [2][kOneStride] one-launch form: the genes near the BH cut with their delta1, by workgroup (kernels.hip, kl_one)
     reo::DevBuf<int32_t> hist, mrank;   // [2][G padded to whole 32768-bin rounds], [Gp] light passes: histogram of the BH ranks (by launch parity), the ranks
     // parameters of the running reo_identify_degs call (kernels.hip, iter_args)
     double it_pval_deg = 1.0, it_padj_deg = 0.05;

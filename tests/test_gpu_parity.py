@@ -1284,15 +1284,16 @@ def test_workgroup_form_of_the_pair_kernel_still_matches(pkg, oracle, monkeypatc
     assert np.array_equal(codes[0], oracle.build_codes(X.astype(np.float64), gid, 2, 0, thr, seed))
 
 
-@pytest.mark.parametrize("window,light,band,xcc", [("3", "1", "32", "1"), ("1", "1", "32", "1"), ("12", "1", "2", "1"), ("12", "1", "0", "0"),
+@pytest.mark.parametrize("window,light,band,xcc", [("3", "3", "32", "1"), ("1", "3", "32", "1"), ("12", "3", "2", "1"), ("12", "3", "0", "0"), ("3", "3", "32", "0"),
+                                                   ("3", "1", "32", "1"), ("1", "1", "32", "1"), ("12", "1", "2", "1"), ("12", "1", "0", "0"),
                                                    ("3", "1", "32", "0"), ("3", "2", "32", "1"), ("1", "2", "32", "1")])
 def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monkeypatch, window, light, band, xcc):
     """The light iteration passes (quantile windows + BH cut from the histogram of step-up ranks) on many small random
     problems: REO_LIGHT_MIN_G lets small gene counts use them, and a window of 1-3 ranks makes windows lose their order
     statistic now and then, so the fall-back to the sorting path and the hand-over of the tally state between the two
     kinds of pass are exercised too.  More passes than usual (n_conv = 0 forces them); different padj / pval cut-offs;
-    tie-heavy data puts many equal delta1 values around the quantiles.  light = 1: two launches per pass (the default), 2: the
-    persistent one-launch form."""
+    tie-heavy data puts many equal delta1 values around the quantiles.  light = 1: two launches per pass (the default), 3: one
+    launch per pass (round 4: bracketed p-values, the cut from the listed genes' exact ranks), 2: the persistent form."""
     monkeypatch.setenv("REO_LIGHT_MIN_G", "64")
     monkeypatch.setenv("REO_LIGHT_WINDOW", window)
     monkeypatch.setenv("REO_LIGHT", light)
@@ -1327,7 +1328,7 @@ def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monke
         if run.timings["k2_launches"] < sum(c["iters_run"] for c in run.comparisons) + 2 * len(run.comparisons):
             light_batches += 1
     assert light_batches > 0
-    if xcc == "1" and light == "1":
+    if xcc == "1" and light in ("1", "3"):
         assert run.info["xcc_local_histograms"] == 1  # (the self-test of reo_create passes on an MI355X)
 
 
@@ -1340,17 +1341,18 @@ def test_sorting_passes_only_and_large_cuts_at_a_size_that_uses_light_passes(pkg
     group = pkg.synth.groups(S)
     ref0 = pkg.synth.ref_mask(G, 3000, seed)
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("3", "1", "0"):
         monkeypatch.setenv("REO_LIGHT", mode)
         with pkg.Context(device=0, seed=seed) as ctx:
             gid, lev = pkg.encode_groups(group)
             ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01); ctx.build_pairs(0)
             out[mode] = [ctx.identify_degs(ref0, 1.0, padj, 16, 0) for padj in (0.05, 0.9)]
-    for (r1, i1, t1), (r0, i0, t0) in zip(out["1"], out["0"]):
-        assert i1 == i0 == 16 and t1 == t0
-        assert np.array_equal(r1[:, 2:11], r0[:, 2:11])
-        ok = np.isfinite(r0).all(axis=1)
-        assert np.allclose(r1[ok][:, :2], r0[ok][:, :2], rtol=0, atol=P_ATOL)
+    for mode in ("3", "1"):
+        for (r1, i1, t1), (r0, i0, t0) in zip(out[mode], out["0"]):
+            assert i1 == i0 == 16 and t1 == t0, mode
+            assert np.array_equal(r1[:, 2:11], r0[:, 2:11]), mode
+            ok = np.isfinite(r0).all(axis=1)
+            assert np.allclose(r1[ok][:, :2], r0[ok][:, :2], rtol=0, atol=P_ATOL), mode
 
 
 @pytest.mark.parametrize("family,ngroups", [("t1", 2), ("t0", 2), ("float", 2), ("t1", 3), ("t1", -2), ("t0", -2)])
