@@ -227,6 +227,10 @@ static int32_t init_state(reo_ctx *c, int32_t nref)
 // complete table and runs the iteration passes on its own, with no further collective.
 static int32_t exchange_table(reo_ctx *c)
 {
+    if (c->x_pipelined) {  // launch_k1 has exchanged the table wave by wave, beside the pair kernel (kernels.hip)
+        c->table_complete = true;
+        return REO_OK;
+    }
     c->table_complete = c->world <= 1;
     if (c->world <= 1 && !c->comm) return REO_OK;  // (a communicator of one rank still makes its call: the path stays testable on one GPU)
     int32_t rc;
@@ -334,6 +338,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (const char *e = getenv("REO_LIGHT_MIN_G")) c->light_min_g = std::max(64, atoi(e));
     // (every switch is read here, once: no getenv on the paths a step takes)
     if (const char *e = getenv("REO_STATE_MIRROR")) c->state_mirror_wanted = (e[0] != '0');
+    if (const char *e = getenv("REO_EXCHANGE_WAVES")) c->x_waves = std::max(1, std::min(8, atoi(e)));
     c->debug_passes = getenv("REO_DEBUG_PASSES") != nullptr;
     c->debug_stamps = getenv("REO_DEBUG_STAMPS") != nullptr;
     c->k1_stamps = getenv("REO_K1_STAMPS") != nullptr;
@@ -367,7 +372,13 @@ void reo_destroy(reo_ctx *c)
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
     c->table.release();
     c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
-    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release(); c->k1_items.release();
+    c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release();
+    for (auto &il : c->k1_wave_items) il.buf.release();
+    for (int q = 0; q < 2; ++q) { if (c->k1s[q]) (void)hipStreamDestroy(c->k1s[q]); if (c->ev_k1_join[q]) (void)hipEventDestroy(c->ev_k1_join[q]); }
+    if (c->xs) (void)hipStreamDestroy(c->xs);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_x) (void)hipEventDestroy(c->ev_x);
+    for (auto &e : c->ev_k1) if (e) (void)hipEventDestroy(e);
     c->t_pos16.release(); c->t_lo16.release(); c->t_hi16.release(); c->gcounts.release();
     c->t_pos32.release(); c->t_lo32.release(); c->t_hi32.release(); c->t_vin32.release(); c->t_vout32.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }

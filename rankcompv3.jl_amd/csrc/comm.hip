@@ -33,10 +33,10 @@ namespace reo {
         }                                                                                     \
     } while (0)
 
-int32_t comm_allgather(reo_ctx *c, const void *send, void *recv, int64_t bytes_per_rank)
+int32_t comm_allgather(reo_ctx *c, const void *send, void *recv, int64_t bytes_per_rank, hipStream_t st)
 {
     if (!c->comm) return 1;
-    const ncclResult_t r = ncclAllGather(send, recv, static_cast<size_t>(bytes_per_rank), ncclUint8, static_cast<ncclComm_t>(c->comm), c->stream);
+    const ncclResult_t r = ncclAllGather(send, recv, static_cast<size_t>(bytes_per_rank), ncclUint8, static_cast<ncclComm_t>(c->comm), st ? st : c->stream);
     if (r != ncclSuccess) { set_error("ncclAllGather failed: %s", ncclGetErrorString(r)); return REO_ECOMM; }
     return REO_OK;
 }

@@ -3310,12 +3310,13 @@ struct XArgs {
     uint32_t *table;
     const uint32_t *units;  // every unit of the build: panel << 16 | i-range; owner = index % world
     int G, Wp, Wc, total, world, rank, maxu;
+    int m0, mcnt;           // the slots (units per shard: unit = shard + slot * world) of this exchange: [m0, m0 + mcnt) -- all of them, or one wave's
 };
 constexpr int kUnitRows = kUnitH * kTileI;
 
 __global__ __launch_bounds__(256) void x_pack(XArgs a, uint32_t *__restrict__ send)
 {
-    const int m = blockIdx.y, gu = a.rank + m * a.world;
+    const int m = blockIdx.y, gu = a.rank + (a.m0 + m) * a.world;
     const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * a.Wc;
     const size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (e >= uw) return;
@@ -3332,13 +3333,13 @@ __global__ __launch_bounds__(256) void x_pack(XArgs a, uint32_t *__restrict__ se
 
 __global__ __launch_bounds__(256) void x_expand_fwd(XArgs a, const uint32_t *__restrict__ recv)
 {
-    const int s = blockIdx.y / a.maxu, m = blockIdx.y % a.maxu, gu = s + m * a.world;
+    const int s = blockIdx.y / a.mcnt, m = blockIdx.y % a.mcnt, gu = s + (a.m0 + m) * a.world;
     if (s == a.rank || gu >= a.total) return;
     const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * a.Wc;
     const size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
     if (e >= uw) return;
-    const uint32_t v = recv[(static_cast<size_t>(s) * a.maxu + m) * uw + e];
-    if (!v) return;
+    const uint32_t v = recv[(static_cast<size_t>(s) * a.mcnt + m) * uw + e];
+    if (!v) return;   // (only words that carry bits are touched: see the note on concurrent pair kernels below)
     const uint32_t um = a.units[gu];
     const int p = static_cast<int>(um >> 16), r = static_cast<int>(um & 0xFFFFu);
     const int w = static_cast<int>(e % a.Wc), pl = static_cast<int>((e / a.Wc) % kPlanes), rr = static_cast<int>(e / (static_cast<size_t>(a.Wc) * kPlanes));
@@ -3351,12 +3352,12 @@ __global__ __launch_bounds__(256) void x_expand_fwd(XArgs a, const uint32_t *__r
 // row 32 jb + c, the two words that cover source rows 64 pair .. 64 pair + 63 -- kept by lane c and OR-ed into the table.
 __global__ __launch_bounds__(256) void x_expand_mirror(XArgs a, const uint32_t *__restrict__ recv)
 {
-    const int s = blockIdx.z / a.maxu, m = blockIdx.z % a.maxu, gu = s + m * a.world;
+    const int s = blockIdx.z / a.mcnt, m = blockIdx.z % a.mcnt, gu = s + (a.m0 + m) * a.world;
     if (s == a.rank || gu >= a.total) return;
     const int jb = blockIdx.x, pl = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * a.Wc;
-    const uint32_t *src = recv + (static_cast<size_t>(s) * a.maxu + m) * uw;
+    const uint32_t *src = recv + (static_cast<size_t>(s) * a.mcnt + m) * uw;
     const uint32_t um = a.units[gu];
     const int p = static_cast<int>(um >> 16), r = static_cast<int>(um & 0xFFFFu);
     const int j = (p * a.Wc + jb) * 32 + (lane & 31);  // the output row of lanes 0..31
@@ -3372,10 +3373,14 @@ __global__ __launch_bounds__(256) void x_expand_mirror(XArgs a, const uint32_t *
         }
         const int ow = (r * kUnitRows) / 32 + 2 * pair;  // two consecutive words of the output row
         if (lane < 32 && j < a.G && mine != 0 && ow + 1 < a.Wp) {
-            uint2 *o = reinterpret_cast<uint2 *>(a.table + (static_cast<size_t>(j) * kPlanes + (pl ^ 1)) * a.Wp + ow);  // L <-> H
-            uint2 t = *o;
-            t.x |= static_cast<uint32_t>(mine); t.y |= static_cast<uint32_t>(mine >> 32);
-            *o = t;
+            // word by word, and only words that carry bits: every word of the table belongs to ONE tile (all its bits come from
+            // one unit, hence one shard), so a word with bits of this sender is touched by nobody else -- but its neighbour may
+            // be a word that this shard's own pair kernel is writing right now (the pipelined exchange runs beside the pair
+            // kernel's later waves), and a read-modify-write of a pair of words would put a stale value back
+            uint32_t *o = a.table + (static_cast<size_t>(j) * kPlanes + (pl ^ 1)) * a.Wp + ow;  // L <-> H
+            const uint32_t lo32 = static_cast<uint32_t>(mine), hi32 = static_cast<uint32_t>(mine >> 32);
+            if (lo32) o[0] |= lo32;
+            if (hi32) o[1] |= hi32;
         }
     }
 }
@@ -3462,6 +3467,8 @@ static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool
     }
 }
 
+static int32_t exchange_args(reo_ctx *c, XArgs &a, int m0, int mcnt);
+
 int32_t launch_k1(reo_ctx *c, int k)
 {
     K1Args a;
@@ -3537,17 +3544,20 @@ int32_t launch_k1(reo_ctx *c, int k)
     }
     a.unit_map = c->unit_map.p;
     a.items = nullptr; a.stamps = nullptr;
-    if (wave || (wcounts && !c->gc_valid) || wmulti) {
-        // item list of the wave form: the owned units in order, side-major, i-tile-major, wave chunks fastest; kept
-        // until the geometry changes.  (Group counts: one item per tile and chunk, all groups' blocks.)
+    const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);   // (workgroup forms)
+    // item list of the wave form for a set of units: the units in order, side-major, i-tile-major, wave chunks fastest; kept
+    // until the geometry changes.  (Group counts: one item per tile and chunk, all groups' blocks.)  part: which wave of how
+    // many the units are (pipelined exchange; 0 of 1: all owned units)
+    auto item_list = [&](const std::vector<uint32_t> &units, reo_ctx::ItemList &cache, int part, int nparts) -> int32_t {
         const int CW = 64 * RJ, QW = Q * (CJ / CW);
         const uint32_t nsides = wave ? 2u : 1u;
         const bool halves = wave && !wide && c->k1_half;  // k1w_pairs only: its last round's items are dealt as two halves each
-        const uint64_t key[4] = {static_cast<uint64_t>(c->G) << 32 | static_cast<uint32_t>(c->Gp), static_cast<uint64_t>(halves ? 1 : 0) << 48 | static_cast<uint64_t>(RJ) << 32 | static_cast<uint32_t>(Q),
+        const uint64_t key[5] = {static_cast<uint64_t>(c->G) << 32 | static_cast<uint32_t>(c->Gp), static_cast<uint64_t>(halves ? 1 : 0) << 48 | static_cast<uint64_t>(RJ) << 32 | static_cast<uint32_t>(Q),
                                  static_cast<uint64_t>(c->world) << 32 | static_cast<uint32_t>(c->rank),
                                  static_cast<uint64_t>(nsides) << 56 | static_cast<uint64_t>(units.size()) << 24 |
-                                     static_cast<uint64_t>(wave ? std::max(a.ce - a.cb, a.te - a.tb) : c->goff32[c->ngroups] / 32)};
-        if (!c->k1_items.p || std::memcmp(key, c->k1_items_key, sizeof key) != 0) {
+                                     static_cast<uint64_t>(wave ? std::max(a.ce - a.cb, a.te - a.tb) : c->goff32[c->ngroups] / 32),
+                                 static_cast<uint64_t>(part) << 32 | static_cast<uint32_t>(nparts)};
+        if (!cache.buf.p || std::memcmp(key, cache.key, sizeof key) != 0) {
             // Workgroup b runs on XCD b & 7.  An item goes to the list of XCD (wave chunk & 7), and an XCD walks its list
             // group by group of its chunks (as many pos chunks of one side as fit about 2.5 MB of its 4 MiB L2), inside a
             // group side-major, then i-tile-major, chunks fastest: the group's pos planes stay in that L2 while each tile
@@ -3607,15 +3617,104 @@ int32_t launch_k1(reo_ctx *c, int k)
                         for (uint32_t x : tail) items.push_back(x | 0x8000u | (half ? 0x4000u : 0u));
                 }
             }
-            if ((rc = c->k1_items.ensure(std::max<size_t>(items.size(), 1)))) return rc;
+            int32_t rc2;
+            if ((rc2 = cache.buf.ensure(std::max<size_t>(items.size(), 1)))) return rc2;
             if (!items.empty()) {
-                REO_HIP_CHECK(hipMemcpyAsync(c->k1_items.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                REO_HIP_CHECK(hipMemcpyAsync(cache.buf.p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
                 REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // `items` is a local
             }
-            c->k1_items_n = items.size();
-            std::memcpy(c->k1_items_key, key, sizeof key);
+            cache.n = items.size();
+            std::memcpy(cache.key, key, sizeof key);
         }
-        a.items = c->k1_items.p;
+        return REO_OK;
+    };
+    auto dispatch = [&]() {   // the pair kernel(s) for a.items / c->k1_items_n on c->stream
+        switch (plane_bits(c->G)) {
+        case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems, wide); break;
+        case 15: launch_pair_kernels<15>(c, a, grid, shared, multi, plane_elems, wide); break;
+        case 16: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems, wide); break;
+        case 17: launch_big_pairs<17>(c, a, shared, multi, plane_elems, wide); break;
+        default: launch_big_pairs<18>(c, a, shared, multi, plane_elems, wide); break;
+        }
+    };
+    c->x_pipelined = false;
+    // Several shards and a gather exchange: this shard's units are counted in WAVES on two alternating streams (the tail of
+    // one wave's launch overlaps the head of the next), and as soon as wave w is done a third stream packs its forward
+    // words, all-gathers the shards' packs of that wave and unpacks them, while wave w + 1 is being counted.  Every word of
+    // the table belongs to one unit, the unpack kernels touch only words that carry another shard's bits, and the pair
+    // kernel only writes words of its own units: the three streams never meet in a word.  (Wave form for two groups only;
+    // everything else exchanges behind the pair kernel, as in round 3.)
+    const int maxu_x = std::max(1, (static_cast<int>(c->units_all_host.size()) + std::max(c->world, 1) - 1) / std::max(c->world, 1));
+    const int nwaves = (wave && c->world > 1 && (c->comm || c->ag) && !c->k1_stamps) ? std::min({c->x_waves, 8, maxu_x}) : 1;
+    if (nwaves > 1) {
+        const int mw = (maxu_x + nwaves - 1) / nwaves;   // slots per wave: the same on every shard
+        const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * (static_cast<size_t>(Q) * CJ / 32);
+        if ((rc = c->xsend.ensure(uw * mw * nwaves)) || (rc = c->xrecv.ensure(uw * mw * nwaves * c->world))) return rc;
+        if (!c->xs) {
+            for (int q = 0; q < 2; ++q) REO_HIP_CHECK(hipStreamCreateWithFlags(&c->k1s[q], hipStreamNonBlocking));
+            REO_HIP_CHECK(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+            REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
+            for (int q = 0; q < 2; ++q) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_k1_join[q], hipEventDisableTiming));
+            for (int q = 0; q < 8; ++q) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming));
+        }
+        // the waves' item lists (uploads synchronise c->stream: before anything is forked)
+        std::vector<std::vector<uint32_t>> wunits(nwaves);
+        for (size_t m = 0; m < units.size(); ++m) wunits[std::min<size_t>(m / mw, nwaves - 1)].push_back(units[m]);
+        for (int w = 0; w < nwaves; ++w)
+            if ((rc = item_list(wunits[w], c->k1_wave_items[w], w, nwaves))) return rc;
+        // the exchange kernels read the unit list and the geometry of THIS build
+        c->k1_cj = CJ; c->k1_q = Q;
+        XArgs xa;
+        if ((rc = exchange_args(c, xa, 0, mw))) return rc;
+        if (!c->table_prezeroed) REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * kPlanes * c->Wp * sizeof(uint32_t), c->stream));
+        c->table_prezeroed = false;
+        c->last_k1_shared = 0;
+        tic(c, 1);
+        REO_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
+        for (int q = 0; q < 2; ++q) REO_HIP_CHECK(hipStreamWaitEvent(c->k1s[q], c->ev_fork, 0));
+        REO_HIP_CHECK(hipStreamWaitEvent(c->xs, c->ev_fork, 0));
+        hipStream_t main_stream = c->stream;
+        int32_t xrc = REO_OK;
+        for (int w = 0; w < nwaves && !xrc; ++w) {
+            hipStream_t ks = c->k1s[w & 1];
+            c->stream = ks;   // (the launchers below enqueue on the context's stream)
+            a.items = c->k1_wave_items[w].buf.p; c->k1_items_n = c->k1_wave_items[w].n;
+            if (c->k1_items_n) dispatch();
+            c->stream = main_stream;
+            if (hipGetLastError() != hipSuccess) { set_error("pair kernel launch failed (wave %d)", w); xrc = REO_EHIP; break; }
+            REO_HIP_CHECK(hipEventRecord(c->ev_k1[w], ks));
+            REO_HIP_CHECK(hipStreamWaitEvent(c->xs, c->ev_k1[w], 0));
+            const int m0 = w * mw, mc = std::max(0, std::min(mw, maxu_x - m0));
+            if (mc == 0) continue;
+            uint32_t *send = c->xsend.p + uw * mw * w, *recv = c->xrecv.p + uw * mw * w * c->world;
+            const int64_t bytes = static_cast<int64_t>(uw) * mc * sizeof(uint32_t);
+            if ((xrc = launch_pack_units(c, m0, mc, send, c->xs))) break;
+            if (c->comm) { if ((xrc = comm_allgather(c, send, recv, bytes, c->xs)) < 0) break; xrc = REO_OK; }
+            else {
+                const int hrc = c->ag(send, recv, bytes, c->xs, c->ag_user);  // stream-ordered on the exchange stream
+                if (hrc) { set_error("all-gather hook failed with %d", hrc); xrc = REO_ECOMM; break; }
+            }
+            if ((xrc = launch_expand_units(c, m0, mc, recv, c->xs))) break;
+        }
+        // join: the pair kernels first (their makespan is the K1 stage time), then the exchange stream (what is left of it: the
+        // exposed part of the exchange)
+        for (int q = 0; q < 2; ++q) {
+            REO_HIP_CHECK(hipEventRecord(c->ev_k1_join[q], c->k1s[q]));
+            REO_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_k1_join[q], 0));
+        }
+        toc(c);
+        tic(c, 6);
+        REO_HIP_CHECK(hipEventRecord(c->ev_x, c->xs));
+        REO_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_x, 0));
+        toc(c);
+        if (xrc) return xrc;
+        c->x_pipelined = true;
+        return REO_OK;
+    }
+    if (wave || (wcounts && !c->gc_valid) || wmulti) {
+        if ((rc = item_list(units, c->k1_wave_items[0], 0, 1))) return rc;
+        a.items = c->k1_wave_items[0].buf.p; c->k1_items_n = c->k1_wave_items[0].n;
         if (c->k1_stamps) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), (std::max<size_t>(c->k1_items_n, 1) * 4 + 2) * sizeof(unsigned long long)));
     }
     // (every reader of the table -- the passes, the pack, a sum hook's element count, the scan of a hook's table -- works on
@@ -3623,17 +3722,10 @@ int32_t launch_k1(reo_ctx *c, int k)
     if (!c->table_prezeroed) REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * kPlanes * c->Wp * sizeof(uint32_t), c->stream));
     c->table_prezeroed = false;
     if (units.empty()) return REO_OK;
-    const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);
     c->last_k1_shared = shared ? 1 : 0;
     if (a.stamps) k_time_mark<<<1, 64, 0, c->stream>>>(a.stamps + c->k1_items_n * 4);
     tic(c, 1);
-    switch (plane_bits(c->G)) {
-    case 12: launch_pair_kernels<12>(c, a, grid, shared, multi, plane_elems, wide); break;
-    case 15: launch_pair_kernels<15>(c, a, grid, shared, multi, plane_elems, wide); break;
-    case 16: launch_pair_kernels<16>(c, a, grid, shared, multi, plane_elems, wide); break;
-    case 17: launch_big_pairs<17>(c, a, shared, multi, plane_elems, wide); break;
-    default: launch_big_pairs<18>(c, a, shared, multi, plane_elems, wide); break;
-    }
+    dispatch();
     toc(c);
     if (a.stamps) k_time_mark<<<1, 64, 0, c->stream>>>(a.stamps + c->k1_items_n * 4 + 1);
     REO_HIP_CHECK(hipGetLastError());
@@ -3686,41 +3778,56 @@ int32_t exchange_units_per_rank(const reo_ctx *c)
     return std::max(1, (total + world - 1) / world);
 }
 
-static int32_t exchange_args(reo_ctx *c, XArgs &a)
+// the unit list of the last launch_k1 on the device (uploaded when it changes)
+static int32_t upload_units_all(reo_ctx *c)
 {
     int32_t rc;
     const size_t total = c->units_all_host.size();
     if ((rc = c->units_all.ensure(std::max<size_t>(total, 1)))) return rc;
-    if (total) {
+    if (total && (c->units_all.p != c->units_all_uploaded || c->units_all_host != c->units_all_dev)) {
         REO_HIP_CHECK(hipMemcpyAsync(c->units_all.p, c->units_all_host.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));  // (the vector may be rebuilt by the next launch_k1 while the copy is in flight)
+        c->units_all_dev = c->units_all_host;
+        c->units_all_uploaded = c->units_all.p;
     }
-    a.table = c->table.p; a.units = c->units_all.p;
-    a.G = static_cast<int>(c->G); a.Wp = c->Wp; a.Wc = c->k1_q * c->k1_cj / 32;
-    a.total = static_cast<int>(total); a.world = std::max(c->world, 1); a.rank = c->rank; a.maxu = exchange_units_per_rank(c);
     return REO_OK;
 }
 
-int32_t launch_pack_units(reo_ctx *c)
+static int32_t exchange_args(reo_ctx *c, XArgs &a, int m0, int mcnt)
+{
+    const int32_t rc = upload_units_all(c);
+    if (rc) return rc;
+    a.table = c->table.p; a.units = c->units_all.p;
+    a.G = static_cast<int>(c->G); a.Wp = c->Wp; a.Wc = c->k1_q * c->k1_cj / 32;
+    a.total = static_cast<int>(c->units_all_host.size()); a.world = std::max(c->world, 1); a.rank = c->rank; a.maxu = exchange_units_per_rank(c);
+    a.m0 = m0; a.mcnt = mcnt < 0 ? a.maxu : mcnt;
+    return REO_OK;
+}
+
+// slots [m0, m0 + mcnt) of this shard -> send (mcnt < 0: all slots -> c->xsend, on the context's stream)
+int32_t launch_pack_units(reo_ctx *c, int m0, int mcnt, uint32_t *send, hipStream_t st)
 {
     XArgs a;
-    int32_t rc = exchange_args(c, a);
+    int32_t rc = exchange_args(c, a, m0, mcnt);
     if (rc) return rc;
     const size_t uw = static_cast<size_t>(exchange_unit_words(c));
-    x_pack<<<dim3(static_cast<unsigned>((uw + 255) / 256), a.maxu), 256, 0, c->stream>>>(a, c->xsend.p);
+    x_pack<<<dim3(static_cast<unsigned>((uw + 255) / 256), a.mcnt), 256, 0, st ? st : c->stream>>>(a, send ? send : c->xsend.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
 
-int32_t launch_expand_units(reo_ctx *c)
+// recv = every shard's pack of slots [m0, m0 + mcnt) -> the table: the others' words and their mirrors
+int32_t launch_expand_units(reo_ctx *c, int m0, int mcnt, const uint32_t *recv, hipStream_t st)
 {
     XArgs a;
-    int32_t rc = exchange_args(c, a);
+    int32_t rc = exchange_args(c, a, m0, mcnt);
     if (rc) return rc;
     if (a.world < 2) return REO_OK;  // (a communicator of one rank: its own pack came back)
     const size_t uw = static_cast<size_t>(exchange_unit_words(c));
-    x_expand_fwd<<<dim3(static_cast<unsigned>((uw + 255) / 256), a.maxu * a.world), 256, 0, c->stream>>>(a, c->xrecv.p);
-    x_expand_mirror<<<dim3(a.Wc, kPlanes, a.maxu * a.world), 256, 0, c->stream>>>(a, c->xrecv.p);
+    if (!st) st = c->stream;
+    if (!recv) recv = c->xrecv.p;
+    x_expand_fwd<<<dim3(static_cast<unsigned>((uw + 255) / 256), a.mcnt * a.world), 256, 0, st>>>(a, recv);
+    x_expand_mirror<<<dim3(a.Wc, kPlanes, a.mcnt * a.world), 256, 0, st>>>(a, recv);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }

@@ -181,9 +181,7 @@ struct reo_ctx {
     hipEvent_t ev_flags = nullptr;       // ... and the point of the stream at which they have arrived
     bool table_prezeroed = false;        // the transform has already queued the clearing of the class table (behind its flags copy)
     const uint32_t *unit_map_uploaded = nullptr;  // ... and into which allocation
-    reo::DevBuf<uint32_t> k1_items;  // wave form of K1: one work item per workgroup (side << 31 | wave chunk << 16 | i-tile)
-    size_t k1_items_n = 0;
-    uint64_t k1_items_key[4] = {0, 0, 0, 0};  // geometry the list was made for
+    size_t k1_items_n = 0;           // wave form of K1: items of the launch being made (one work item per workgroup: side << 31 | wave chunk << 16 | i-tile; lists: k1_wave_items)
     bool transformed = false;
     int has_ties = 0;
     int transform_in_lds = 0;  // the last transform sorted each sample inside one workgroup's LDS (transform.hip)
@@ -210,8 +208,17 @@ struct reo_ctx {
     int k1_cj = 0, k1_q = 0;  // K1 geometry of the last build: genes j per workgroup, j-chunks per panel
     // gather form of the exchange (kernels.hip, x_pack / x_expand_*): every work unit of the last build (panel << 16 | i-range,
     // owner = index % world), pack and gather buffers
-    std::vector<uint32_t> units_all_host;
+    std::vector<uint32_t> units_all_host, units_all_dev;   // ... and what the device copy holds
+    const uint32_t *units_all_uploaded = nullptr;
     reo::DevBuf<uint32_t> units_all, xsend, xrecv;
+    // pipelined exchange (several shards, wave form of the pair kernel): the shard's units are counted in waves, and wave w is
+    // packed, gathered and unpacked on a second stream while wave w + 1 is being counted (kernels.hip, launch_k1)
+    int x_waves = 4;                    // REO_EXCHANGE_WAVES (1: the whole exchange behind the pair kernel, as in round 3)
+    bool x_pipelined = false;           // the last launch_k1 has already exchanged the table
+    hipStream_t k1s[2] = {nullptr, nullptr}, xs = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_k1[8] = {nullptr}, ev_k1_join[2] = {nullptr, nullptr}, ev_x = nullptr;
+    struct ItemList { reo::DevBuf<uint32_t> buf; size_t n = 0; uint64_t key[5] = {0, 0, 0, 0, 0}; };
+    ItemList k1_wave_items[8];          // the item lists of the waves (kept until the geometry changes)
     reo::DevBuf<int32_t> check_flag;    // [1] verdict of k_check_table (kernels.hip, launch_check_table)
 
     // iteration state
@@ -274,8 +281,8 @@ int32_t run_transform(reo_ctx *c);
 int32_t launch_k1(reo_ctx *c, int k);
 int64_t exchange_unit_words(const reo_ctx *c);   // uint32 per packed work unit
 int32_t exchange_units_per_rank(const reo_ctx *c);
-int32_t launch_pack_units(reo_ctx *c);           // this shard's units -> c->xsend
-int32_t launch_expand_units(reo_ctx *c);         // c->xrecv (every shard's pack) -> the table: the others' words and their mirrors
+int32_t launch_pack_units(reo_ctx *c, int m0 = 0, int mcnt = -1, uint32_t *send = nullptr, hipStream_t st = nullptr);    // this shard's units (all, or slots m0 .. m0 + mcnt - 1) -> c->xsend / send
+int32_t launch_expand_units(reo_ctx *c, int m0 = 0, int mcnt = -1, const uint32_t *recv = nullptr, hipStream_t st = nullptr);  // every shard's pack -> the table: the others' words and their mirrors
 int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint16_t *d_gt, uint16_t *d_eq);
 int32_t launch_check_table(reo_ctx *c, int *bad);  // consistency of an exchanged class table (kernels.hip, k_check_table)
 int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
@@ -291,7 +298,7 @@ int32_t light_window();
 int32_t launch_mccullagh(reo_ctx *c, const int32_t *d_cont, int64_t n, double *d_out);
 
 // comm.hip: in-library RCCL.  Returns REO_OK after enqueueing the sum on c->stream, 1 when no communicator is attached
-int32_t comm_allgather(reo_ctx *c, const void *send, void *recv, int64_t bytes_per_rank);
+int32_t comm_allgather(reo_ctx *c, const void *send, void *recv, int64_t bytes_per_rank, hipStream_t st = nullptr);
 void comm_release(reo_ctx *c);
 void comm_abort(reo_ctx *c);                     // abort the communicator, mark the context unusable for exchanges
 int32_t comm_wait(reo_ctx *c);                   // stream wait that watches the communicator (async errors, time limit)

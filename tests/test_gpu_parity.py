@@ -404,6 +404,70 @@ def test_shards_on_one_gpu_reproduce_the_unsharded_run(pkg, oracle, exchange, wo
         _check_result(res, exp)
 
 
+@pytest.mark.parametrize("world,waves,family", [(2, "4", "t0"), (3, "4", "t1"), (3, "8", "t0"), (2, "1", "t0")])
+def test_pipelined_exchange_equals_the_unsharded_table(pkg, monkeypatch, world, waves, family):
+    """Several shards with a gather exchange count their units in waves and exchange wave w (pack, all-gather, unpack on a
+    second stream) while wave w + 1 is being counted (kernels.hip, launch_k1; REO_EXCHANGE_WAVES, 1 = the whole exchange
+    behind the pair kernel).  9 000 genes: 21 work units, i.e. several per shard and wave.  Every shard's table, tallies
+    and iteration must equal the unsharded context's, bit for bit; the hook is called once per wave."""
+    import threading
+    import torch
+    monkeypatch.setenv("REO_EXCHANGE_WAVES", waves)
+    G, S, seed = 9000, 32, 0x5EED0072
+    X = (pkg.synth.t1_counts if family == "t1" else pkg.synth.t0_ranks)(G, S, seed)
+    gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+    ref0 = pkg.synth.ref_mask(G, 900, seed)
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01); ctx.build_pairs(0)
+        want_codes = ctx.get_codes(0, G, 0, G)
+        want_cont = ctx.tally(ref0)
+        want_res, want_it, want_tr = ctx.identify_degs(ref0, 1.0, 0.05, 6, 0)
+    barrier = threading.Barrier(world)
+    slots, calls = [None] * world, [0] * world
+    dev = torch.device("cuda", 0)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            def gather(send, recv, nbytes, stream):
+                torch.cuda.ExternalStream(stream, device=dev).synchronize()
+                calls[rank] += 1
+                slots[rank] = torch.as_tensor(pkg.dist._RawDevBytes(send, nbytes), device=dev)
+                mine = torch.as_tensor(pkg.dist._RawDevBytes(recv, nbytes * world), device=dev)
+                barrier.wait()
+                for r in range(world):
+                    mine[r * nbytes:(r + 1) * nbytes].copy_(slots[r])
+                torch.cuda.synchronize()
+                barrier.wait()
+
+            with pkg.Context(device=0, seed=seed) as ctx:
+                ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+                ctx.set_shard(rank, world)
+                ctx.set_allgather(gather)
+                for rep in range(2):   # (the second build reuses the waves' item lists)
+                    ctx.build_pairs(0)
+                results[rank] = (ctx.get_codes(0, G, 0, G), ctx.tally(ref0), ctx.identify_degs(ref0, 1.0, 0.05, 6, 0), ctx.info())
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    total_units = 21
+    per_shard = -(-total_units // world)
+    assert calls == [2 * min(int(waves), per_shard)] * world, calls
+    for r in range(world):
+        codes, cont, (res, it, tr), info = results[r]
+        assert np.array_equal(codes, want_codes) and np.array_equal(cont, want_cont)
+        assert it == want_it and tr == want_tr and np.array_equal(res[:, 2:11], want_res[:, 2:11])
+        assert np.allclose(res[:, :2], want_res[:, :2], rtol=0, atol=1e-12)
+
+
 def test_three_group_golden_and_synthetic_one_vs_rest(pkg, oracle, golden):
     """More than two groups: one comparison per group against every other sample, 16 columns each."""
     g = golden("three_groups48.json")
