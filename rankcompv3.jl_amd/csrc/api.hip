@@ -700,9 +700,14 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // sorting passes, or a run of light passes; small problems sort every pass.
     // (more than 65 535 genes: sorting passes only -- the light passes keep per-workgroup lists and sums for at most 256
     //  workgroups of 256 genes)
-    c->state_mirror = c->light_mode != 2 && c->state_mirror_wanted;
-    bool small = G < c->light_min_g || c->light_mode == 0 || G > 65535;
-    c->it_no_light = G > 65535;  // (the device must know as well: a sorting pass that left need_full clear would wait for light passes nobody enqueues)
+
+    // light passes above 65 535 genes: the two-launch form only (its lists and block moments are sized for 1 024 workgroups of 256
+    // genes; the persistent form needs every workgroup resident, the one-launch form packs 16-bit state)
+    const int light_form = (G > 65535 && c->light_mode != 0) ? 1 : c->light_mode;
+    c->it_light_form = light_form;
+    c->state_mirror = light_form != 2 && c->state_mirror_wanted;
+    bool small = G < c->light_min_g || c->light_mode == 0;
+    c->it_no_light = false;  // (the device must know when nobody enqueues light passes: a sorting pass that left need_full clear would wait for them)
     int passes = 0, seen_need_full = 1, light_batches = 0, idle_light = 0, idle_any = 0;  // idle_light: light batches in a row that completed no pass
     while (n_iter > 0) {  // :400
         const int remaining = n_iter - passes;
@@ -716,7 +721,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         tic(c, 3);
         for (int t = 0; t < nfull; ++t)
             if ((rc = launch_full_pass(c, false))) return rc;
-        if (nlight > 0 && c->light_mode == 2) {
+        if (nlight > 0 && light_form == 2) {
             if ((rc = launch_light_persistent(c))) return rc;  // runs light passes until the state stops them
         } else if (nlight > 0) {
             if ((rc = launch_light_batch(c, nlight))) return rc;
@@ -724,7 +729,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         toc(c);
         if (!c->state_mirror) REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
         if ((rc = wait_or_drop_table(c))) return rc;
-        if (c->debug_passes && nlight > 0 && c->light_mode == 3) {  // which check of the one-launch form ended the batch
+        if (c->debug_passes && nlight > 0 && light_form == 3) {  // which check of the one-launch form ended the batch
             static LightState hs;
             if (hipMemcpy(&hs, c->lstate.p, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess)
                 for (int q = 1; q <= nlight; ++q)
@@ -770,10 +775,10 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     if (c->debug_stamps) {  // diagnostic builds (-DREO_STAMPS): marks of workgroup 0 in the last light launches, 10 ns units
         unsigned long long st[24];
         REO_HIP_CHECK(hipMemcpy(st, c->scal.p + 32, sizeof st, hipMemcpyDeviceToHost));
-        if (c->light_mode == 3) {
+        if (light_form == 3) {
             fprintf(stderr, "stamps kl_one (inputs back, se, cut, lists + mask step, changed rows, delta1, sums + windows, end):");
             for (int k = 0; k <= 7; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[8]));
-        } else if (c->light_mode == 2) {
+        } else if (light_form == 2) {
             fprintf(stderr, "stamps kl_persist, one pass (phase 1, barrier, phase 2, barrier, loads asked, cut, mask step):");
             for (int k = 1; k <= 7; ++k) fprintf(stderr, " %lld", (long long)(st[k] - st[0]));
         } else {

@@ -2069,8 +2069,8 @@ __device__ __forceinline__ int bh_rank(double p, int G, double al)
 // statistic.  sel: LDS scratch [2][4].
 // x: the window member this lane holds (wave 0: window A, wave 1: window B; lanes past the count: anything);
 // pn, pm, pq: the block partial this thread holds (threads past the number of partials: zeros).
-__device__ __forceinline__ bool slice_std_vals(const IterArgs &a, double x, double pn, double pm, double pq, int below_a, int below_b, int cnt_a, int cnt_b,
-                                               double (*sel)[4], double *red, double &se, double &va, double &vb)
+__device__ __forceinline__ bool slice_std_vals(const IterArgs &a, double x, const double (&pn)[kPartPer], const double (&pm)[kPartPer], const double (&pq)[kPartPer],
+                                               int below_a, int below_b, int cnt_a, int cnt_b, double (*sel)[4], double *red, double &se, double &va, double &vb)
 {
     const int ia = a.a0 - below_a, ib = a.b0 - below_b;  // positions of the order statistics inside the sorted windows
     if (!(cnt_a <= kCandMax && cnt_b <= kCandMax && ia >= 0 && ia < cnt_a && ib >= 0 && ib < cnt_b)) return false;  // workgroup-uniform
@@ -2087,10 +2087,16 @@ __device__ __forceinline__ bool slice_std_vals(const IterArgs &a, double x, doub
     }
     // Chan's combination of the block partials (the same bits in every thread of every workgroup; one partial per
     // thread); its barriers also publish sel
-    double n0, mean0;
-    block_sum2_256(pn, pn * pm, red, n0, mean0);
+    // (a thread holds the partials of workgroups t, t + 256, ...: one below 65 537 genes -- the others are zeros and change no bit)
+    double n0, mean0, sn = 0.0, sm = 0.0;
+#pragma unroll
+    for (int u = 0; u < kPartPer; ++u) { sn += pn[u]; sm += pn[u] * pm[u]; }
+    block_sum2_256(sn, sm, red, n0, mean0);
     mean0 /= n0;
-    double q0 = block_sum_256(pq + pn * (pm - mean0) * (pm - mean0), red);
+    double sq = 0.0;
+#pragma unroll
+    for (int u = 0; u < kPartPer; ++u) sq += pq[u] + pn[u] * (pm[u] - mean0) * (pm[u] - mean0);
+    double q0 = block_sum_256(sq, red);
     va = sel[0][0]; vb = sel[1][0];
     const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
     lds_barrier();  // sel may be rewritten by the next pass
@@ -2108,9 +2114,13 @@ __device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand,
                                           double (*sel)[4], double *red, double &se, double &va, double &vb)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double x = 0.0, pn = 0.0, pm = 0.0, pq = 0.0;
+    double x = 0.0, pn[kPartPer] = {0.0}, pm[kPartPer] = {0.0}, pq[kPartPer] = {0.0};
     if (wave < 2 && lane < (wave ? cnt_b : cnt_a) && lane < kCandMax) x = ldc<COH>(cand + wave * kCandMax + lane);
-    if (static_cast<int>(threadIdx.x) < npart) { pn = ldc<COH>(a.part + 3 * threadIdx.x); pm = ldc<COH>(a.part + 3 * threadIdx.x + 1); pq = ldc<COH>(a.part + 3 * threadIdx.x + 2); }
+#pragma unroll
+    for (int u = 0; u < kPartPer; ++u) {
+        const int w = threadIdx.x + 256 * u;
+        if (w < npart) { pn[u] = ldc<COH>(a.part + 3 * w); pm[u] = ldc<COH>(a.part + 3 * w + 1); pq[u] = ldc<COH>(a.part + 3 * w + 2); }
+    }
     return slice_std_vals(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
 }
 
@@ -2343,7 +2353,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
             for (int q = 0; q < kListPre; ++q) {
                 const int e = threadIdx.x + 256 * q, blk = e / kListCap;
                 le[q] = make_int2(0, 0); lcnt[q] = 0;
-                if (blk < nrow) { lcnt[q] = cl[blk]; le[q] = reinterpret_cast<const int2 *>(cl + 256)[e]; }
+                if (blk < nrow) { lcnt[q] = cl[blk]; le[q] = reinterpret_cast<const int2 *>(cl + kListWgs)[e]; }
             }
         }
         if (i < G) own_m = a.mrank[mrank_slot(i)];
@@ -2452,7 +2462,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
             for (int q = 0; q < kListPre; ++q) note(lcnt[q], le[q], threadIdx.x + 256 * q);
             const int32_t *cl = a.clist + static_cast<size_t>(pb) * kListStride;
 #pragma unroll 1
-            for (int e = threadIdx.x + 256 * kListPre; e < nrow * kListCap; e += 256) note(cl[e / kListCap], reinterpret_cast<const int2 *>(cl + 256)[e], e);
+            for (int e = threadIdx.x + 256 * kListPre; e < nrow * kListCap; e += 256) note(cl[e / kListCap], reinterpret_cast<const int2 *>(cl + kListWgs)[e], e);
             if (__ballot(bad) && lane == 0) s_fb = 1;
             lds_barrier();
             if (s_fb) {  // workgroup-uniform (and, the inputs being the same, the same in every workgroup)
@@ -2587,8 +2597,12 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
 #pragma unroll
     for (int q = 0; q < kSpread; ++q) { below_a += lc->below_a[q][0]; below_b += lc->below_b[q][0]; }
     const double x = wave < 2 ? a.cand[wave * kCandMax + lane] : 0.0;  // (every slot of cand exists; slots past the count are ignored)
-    double pn = 0.0, pm = 0.0, pq = 0.0;
-    if (static_cast<int>(threadIdx.x) < (G + 255) / 256) { pn = a.part[3 * threadIdx.x]; pm = a.part[3 * threadIdx.x + 1]; pq = a.part[3 * threadIdx.x + 2]; }
+    double pn[kPartPer] = {0.0}, pm[kPartPer] = {0.0}, pq[kPartPer] = {0.0};
+#pragma unroll
+    for (int u = 0; u < kPartPer; ++u) {   // (workgroup-uniform bound: above 65 536 genes a thread holds more than one block's moments)
+        const int w = threadIdx.x + 256 * u;
+        if (w < (G + 255) / 256) { pn[u] = a.part[3 * w]; pm[u] = a.part[3 * w + 1]; pq[u] = a.part[3 * w + 2]; }
+    }
     const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
     const double d1 = live ? a.result[11 * static_cast<size_t>(G) + i] : 0.0;
     // this gene's mask bit, both parities (which one counts is in the record, not known yet): asked for here because a load
@@ -2657,7 +2671,7 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
         pos = __shfl(pos, 0, 64) + __popcll(cm & ((1ULL << lane) - 1ULL));
         int32_t *cl = a.clist + static_cast<size_t>(pbuf) * kListStride;
         if (want && pos < kListCap)
-            reinterpret_cast<int2 *>(cl + 256)[blockIdx.x * kListCap + pos] = make_int2(static_cast<int>(static_cast<uint32_t>(rk) | (ob ? 0x80000000u : 0u)), i);
+            reinterpret_cast<int2 *>(cl + kListWgs)[blockIdx.x * kListCap + pos] = make_int2(static_cast<int>(static_cast<uint32_t>(rk) | (ob ? 0x80000000u : 0u)), i);
         lds_barrier();
         if (threadIdx.x == 0) cl[blockIdx.x] = min(s_c, kListCap + 1);
     }
@@ -2723,7 +2737,7 @@ __global__ __launch_bounds__(256) void kl_one(IterArgs a, LightState *ls, int b)
     int4 r0 = make_int4(0, 0, 0, 0), r1 = make_int4(0, 0, 0, 0);
     double win[4];
     int cnt_a = 0, cnt_b = 0, below_a = 0, below_b = 0, sig = 0, nsure = 0;
-    double xw = 0.0, pn = 0.0, pm = 0.0, pq = 0.0, se_base_prev = 0.0, eta_prev = 0.0;
+    double xw = 0.0, pn[kPartPer] = {0.0}, pm[kPartPer] = {0.0}, pq[kPartPer] = {0.0}, se_base_prev = 0.0, eta_prev = 0.0;   // (this form: at most 65 535 genes, one partial per thread)
     const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
     if (b > 0) {
         const int32_t *hist = a.hist + static_cast<size_t>(hb_prev) * kHistParts * a.hist_stride;
@@ -2747,7 +2761,7 @@ __global__ __launch_bounds__(256) void kl_one(IterArgs a, LightState *ls, int b)
         }
         if (live) { own_state = a.mrank[i]; d1prev = a.result[11 * static_cast<size_t>(G) + i]; }
         if (wave < 2) xw = a.cand[pb * 2 * kCandMax + wave * kCandMax + lane];
-        if (static_cast<int>(threadIdx.x) < nrow) { const double *pp = a.part + static_cast<size_t>(pb) * 768 + 3 * threadIdx.x; pn = pp[0]; pm = pp[1]; pq = pp[2]; }
+        if (static_cast<int>(threadIdx.x) < nrow) { const double *pp = a.part + static_cast<size_t>(pb) * 768 + 3 * threadIdx.x; pn[0] = pp[0]; pm[0] = pp[1]; pq[0] = pp[2]; }
     }
     if (!TAIL && live) {
         const int4 *o = reinterpret_cast<const int4 *>(a.raw + static_cast<size_t>(i) * kRaw);
@@ -3202,8 +3216,8 @@ __global__ __launch_bounds__(256) void kl_persist(IterArgs a, LightState *ls, un
 #pragma unroll
             for (int q = 0; q < kSpread; ++q) { below_a += ldc<true>(&lc->below_a[q][0]); below_b += ldc<true>(&lc->below_b[q][0]); }
             const double x = wave < 2 ? ldc<true>(a.cand + wave * kCandMax + lane) : 0.0;
-            double pn = 0.0, pm = 0.0, pq = 0.0;
-            if (static_cast<int>(threadIdx.x) < nrow) { pn = ldc<true>(a.part + 3 * threadIdx.x); pm = ldc<true>(a.part + 3 * threadIdx.x + 1); pq = ldc<true>(a.part + 3 * threadIdx.x + 2); }
+            double pn[kPartPer] = {0.0}, pm[kPartPer] = {0.0}, pq[kPartPer] = {0.0};   // (this form: at most 65 535 genes)
+            if (static_cast<int>(threadIdx.x) < nrow) { pn[0] = ldc<true>(a.part + 3 * threadIdx.x); pm[0] = ldc<true>(a.part + 3 * threadIdx.x + 1); pq[0] = ldc<true>(a.part + 3 * threadIdx.x + 2); }
             double va = 0.0, vb = 0.0;
             bool ok = slice_std_vals(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
             ok = ok && (va + wd1 < vb - wd2);
@@ -3980,7 +3994,7 @@ int32_t launch_light_batch(reo_ctx *c, int nlight)
     const int nb = (a.G + 255) / 256, nbp = a.Gp / 256;  // (the head writes every mask byte, padding included)
     if (nlight < 1 || nlight > kLightBatch) { set_error("light batch of %d passes", nlight); return REO_EINVAL; }
     REO_HIP_CHECK(hipMemsetAsync(c->lstate.p, 0, static_cast<size_t>(nlight + 1) * sizeof(LightSlot), c->stream));  // the slots this batch writes
-    if (c->light_mode == 3) {
+    if (c->it_light_form == 3) {
         // launch b fills histogram b % 3 and clears (b + 1) % 3: the first one of a batch is cleared here
         REO_HIP_CHECK(hipMemsetAsync(c->hist.p, 0, static_cast<size_t>(kHistParts) * a.hist_stride * sizeof(int32_t), c->stream));
         for (int b = 0; b < nlight; ++b) kl_one<false><<<nbp, 256, 0, c->stream>>>(a, c->lstate.p, b);

@@ -67,7 +67,9 @@ struct LightRec {
 constexpr int kHistParts = 8;   // partial histograms of the BH ranks, one per XCD (kernels.hip, kl_rank)
 constexpr int kSpread = 8;
 constexpr int kListCap = 16;   // genes near the BH cut that one workgroup of kl_rank can list
-constexpr int kListStride = 256 + 256 * kListCap * 2;  // int32 per parity: counts by workgroup, then (word, gene) pairs
+constexpr int kListWgs = 1024;  // workgroups of 256 genes that the lists and the block moments are sized for (262 144 genes)
+constexpr int kPartPer = kListWgs / 256;  // block moments per thread when every workgroup combines all of them
+constexpr int kListStride = kListWgs + kListWgs * kListCap * 2;  // int32 per parity: counts by workgroup, then (word, gene) pairs
 constexpr int kOneListCap = 16;   // one-launch form (kl_one): genes that one workgroup can list per pass ...
 constexpr int kOneListMax = 512;  // ... and that a mask step takes in all (more: the pass goes to the sorting path)
 constexpr int kOneStride = 256 + 256 * kOneListCap * 4;  // int32 per parity: counts by workgroup, then entries of 16 bytes (gene | bit << 31, 0, delta1)
@@ -254,6 +256,7 @@ struct reo_ctx {
     double it_pval_deg = 1.0, it_padj_deg = 0.05;
     int it_n_iter = 0, it_n_conv = 0, it_a0 = 0, it_b0 = 0;
     int k2_idx = 0;                     // K2 launches of the running call
+    int it_light_form = 1;              // the form of light pass the running call uses (light_mode, or 1 above 65 535 genes)
     bool it_no_light = false;           // the running call has given up on light passes (two light batches in a row completed no pass)
     reo::IterState *host_state = nullptr;  // pinned
     bool state_mirror_wanted = true;       // REO_STATE_MIRROR=0 (read once, in reo_create, like every other switch)
