@@ -2109,6 +2109,51 @@ __device__ __forceinline__ bool slice_std_vals(const IterArgs &a, double x, cons
     return static_cast<int>(n) == a.b0 - a.a0 + 1;
 }
 
+// The same, with the three jobs on three waves and ONE barrier (kl_rank): wave 0 sorts window A, wave 1 window B, wave 2 combines
+// the block partials by itself -- lane l holds the partials of workgroups l, l + 64, ... (kPartLane of them) and the sums are
+// wave sums -- instead of three workgroup-wide sums with two barriers each behind the sorts.  Every workgroup does the same
+// operations in the same order, so all of them get the same bits (not the bits of slice_std_vals: another summation order).
+constexpr int kPartLane = kListWgs / 64;
+__device__ __forceinline__ bool slice_std_split(const IterArgs &a, double x, const double (&pn)[kPartLane], const double (&pm)[kPartLane], const double (&pq)[kPartLane],
+                                                int below_a, int below_b, int cnt_a, int cnt_b, double (*sel)[4], double &se, double &va, double &vb)
+{
+    const int ia = a.a0 - below_a, ib = a.b0 - below_b;  // positions of the order statistics inside the sorted windows
+    if (!(cnt_a <= kCandMax && cnt_b <= kCandMax && ia >= 0 && ia < cnt_a && ib >= 0 && ib < cnt_b)) return false;  // workgroup-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < 2) {
+        const int cnt = wave ? cnt_b : cnt_a, pos = wave ? ib : ia;
+        x = sort64(lane < cnt ? x : INFINITY);
+        const bool in = wave ? lane <= pos : (lane >= pos && lane < cnt);
+        const double n = static_cast<double>(wave ? pos + 1 : cnt - pos);
+        const double mean = wave_sum(in ? x : 0.0) / n;
+        const double q = wave_sum(in ? (x - mean) * (x - mean) : 0.0);
+        const double stat = __shfl(x, pos, 64);
+        if (lane == 0) { sel[wave][0] = stat; sel[wave][1] = n; sel[wave][2] = mean; sel[wave][3] = q; }
+    } else if (wave == 2) {
+        double sn = 0.0, sm = 0.0;
+#pragma unroll
+        for (int u = 0; u < kPartLane; ++u) { sn += pn[u]; sm += pn[u] * pm[u]; }
+        const double n0 = wave_sum(sn);
+        const double mean0 = wave_sum(sm) / n0;
+        double sq = 0.0;
+#pragma unroll
+        for (int u = 0; u < kPartLane; ++u) sq += pq[u] + pn[u] * (pm[u] - mean0) * (pm[u] - mean0);
+        const double q0 = wave_sum(sq);
+        if (lane == 0) { sel[2][0] = 0.0; sel[2][1] = n0; sel[2][2] = mean0; sel[2][3] = q0; }
+    }
+    lds_barrier();
+    va = sel[0][0]; vb = sel[1][0];
+    const double n1 = sel[0][1], mean1 = sel[0][2], q1 = sel[0][3], n2 = sel[1][1], mean2 = sel[1][2], q2 = sel[1][3];
+    double n0 = sel[2][1], mean0 = sel[2][2], q0 = sel[2][3];
+    if (!(n0 > 0.0)) { mean0 = 0.0; q0 = 0.0; }  // no value between the windows: the mean above divided by zero
+    const double n = n0 + n1 + n2;
+    const double mean = (n0 * mean0 + n1 * mean1 + n2 * mean2) / n;
+    const double m2 = (q0 + n0 * (mean0 - mean) * (mean0 - mean)) + (q1 + n1 * (mean1 - mean) * (mean1 - mean)) +
+                      (q2 + n2 * (mean2 - mean) * (mean2 - mean));
+    se = sqrt(m2 / (n - 1.0));
+    return static_cast<int>(n) == a.b0 - a.a0 + 1;
+}
+
 template <bool COH>
 __device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand, int npart, int below_a, int below_b, int cnt_a, int cnt_b,
                                           double (*sel)[4], double *red, double &se, double &va, double &vb)
@@ -2597,11 +2642,12 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
 #pragma unroll
     for (int q = 0; q < kSpread; ++q) { below_a += lc->below_a[q][0]; below_b += lc->below_b[q][0]; }
     const double x = wave < 2 ? a.cand[wave * kCandMax + lane] : 0.0;  // (every slot of cand exists; slots past the count are ignored)
-    double pn[kPartPer] = {0.0}, pm[kPartPer] = {0.0}, pq[kPartPer] = {0.0};
+    double pn[kPartLane], pm[kPartLane], pq[kPartLane];   // wave 2: lane l holds the moments of workgroups l, l + 64, ... (slice_std_split)
 #pragma unroll
-    for (int u = 0; u < kPartPer; ++u) {   // (workgroup-uniform bound: above 65 536 genes a thread holds more than one block's moments)
-        const int w = threadIdx.x + 256 * u;
-        if (w < (G + 255) / 256) { pn[u] = a.part[3 * w]; pm[u] = a.part[3 * w + 1]; pq[u] = a.part[3 * w + 2]; }
+    for (int u = 0; u < kPartLane; ++u) {
+        const int w = lane + 64 * u;
+        pn[u] = pm[u] = pq[u] = 0.0;
+        if (wave == 2 && w < (G + 255) / 256) { pn[u] = a.part[3 * w]; pm[u] = a.part[3 * w + 1]; pq[u] = a.part[3 * w + 2]; }
     }
     const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
     const double d1 = live ? a.result[11 * static_cast<size_t>(G) + i] : 0.0;
@@ -2610,10 +2656,9 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     const uint8_t ob_e = live ? a.refbytes[0][i] : 0, ob_o = live ? a.refbytes[1][i] : 0;
     if (!active) return;
     STAMP(a, 20);
-    __shared__ double red[256];
-    __shared__ double sel[2][4];
+    __shared__ double sel[3][4];
     double se = 0.0, va = 0.0, vb = 0.0;
-    bool ok = slice_std_vals(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, red, se, va, vb);
+    bool ok = slice_std_split(a, x, pn, pm, pq, below_a, below_b, cnt_a, cnt_b, sel, se, va, vb);
     ok = ok && (va + wd1 < vb - wd2);
     STAMP(a, 21);
     if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -157,15 +157,32 @@ def unit_list(G: int, slots: int, has_ties: bool):
     return units, Q * CJ
 
 
-def pack_units(planes: np.ndarray, G: int, slots: int, has_ties: bool, rank: int, world: int) -> np.ndarray:
-    """x_pack: the forward rectangles of this shard's units as they stand in its (partial) table `planes` [G, 4, G],
-    one after the other, zero-padded to whole rectangles and to ceil(units / world) units."""
+def wave_plan(G: int, slots: int, has_ties: bool, world: int, waves: int = 4):
+    """The pipelined exchange of launch_k1: a shard's slots (unit = shard + slot * world) are counted and exchanged in
+    `nwaves` waves of `mw` slots -- the same numbers on every shard.  Returns (nwaves, mw, slots per shard)."""
+    units, _ = unit_list(G, slots, has_ties)
+    maxu = max(1, (len(units) + world - 1) // world)
+    nwaves = min(waves, 8, maxu) if world > 1 else 1
+    mw = (maxu + nwaves - 1) // nwaves
+    return nwaves, mw, maxu
+
+
+def wave_of_unit(G: int, slots: int, has_ties: bool, world: int, waves: int = 4) -> np.ndarray:
+    """wave in which each unit of the build is counted (by its owner)."""
+    units, _ = unit_list(G, slots, has_ties)
+    nwaves, mw, _ = wave_plan(G, slots, has_ties, world, waves)
+    return np.array([min((u // world) // mw, nwaves - 1) for u in range(len(units))], dtype=np.int64)
+
+
+def pack_units(planes: np.ndarray, G: int, slots: int, has_ties: bool, rank: int, world: int, m0: int = 0, mcnt: int | None = None) -> np.ndarray:
+    """x_pack: the forward rectangles of this shard's units (all of them, or the slots m0 .. m0 + mcnt - 1 of one wave) as they
+    stand in its (partial) table `planes` [G, 4, G], one after the other, zero-padded to whole rectangles and to the slot count."""
     units, W = unit_list(G, slots, has_ties)
     H = UNIT_H * TILE_I
-    maxu = max(1, (len(units) + world - 1) // world)
+    maxu = max(1, (len(units) + world - 1) // world) if mcnt is None else mcnt
     out = np.zeros((maxu, H, 4, W), dtype=planes.dtype)
     for m in range(maxu):
-        gu = rank + m * world
+        gu = rank + (m0 + m) * world
         if gu >= len(units):
             continue
         p, r = units[gu]
@@ -174,13 +191,13 @@ def pack_units(planes: np.ndarray, G: int, slots: int, has_ties: bool, rank: int
     return out
 
 
-def expand_units(planes: np.ndarray, recv: np.ndarray, G: int, slots: int, has_ties: bool, rank: int, world: int) -> None:
-    """x_expand_fwd + x_expand_mirror: OR the other shards' rectangles (recv[s] = shard s's pack) into `planes`, then their
-    transposes with the low / high planes swapped (the pair seen from the other gene, src/RankCompV3.jl:386)."""
+def expand_units(planes: np.ndarray, recv: np.ndarray, G: int, slots: int, has_ties: bool, rank: int, world: int, m0: int = 0) -> None:
+    """x_expand_fwd + x_expand_mirror: OR the other shards' rectangles (recv[s] = shard s's pack of the slots from m0 on) into
+    `planes`, then their transposes with the low / high planes swapped (the pair seen from the other gene, src/RankCompV3.jl:386)."""
     units, W = unit_list(G, slots, has_ties)
     H = UNIT_H * TILE_I
     swap = [1, 0, 3, 2]
-    todo = [(s, m, units[s + m * world]) for s in range(world) if s != rank for m in range(recv.shape[1]) if s + m * world < len(units)]
+    todo = [(s, m, units[s + (m0 + m) * world]) for s in range(world) if s != rank for m in range(recv.shape[1]) if s + (m0 + m) * world < len(units)]
     for s, m, (p, r) in todo:
         rows, cols = slice(r * H, min((r + 1) * H, G)), slice(p * W, min((p + 1) * W, G))
         planes[rows, :, cols] |= recv[s, m, :rows.stop - rows.start, :, :cols.stop - cols.start]

@@ -66,6 +66,55 @@ def test_gather_exchange_mirror_assembles_the_table(pkg, G, ties, world):
         assert np.array_equal(t, whole), (r, world)
 
 
+@pytest.mark.parametrize("G,ties,world,waves", [(5200, False, 3, 4), (5200, True, 2, 4), (4100, False, 2, 8), (3100, True, 3, 4)])
+def test_pipelined_exchange_mirror_assembles_the_table_wave_by_wave(pkg, G, ties, world, waves):
+    """The pipelined form of the exchange (launch_k1): units are counted in waves; wave w is packed from a table that holds the
+    shard's own bits of the waves up to w -- and, because the pair kernel runs on beside the pack, ANY part of its later
+    waves' bits -- gathered and OR-ed in before the later waves exist.  Every shard must end with the complete table, whatever
+    the later waves had written when an earlier one was packed (bits that travel early arrive again: everything is OR-ed)."""
+    import sharding_mirror as sh
+    rng = np.random.default_rng(G * 7 + world)
+    code = rng.integers(0, 9, size=(G, G)).astype(np.uint8)
+    iu = np.triu_indices(G, 1)
+    code[iu[1], iu[0]] = (2 - code[iu] // 3) * 3 + (2 - code[iu] % 3)
+    np.fill_diagonal(code, 255)
+    slots = 64
+    whole = sh.class_planes(code)
+    owner = sh.tile_owner(G, slots, ties, world)                     # per pair tile
+    nwaves, mw, maxu = sh.wave_plan(G, slots, ties, world, waves)
+    assert nwaves > 1
+    # the bits of every shard by wave: mask of the pairs of its units counted in that wave
+    units, W = sh.unit_list(G, slots, ties)
+    wave_of = sh.wave_of_unit(G, slots, ties, world, waves)
+    H = sh.UNIT_H * sh.TILE_I
+    unit_of_pair = np.full((G, G), -1, dtype=np.int64)
+    for u, (p_, r_) in enumerate(units):
+        unit_of_pair[r_ * H:(r_ + 1) * H, p_ * W:(p_ + 1) * W] = u
+    upper = np.triu(np.ones((G, G), dtype=bool), 1)
+    unit_of_pair = np.where(upper, unit_of_pair, unit_of_pair.T)     # a pair and its mirror belong to the unit of the (i < j) pair
+    tables = []
+    for r in range(world):
+        mine = sh.owned_pair_mask(G, slots, ties, r, world)
+        assert np.array_equal(mine, (unit_of_pair % world == r) & (unit_of_pair >= 0) & ~np.eye(G, dtype=bool))
+        tables.append(np.zeros_like(whole))
+    for w in range(nwaves):
+        packs = []
+        for r in range(world):
+            mine_w = (unit_of_pair >= 0) & (unit_of_pair % world == r) & (wave_of[np.maximum(unit_of_pair, 0)] == w) & ~np.eye(G, dtype=bool)
+            tables[r] |= sh.class_planes(code, mine_w)               # wave w is counted ...
+            later = (unit_of_pair >= 0) & (unit_of_pair % world == r) & (wave_of[np.maximum(unit_of_pair, 0)] > w) & ~np.eye(G, dtype=bool)
+            seen = tables[r] | sh.class_planes(code, later & (rng.random((G, G)) < 0.3))   # ... and the pack may catch bits of the waves still running
+            mc = max(0, min(mw, maxu - w * mw))                      # (the last waves can be empty: no exchange then, on any shard)
+            if mc:
+                packs.append(sh.pack_units(seen, G, slots, ties, r, world, m0=w * mw, mcnt=mc))
+        if packs:
+            packs = np.stack(packs)
+            for r in range(world):
+                sh.expand_units(tables[r], packs, G, slots, ties, r, world, m0=w * mw)
+    for r in range(world):
+        assert np.array_equal(tables[r], whole), (r, world)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -105,6 +154,18 @@ def _worker(rank, world, port, G, S, seed, out):
         recv = [torch.empty_like(pack) for _ in range(world)]
         dist.all_gather(recv, pack)
         sh.expand_units(part, np.stack([r.numpy() for r in recv]), G, slots, True, rank, world)
+        assert part.max() == 1 and np.array_equal(sh.codes_from_planes(part), code)
+        # the pipelined form of it (launch_k1): one all-gather per wave of units, every shard calling it the same number of times
+        nwaves, mw, maxu = sh.wave_plan(G, slots, True, world)
+        part = np.ascontiguousarray(sh.class_planes(code, mask))
+        for w in range(nwaves):
+            mc = max(0, min(mw, maxu - w * mw))
+            if mc == 0:
+                continue
+            pack = torch.from_numpy(sh.pack_units(part, G, slots, True, rank, world, m0=w * mw, mcnt=mc))
+            recv = [torch.empty_like(pack) for _ in range(world)]
+            dist.all_gather(recv, pack)
+            sh.expand_units(part, np.stack([r.numpy() for r in recv]), G, slots, True, rank, world, m0=w * mw)
         assert part.max() == 1 and np.array_equal(sh.codes_from_planes(part), code)
         # ... after which tallies and the loop of src/RankCompV3.jl:396-425 run unsharded on every rank
         ref0 = pkg.synth.ref_mask(G, 200, seed)
