@@ -715,8 +715,10 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         // (they would return at once otherwise: seven idle launches each), light launches only behind a pass that left
         // windows.  The first light batch is short, because a run that converges does so within a few passes and every
         // launch after that is idle; later ones are longer.
-        const int nfull = small ? std::min(8, remaining) : (seen_need_full ? std::min(2, remaining) : 0);
-        const int nlight = (small || seen_need_full) ? 0 : std::min(light_batches == 0 ? kLightBatch / 2 : kLightBatch, remaining);
+        // (the first batch: four -- the reference set settles over the first three or four passes, and a sorting launch that is not
+        //  wanted returns at once for the price of a batch boundary)
+        const int nfull = small ? std::min(8, remaining) : (seen_need_full ? std::min(passes == 0 ? 4 : 2, remaining) : 0);
+        const int nlight = (small || seen_need_full) ? 0 : std::min(light_batches == 0 ? 32 : kLightBatch, remaining);
         if (nlight > 0) ++light_batches;
         tic(c, 3);
         for (int t = 0; t < nfull; ++t)
@@ -730,7 +732,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         if (!c->state_mirror) REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
         if ((rc = wait_or_drop_table(c))) return rc;
         if (c->debug_passes && nlight > 0 && light_form == 3) {  // which check of the one-launch form ended the batch
-            static LightState hs;
+            static LightState hs;  // (half a megabyte: not on the stack)
             if (hipMemcpy(&hs, c->lstate.p, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess)
                 for (int q = 1; q <= nlight; ++q)
                     if (hs.slot[q].pad0[0] || q <= 3)

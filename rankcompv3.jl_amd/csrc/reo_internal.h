@@ -50,7 +50,7 @@ constexpr int kFaultTallies = 2;   // a gene's tallies broke their invariant: no
 // append-only log, so that no kernel reads a word that another workgroup of the same launch writes.  rec[b] = the state
 // in front of light pass b of the batch (rec of slot nlight: behind the last one), written by workgroup 0 of launch b,
 // read by the launches after it.
-constexpr int kLightBatch = 64;  // light passes per batch of launches (the first batch of a call: half)
+constexpr int kLightBatch = 128; // most light passes per batch of launches (the first batch of a call: 32)
 struct LightRec {
     int32_t active;     // pass `t` is to run as a light pass
     int32_t t;          // passes executed so far = index of the next pass
