@@ -382,6 +382,8 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
 //      fl(x - y) is monotone in y, so the tied codes are an interval around the gene's code; start at x -+ 0.1, gallop,
 //      bisect (two or three evaluations unless x - 0.1 cancels to something tiny).  Exact, like the band search in the
 //      sorted keys that it replaces.
+// Phase 4 walks the SLOTS, not the genes: the lanes of a wave then hold members of the same or of neighbouring buckets and
+// their scans run equally long (results go to a by-slot scratch row and into gene order through LDS at the end).
 // Never gives up: a crowded bucket only costs its own members a longer scan.  Arrival slot, bucket and the 16 offset bits are
 // parked in the gene's pos / lo / hi rows between the phases (a thread reads back what it wrote itself).
 // flags: 0 non-finite input, 1 some tie.
@@ -439,7 +441,8 @@ template <class T, int LOGSUB>
 __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
                                                       const int32_t *__restrict__ slots, int G, int Gp, int S,
                                                       uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
-                                                      uint16_t *__restrict__ hi, int32_t *__restrict__ flags)
+                                                      uint16_t *__restrict__ hi, int32_t *__restrict__ flags,
+                                                      uint64_t *__restrict__ oslot, uint16_t *__restrict__ bslot)
 {
     constexpr int SUB = 1 << LOGSUB, PER = SUB + 1, NB = kSplit1 * PER;   // per splitter: SUB pieces of the interval below it + its equality bucket
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     // value only) or lies strictly between splitters lb - 1 and lb, in piece ((k - from) >> sh) of that interval; r16 = the
     // next 16 bits of its offset; exact: bucket and r16 are the whole code.
     auto locate = [&](uint64_t k, uint32_t &bucket, uint32_t &r16, bool &exact) {
-        int lb = 0;
+        int lb = 0;   // (a 4-ary search -- five levels of three independent reads -- was slower: 48 against 29 us for the histogram phase)
 #pragma unroll
         for (int s = kSplit1 / 2; s > 0; s >>= 1) lb += spl[lb + s - 1] < k ? s : 0;
         const uint64_t to = spl[lb];
@@ -557,11 +560,14 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     __syncthreads();
     TSTAMP(4);
     // ---- 3. members into bucket order
+    uint16_t *bs = bslot + static_cast<size_t>(c) * Gp;      // by slot: bucket | exact << 15 (global scratch: phase 4 walks the slots)
+    uint64_t *os = oslot + static_cast<size_t>(c) * Gp;      // by slot: gene | pos << 16 | lo << 32 | hi << 48
 #pragma unroll 4
     for (int i = t; i < G; i += 1024) {
-        const uint32_t sl = hist[at(lrow[i])] + (prow[i] & 0x7FFFu);
+        const uint32_t b = lrow[i], pk = prow[i], sl = hist[at(b)] + (pk & 0x7FFFu);
         rem[sl] = hrow[i];
         gen[sl] = static_cast<uint16_t>(i);
+        bs[sl] = static_cast<uint16_t>(b | (pk & 0x8000u));   // (a bucket index is below 2^15: 1 024 x 17)
     }
     __syncthreads();
     // number of genes whose code is below cq (le: below or equal)
@@ -582,15 +588,19 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
         }
         return s0 + n;
     };
-    // ---- 4. pos, lo, hi of every gene
+    // ---- 4. pos, lo, hi, slot by slot: the lanes of a wave take CONSECUTIVE slots, i.e. members of the same or of neighbouring
+    // buckets, so their scans run equally long (in gene order a wave ran as long as the longest of 64 unrelated buckets: mean
+    // bucket 4.6 members, wave maximum 28) and their band edges land in neighbouring buckets.  The gene's value is gathered
+    // from the column (L2); the results go to a by-slot scratch row and are put in gene order through LDS afterwards.
     TSTAMP(5);
     bool tied = false;
 #pragma unroll 1
-    for (int i = t; i < G; i += 1024) {
-        const T x = col[i];
+    for (int sl = t; sl < G; sl += 1024) {   // (fetching the next slot's value one iteration ahead changed nothing: 102 against 103 us)
+        const uint32_t gene = gen[sl], bw = bs[sl], b = bw & 0x7FFFu, mr = rem[sl], me = static_cast<uint32_t>(sl);
+        const bool exact = (bw & 0x8000u) != 0;
+        const T x = col[gene];
         const uint64_t k = Codec<T>::enc(x);
-        const uint32_t b = lrow[i], mr = hrow[i], pk = prow[i], s0 = hist[at(b)], s1 = hist[at(b + 1)], me = s0 + (pk & 0x7FFFu);
-        const bool exact = (pk & 0x8000u) != 0;
+        const uint32_t s0 = hist[at(b)], s1 = hist[at(b + 1)];
         uint32_t l, h, p;
         if (b % PER == SUB) {  // one value: slot order
             l = s0; h = s1; p = me;
@@ -623,11 +633,28 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
             h = rank_of(band_edge_code<true>(x, k), true);
         }
         tied |= h - l > 1u;
-        prow[i] = static_cast<uint16_t>(p);
-        lrow[i] = static_cast<uint16_t>(l);
-        hrow[i] = static_cast<uint16_t>(h);
+        os[sl] = static_cast<uint64_t>(gene) | (static_cast<uint64_t>(p) << 16) | (static_cast<uint64_t>(l) << 32) | (static_cast<uint64_t>(h) << 48);
     }
-    for (int g = G + t; g < Gp; g += 1024) { prow[g] = 0; lrow[g] = 0; hrow[g] = 0; }  // padded genes are below no band edge
+    TSTAMP(7);
+    __syncthreads();   // every query is done: the LDS behind the splitters becomes pos16 / lo16 / hi16, indexed by gene
+    {   // two rows at a time (4 Gp bytes always fit behind the splitters), then the third
+        uint16_t *a16 = reinterpret_cast<uint16_t *>(hist), *b16 = a16 + Gp;
+        for (int g = G + t; g < Gp; g += 1024) { a16[g] = 0; b16[g] = 0; }  // padded genes are below no band edge
+        for (int sl = t; sl < G; sl += 1024) {
+            const uint64_t o = os[sl];
+            const uint32_t gene = static_cast<uint32_t>(o & 0xFFFFu);
+            a16[gene] = static_cast<uint16_t>(o >> 16); b16[gene] = static_cast<uint16_t>(o >> 32);
+        }
+        __syncthreads();
+        for (int q = t; q < Gp / 8; q += 1024) {
+            reinterpret_cast<uint4 *>(prow)[q] = reinterpret_cast<const uint4 *>(a16)[q];
+            reinterpret_cast<uint4 *>(lrow)[q] = reinterpret_cast<const uint4 *>(b16)[q];
+        }
+        __syncthreads();
+        for (int sl = t; sl < G; sl += 1024) { const uint64_t o = os[sl]; a16[o & 0xFFFFu] = static_cast<uint16_t>(o >> 48); }   // (the padded genes' zeros are still there)
+        __syncthreads();
+        for (int q = t; q < Gp / 8; q += 1024) reinterpret_cast<uint4 *>(hrow)[q] = reinterpret_cast<const uint4 *>(a16)[q];
+    }
     if (tied && *anytie == 0) atomicOr(anytie, 1);
     TSTAMP(6);
 }
@@ -751,8 +778,12 @@ int32_t launch_sample_wide(reo_ctx *c, const T *X, const int32_t *d_order, int32
     constexpr size_t NB = static_cast<size_t>(kSplit1) * ((1 << LOGSUB) + 1);
     const size_t lds = wide_lds_head(NB) + sizeof(uint16_t) * 2 * static_cast<size_t>(c->Gp);
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample_wide<T, LOGSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // by-slot scratch rows of every sample (the segmented path's buffers: it is not running)
+    int32_t rc;
+    const size_t n = static_cast<size_t>(c->S) * c->Gp;
+    if ((rc = c->t_kin.ensure(n)) || (rc = c->t_vin.ensure(n))) return rc;
     t_sample_wide<T, LOGSUB><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
-                                                                                    static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags);
+                                                                                    static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, c->t_kin.p, c->t_vin.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -892,8 +923,9 @@ int32_t transform_impl(reo_ctx *c)
             if (c->debug_stamps && wide) {  // diagnostic builds (-DREO_STAMPS): marks of workgroup 0 of t_sample_wide, 10 ns units
                 unsigned long long stv[8];
                 REO_HIP_CHECK(hipMemcpy(stv, d_flags.p + 8, sizeof stv, hipMemcpyDeviceToHost));
-                fprintf(stderr, "stamps t_sample_wide (max + flags, sample sort, histogram, prefix sums, scatter, ranks):");
-                for (int k = 1; k <= 6; ++k) fprintf(stderr, " %lld", (long long)(stv[k] - stv[k - 1]));
+                fprintf(stderr, "stamps t_sample_wide (max + flags, sample sort, histogram, prefix sums, scatter, ranks in slot order, into gene order + rows):");
+                for (int k = 1; k <= 5; ++k) fprintf(stderr, " %lld", (long long)(stv[k] - stv[k - 1]));
+                fprintf(stderr, " %lld %lld", (long long)(stv[7] - stv[5]), (long long)(stv[6] - stv[7]));
                 fprintf(stderr, "  (x 10 ns)\n");
             }
             if (!fl[4] && !fl[5]) {
