@@ -2354,7 +2354,6 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     __shared__ int s_n, s_nn, s_fb;
     __shared__ uint4 dbuf[kDeltaMax * 8];
     __shared__ double red[256];
-    __shared__ int wcnt[4][2];
     warm_kernargs<sizeof(IterArgs) + 16>();
     if (!TAIL) STAMP(a, 8);
     const int pb = (b - 1) & 1;
@@ -2594,7 +2593,14 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         inner = v > wa_hi && v < wb_lo;
     }
     if (!TAIL) STAMP(a, 5);
-    {
+    if (G <= 65535) {
+        // the moments of the values between the windows, per WAVE (wave sums only: no barrier; kl_rank combines 4 x as many
+        // partials, which its third wave holds sixteen to a lane anyway)
+        const double nb = static_cast<double>(__popcll(__ballot(inner))), sum = wave_sum(inner ? v : 0.0);
+        const double mean = nb > 0.0 ? sum / nb : 0.0;
+        const double m2 = wave_sum(inner ? (v - mean) * (v - mean) : 0.0);
+        if (lane == 0) { double *pp = a.part + 3 * (4 * blockIdx.x + wave); pp[0] = nb; pp[1] = mean; pp[2] = m2; }
+    } else {   // (above 65 535 genes four partials per workgroup would be more than kl_rank's third wave can hold: one per workgroup)
         double nb, sum;
         block_sum2_256(inner ? 1.0 : 0.0, inner ? v : 0.0, red, nb, sum);
         const double mean = nb > 0.0 ? sum / nb : 0.0;
@@ -2607,18 +2613,14 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     if (lane == 0) {
         if (mA) baseA = atomicAdd(&lc->cnt_a, __popcll(mA));
         if (mB) baseB = atomicAdd(&lc->cnt_b, __popcll(mB));
-        wcnt[wave][0] = __popcll(bA); wcnt[wave][1] = __popcll(bB);
+        // the counts below the windows, per wave (no workgroup sum, no barrier at the end of the launch: the adds stay in the XCD's L2)
+        if (bA) spread_add(lc->below_a, __popcll(bA), a.xcc_local);
+        if (bB) spread_add(lc->below_b, __popcll(bB), a.xcc_local);
     }
     baseA = __shfl(baseA, 0, 64); baseB = __shfl(baseB, 0, 64);
     const unsigned long long lt = (1ULL << lane) - 1ULL;
     if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) a.cand[at] = v; }
     if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) a.cand[kCandMax + at] = v; }
-    lds_barrier();
-    if (threadIdx.x == 0) {
-        const int ba = wcnt[0][0] + wcnt[1][0] + wcnt[2][0] + wcnt[3][0], bb = wcnt[0][1] + wcnt[1][1] + wcnt[2][1] + wcnt[3][1];
-        if (ba) spread_add(lc->below_a, ba, a.xcc_local);
-        if (bb) spread_add(lc->below_b, bb, a.xcc_local);
-    }
     if (!TAIL) STAMP(a, 7);
 }
 
@@ -2647,7 +2649,7 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
     for (int u = 0; u < kPartLane; ++u) {
         const int w = lane + 64 * u;
         pn[u] = pm[u] = pq[u] = 0.0;
-        if (wave == 2 && w < (G + 255) / 256) { pn[u] = a.part[3 * w]; pm[u] = a.part[3 * w + 1]; pq[u] = a.part[3 * w + 2]; }
+        if (wave == 2 && w < (G <= 65535 ? 4 : 1) * ((G + 255) / 256)) { pn[u] = a.part[3 * w]; pm[u] = a.part[3 * w + 1]; pq[u] = a.part[3 * w + 2]; }   // (kl_head: a partial per wave up to 65 535 genes, per workgroup above)
     }
     const double wd0 = a.scal[5], wd1 = a.scal[6], wd2 = a.scal[7], wd3 = a.scal[8];
     const double d1 = live ? a.result[11 * static_cast<size_t>(G) + i] : 0.0;
