@@ -160,6 +160,7 @@ int32_t reo_create_multi(reo_ctx **out, int32_t n_gpus, uint64_t seed)
         all[d]->rank = d; all[d]->world = n_gpus;
         all[d]->comm = comms[d];
         all[d]->multi_one_device = one_device;
+        all[d]->in_multi = true;
     }
     all[0]->peers.assign(all.begin() + 1, all.end());
     *out = all[0];

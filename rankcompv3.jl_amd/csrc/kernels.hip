@@ -3706,7 +3706,7 @@ int32_t launch_k1(reo_ctx *c, int k)
     // kernel only writes words of its own units: the three streams never meet in a word.  (Wave form for two groups only;
     // everything else exchanges behind the pair kernel, as in round 3.)
     const int maxu_x = std::max(1, (static_cast<int>(c->units_all_host.size()) + std::max(c->world, 1) - 1) / std::max(c->world, 1));
-    const int nwaves = (wave && c->world > 1 && (c->comm || c->ag) && !c->k1_stamps) ? std::min({c->x_waves, 8, maxu_x}) : 1;
+    const int nwaves = (wave && c->world > 1 && (c->comm || c->ag) && !c->in_multi && !c->k1_stamps) ? std::min({c->x_waves, 8, maxu_x}) : 1;   // (a reo_create_multi context hands its packs to the leader itself: comm.hip)
     if (nwaves > 1) {
         const int mw = (maxu_x + nwaves - 1) / nwaves;   // slots per wave: the same on every shard
         const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * (static_cast<size_t>(Q) * CJ / 32);

@@ -196,6 +196,7 @@ struct reo_ctx {
     int spin_wait = 0;                  // REO_SPIN_WAIT=1: poll the stream on the hot path instead of the blocking wait (api.hip, stream_wait; measured: 0.04 ms per step)
     int check_hook_table = 1;           // REO_CHECK_HOOK_TABLE=0: skip the consistency scan of a table delivered by a caller's hook (timing tools)
     bool comm_dead = false;             // the communicator was aborted after a failure: every later build answers REO_ECOMM
+    bool in_multi = false;              // this context is the leader or a peer of a reo_create_multi context (its exchange is multi_build_pairs', not launch_k1's)
     bool multi_one_device = false;      // reo_create_multi under REO_MULTI_ONE_DEVICE=1 (test seam: shards share one device, no RCCL)
     std::vector<reo_ctx *> peers;       // reo_create_multi: the contexts of devices 1.. owned by this (leader) context
     // one-vs-rest with > 2 groups: per-group pair counts shared by the comparisons (kernels.hip, k1_group_counts)
