@@ -332,6 +332,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (const char *e = getenv("REO_CHECK_HOOK_TABLE")) c->check_hook_table = (e[0] != '0');
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
     if (const char *e = getenv("REO_LIGHT_BAND")) c->light_band = std::max(0, atoi(e));
+    if (const char *e = getenv("REO_HIST_BELOW")) c->hist_below = std::max(0, atoi(e));
     if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : (e[0] == '3' ? 3 : 1));
     c->light_window = light_window(); c->light_min_g = light_min_genes();
     if (const char *e = getenv("REO_LIGHT_WINDOW")) c->light_window = std::max(1, std::min(31, atoi(e)));  // 2 W + 1 <= 64 window members

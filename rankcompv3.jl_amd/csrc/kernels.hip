@@ -1341,6 +1341,7 @@ struct IterArgs {
     int k2_idx;                  // index of this k2_tally launch (for the stage timers)
     int xcc_local;               // light passes: the histogram atomics may stay in the XCD's L2 (reo_create's self-test passed)
     int32_t *olist;              // one-launch light passes: [2][kOneStride] genes near the BH cut with their delta1, by workgroup
+    int hist_below;              // light passes, two-launch form: see hist_first
     int32_t *clist; int band;    // light passes: genes near the BH cut listed by kl_rank ([2][kListStride]); half width of "near" in ranks
     int window, light_min_g;     // light passes: ranks on either side of a quantile that its window is made to hold; smallest G that uses them
     unsigned long long *stamps;  // diagnostic builds (-DREO_STAMPS): s_memrealtime marks of workgroup 0, else unused
@@ -2184,32 +2185,41 @@ __device__ __forceinline__ bool slice_std(const IterArgs &a, const double *cand,
 // cannot qualify (H never exceeds the number of finite ranks), so no masking is needed.
 // tile0, carry: the four tiles are tiles tile0 .. tile0 + 3 of the histogram and `carry` ranks lie in the tiles before them
 // (updated to include these four); a trailing barrier lets the call be repeated.
-__device__ __forceinline__ int bh_cut4(const int (&hv)[4][8], int G, int tile0, int &carry_io)
+// The two-launch light passes keep their histogram RELATIVE to the last cut: bin 0 is rank hist_first(kstar) + 1, and the genes
+// whose rank is not above hist_first are only counted (LightCnt::nlow).  The cut moves by a handful of ranks per pass, so the
+// bins that matter -- from a little below the last cut to the number of finite ranks -- fit ONE tile of 2 048 bins: kl_head
+// asks for 64 KB of partial histograms at its start instead of 128, and its scan has a quarter of the work.  A cut that has
+// dropped below hist_first cannot be found this way: the pass then goes to the sorting path (like a lost quantile window).
+// below: ranks under the last cut that still get bins (IterArgs::hist_below; 256 unless a test asks for less)
+__device__ __forceinline__ int hist_first(int kstar, int below) { return kstar > below ? kstar - below : 0; }
+
+template <int NT = 4>   // NT: the tiles of hv that are in use
+__device__ __forceinline__ int bh_cut4(const int (&hv)[4][8], int G, int tile0, int &carry_io, int roff = 0)
 {
     __shared__ __attribute__((aligned(16))) int wsum[4][4];
     __shared__ int wbest[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int s[4], inc[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NT; ++e) {
         s[e] = ((hv[e][0] + hv[e][1]) + (hv[e][2] + hv[e][3])) + ((hv[e][4] + hv[e][5]) + (hv[e][6] + hv[e][7]));
         inc[e] = s[e];
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < NT; ++e)
         { const int u = __shfl_up(inc[e], o, 64); if (lane >= o) inc[e] += u; }
     if (lane == 63)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wsum[e][wave] = inc[e];
+        for (int e = 0; e < NT; ++e) wsum[e][wave] = inc[e];
     lds_barrier();
     int best = 0, carry = carry_io;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NT; ++e) {
         const int4 ws = *reinterpret_cast<const int4 *>(wsum[e]);
         int run = carry + inc[e] - s[e] + (wave > 0 ? ws.x : 0) + (wave > 1 ? ws.y : 0) + (wave > 2 ? ws.z : 0);
-        const int r0 = ((tile0 + e) * 256 + threadIdx.x) * 8 + 1;
+        const int r0 = roff + ((tile0 + e) * 256 + threadIdx.x) * 8 + 1;   // rank of the first of this thread's eight bins
 #pragma unroll
         for (int u = 0; u < 8; ++u) { run += hv[e][u]; if (r0 + u <= G && run >= r0 + u) best = max(best, r0 + u); }
         carry += ws.x + ws.y + ws.z + ws.w;
@@ -2360,9 +2370,9 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     // ---- everything whose address does not depend on loaded data is requested first: the launch is a chain of
     // dependent round trips otherwise (measured: 22 us with the loads where they are used, most of it waiting)
     LightRec r;
-    int bfail = 0, sig = 0;
+    int bfail = 0, sig = 0, nlow = 0;
     int hv[4][8];
-    int4 hx[kHistParts][2][2];
+    int4 hx[kHistParts][2];
     int4 mv[kHeadPre];
     int2 le[kListPre];
     int lcnt[kListPre];
@@ -2371,20 +2381,19 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     double win[4];
     const int nrow = (G + 255) >> 8;
     if (b > 0) {
-        // the histogram of the BH ranks is kept as one partial histogram per XCD (kl_rank); the first two tiles of each
-        // (4096 bins: enough unless more genes than that have a finite rank) are requested now and summed below
+        // the histogram of the BH ranks is kept as one partial histogram per XCD (kl_rank), relative to the last cut
+        // (hist_first); the first tile of each (2 048 bins: enough unless the cut has more than 1 792 finite ranks above
+        // it) is requested now and summed below
         const int32_t *hist = a.hist + static_cast<size_t>(pb) * kHistParts * a.hist_stride;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int u = 0; u < 8; ++u) hv[e][u] = 0;
 #pragma unroll
-        for (int x = 0; x < kHistParts; ++x)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + (e * 256 + threadIdx.x) * 8);
-                hx[x][e][0] = hp[0]; hx[x][e][1] = hp[1];
-            }
+        for (int x = 0; x < kHistParts; ++x) {   // (the first tile of every partial: the histogram is relative to the last cut, see hist_first)
+            const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + threadIdx.x * 8);
+            hx[x][0] = hp[0]; hx[x][1] = hp[1];
+        }
 #pragma unroll
         for (int q = 0; q < kHeadPre; ++q) {
             const int R = wave + 4 * q;
@@ -2410,7 +2419,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         const LightSlot *ps = &ls->slot[b - 1];
         r = ps->rec; bfail = ps->bfail;
 #pragma unroll
-        for (int q = 0; q < kSpread; ++q) sig += ps->lc.sig[q][0];
+        for (int q = 0; q < kSpread; ++q) { sig += ps->lc.sig[q][0]; nlow += ps->lc.nlow[q][0]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) win[q] = ps->wnext[q];
     } else {
@@ -2437,31 +2446,30 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     } else if (r.active) {
         // ---- the mask step of pass r.t (:413-424)
         const int t = r.t, cur = t & 1, nxt = cur ^ 1;
+        const int off = hist_first(r.kstar, a.hist_below), srel = sig - off;   // bins are ranks off + 1 ..; finite ranks above off: at most srel
         {
             const int32_t *hist = a.hist + static_cast<size_t>(pb) * kHistParts * a.hist_stride;
 #pragma unroll
-            for (int x = 0; x < kHistParts; ++x)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    hv[e][0] += hx[x][e][0].x; hv[e][1] += hx[x][e][0].y; hv[e][2] += hx[x][e][0].z; hv[e][3] += hx[x][e][0].w;
-                    hv[e][4] += hx[x][e][1].x; hv[e][5] += hx[x][e][1].y; hv[e][6] += hx[x][e][1].z; hv[e][7] += hx[x][e][1].w;
-                }
-            if (sig > 4096) {  // (workgroup-uniform) the other two tiles, now
+            for (int x = 0; x < kHistParts; ++x) {
+                hv[0][0] += hx[x][0].x; hv[0][1] += hx[x][0].y; hv[0][2] += hx[x][0].z; hv[0][3] += hx[x][0].w;
+                hv[0][4] += hx[x][1].x; hv[0][5] += hx[x][1].y; hv[0][6] += hx[x][1].z; hv[0][7] += hx[x][1].w;
+            }
+            if (srel > 2048) {  // (workgroup-uniform; not at config 3) the other three tiles of the first four, now
 #pragma unroll 1
                 for (int x = 0; x < kHistParts; ++x)
 #pragma unroll
-                    for (int e = 2; e < 4; ++e) {
+                    for (int e = 1; e < 4; ++e) {
                         const int4 *hp = reinterpret_cast<const int4 *>(hist + static_cast<size_t>(x) * a.hist_stride + (e * 256 + threadIdx.x) * 8);
                         const int4 h0 = hp[0], h1 = hp[1];
                         hv[e][0] += h0.x; hv[e][1] += h0.y; hv[e][2] += h0.z; hv[e][3] += h0.w; hv[e][4] += h1.x; hv[e][5] += h1.y; hv[e][6] += h1.z; hv[e][7] += h1.w;
                     }
             }
         }
-        int carry = 0;
-        int kstar = bh_cut4(hv, G, 0, carry);
-        if (sig > 8192) {  // (workgroup-uniform; rare: more than 8192 genes inside or near the cut) the tiles after the first four, four at a time
+        int carry = nlow;   // the genes whose rank is not above `off`
+        int kstar = srel > 2048 ? bh_cut4(hv, G, 0, carry, off) : bh_cut4<1>(hv, G, 0, carry, off);   // (workgroup-uniform)
+        if (srel > 8192) {  // (workgroup-uniform; rare: more than 8192 genes inside or near the cut) the tiles after the first four, four at a time
             const int32_t *hist = a.hist + static_cast<size_t>(pb) * kHistParts * a.hist_stride;
-            const int ntile = (min(G, sig) + 2047) / 2048;
+            const int ntile = (min(G - off, srel) + 2047) / 2048;
 #pragma unroll 1
             for (int tile0 = 4; tile0 < ntile; tile0 += 4) {
 #pragma unroll
@@ -2477,10 +2485,14 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
                         const int4 h0 = hp[0], h1 = hp[1];
                         hv[e][0] += h0.x; hv[e][1] += h0.y; hv[e][2] += h0.z; hv[e][3] += h0.w; hv[e][4] += h1.x; hv[e][5] += h1.y; hv[e][6] += h1.z; hv[e][7] += h1.w;
                     }
-                kstar = max(kstar, bh_cut4(hv, G, tile0, carry));
+                kstar = max(kstar, bh_cut4(hv, G, tile0, carry, off));
             }
         }
+        const bool cut_lost = off > 0 && kstar == 0;   // (the same in every workgroup) the cut dropped below the histogram's first bin
         if (!TAIL) STAMP(a, 1);
+        if (cut_lost) {
+            r.active = 0; r.need_full = 1;  // the sorting path finds the cut of pass r.t (its tallies are in place)
+        } else {
         if (threadIdx.x == 0) { s_n = 0; s_nn = 0; s_fb = 0; }
         lds_barrier();
         if (LIST) {
@@ -2539,6 +2551,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         inref = ind;
         n = min(chg, kDeltaMax);
         stepped = true;
+        }
     }
     if (TAIL) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2682,18 +2695,22 @@ __global__ __launch_bounds__(256) void kl_rank(IterArgs a, LightState *ls, int b
         // one partial histogram per XCD, updated with atomics that need not be coherent beyond the XCD's own L2 (only
         // workgroups running on this XCD touch this partial): an atomic that has to be coherent across the XCDs is
         // performed at the memory side, and 3 500 of those kept the launch alive for 4.5 us
-        const unsigned long long first = __ballot(m == 1), finite = __ballot(m <= G);
-        const bool lead1 = m == 1 && lane == __ffsll(static_cast<long long>(first)) - 1;  // the hot bin: one add per wave
+        // the bins are relative to the last cut (hist_first): ranks up to `off` are only counted
+        const int off = hist_first(rec_kstar, a.hist_below);
+        const unsigned long long first = __ballot(m == 1 && off == 0), finite = __ballot(m <= G), low = __ballot(m <= off);
+        const bool lead1 = m == 1 && off == 0 && lane == __ffsll(static_cast<long long>(first)) - 1;  // the hot bin: one add per wave
+        const bool binned = m > off && m <= G && !(m == 1 && off == 0);
         if (a.xcc_local) {
             int32_t *hist = a.hist + (static_cast<size_t>(pbuf) * kHistParts + xcc_id()) * a.hist_stride;
             if (lead1) __hip_atomic_fetch_add(&hist[0], __popcll(first), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else if (m >= 2 && m <= G) __hip_atomic_fetch_add(&hist[m - 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (binned) __hip_atomic_fetch_add(&hist[m - 1 - off], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {  // (self-test failed or switched off: device-coherent atomics into partial 0)
             int32_t *hist = a.hist + static_cast<size_t>(pbuf) * kHistParts * a.hist_stride;
             if (lead1) atomicAdd(&hist[0], __popcll(first));
-            else if (m >= 2 && m <= G) atomicAdd(&hist[m - 1], 1);
+            else if (binned) atomicAdd(&hist[m - 1 - off], 1);
         }
         if (lane == 0 && finite) spread_add(lc->sig, __popcll(finite), a.xcc_local);
+        if (lane == 0 && low) spread_add(lc->nlow, __popcll(low), a.xcc_local);
     }
     {   // every slot of the row is written (the mask step reads whole rows), transposed through LDS so that each wave
         // stores whole cache lines: rows written as scattered 4-byte pieces came back slowly in the next launch
@@ -3983,7 +4000,7 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     a.trace = c->trace.p; a.modes = nullptr;
     a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / (3 * kHistParts)); a.mrank = c->mrank.p;
     a.replay = replay; a.k2_idx = 0;
-    a.clist = c->clist.p; a.olist = c->olist.p; a.band = c->light_band; a.xcc_local = c->xcc_local;
+    a.clist = c->clist.p; a.olist = c->olist.p; a.band = c->light_band; a.hist_below = c->hist_below; a.xcc_local = c->xcc_local;
     // (no light passes -- switched off, or given up by the running call: the sorting path then leaves need_full set, else its
     //  launches would wait for light passes that nobody enqueues)
     a.window = c->light_window; a.light_min_g = (c->it_no_light || c->light_mode == 0) ? 0x7FFFFFFF : c->light_min_g;

@@ -80,6 +80,7 @@ struct LightCnt {
     int32_t below_b[kSpread][32];
     int32_t sig[kSpread][32];        // genes with a finite BH rank
     int32_t nsure[kSpread][32];      // one-launch form: genes outside the lists whose BH rank is surely within the cut's band
+    int32_t nlow[kSpread][32];       // two-launch form: genes whose BH rank lies below the histogram's first bin (kernels.hip, hist_first)
 };
 // everything the launches after pass b of a batch need of it: rec = the state in FRONT of pass b; the rest is made by
 // pass b itself.  Zeroed by the host in front of the batch.
@@ -247,6 +248,7 @@ struct reo_ctx {
     reo::DevBuf<reo::LightState> lstate;  // [1] batch log of the two-launch light passes
     reo::DevBuf<int32_t> clist;         // [2][256 + 256 * kListCap * 2] genes near the BH cut, by workgroup (kernels.hip, kl_rank)
     int light_band = 32;                // REO_LIGHT_BAND (tests)
+    int hist_below = 256;               // REO_HIST_BELOW (tests): ranks under the last cut that keep a histogram bin (kernels.hip, hist_first)
     int xcc_local = 0;                  // the per-XCD histogram atomics may stay in the XCD's L2 (checked once per context: kernels.hip, xcc_selftest)
     int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
     int light_mode = 1;                 // 0 sorting passes only, 1 light passes as two launches each (the default), 2 as one persistent launch,

@@ -1348,21 +1348,26 @@ def test_workgroup_form_of_the_pair_kernel_still_matches(pkg, oracle, monkeypatc
     assert np.array_equal(codes[0], oracle.build_codes(X.astype(np.float64), gid, 2, 0, thr, seed))
 
 
-@pytest.mark.parametrize("window,light,band,xcc", [("3", "3", "32", "1"), ("1", "3", "32", "1"), ("12", "3", "2", "1"), ("12", "3", "0", "0"), ("3", "3", "32", "0"),
-                                                   ("3", "1", "32", "1"), ("1", "1", "32", "1"), ("12", "1", "2", "1"), ("12", "1", "0", "0"),
-                                                   ("3", "1", "32", "0"), ("3", "2", "32", "1"), ("1", "2", "32", "1")])
-def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monkeypatch, window, light, band, xcc):
+@pytest.mark.parametrize("window,light,band,xcc,below", [
+    ("3", "3", "32", "1", "256"), ("1", "3", "32", "1", "256"), ("12", "3", "2", "1", "256"), ("12", "3", "0", "0", "256"), ("3", "3", "32", "0", "256"),
+    ("3", "1", "32", "1", "256"), ("1", "1", "32", "1", "256"), ("12", "1", "2", "1", "256"), ("12", "1", "0", "0", "256"),
+    ("3", "1", "32", "0", "256"), ("3", "2", "32", "1", "256"), ("1", "2", "32", "1", "256"),
+    ("12", "1", "32", "1", "0"), ("12", "1", "2", "0", "3"), ("3", "1", "32", "1", "12")])
+def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monkeypatch, window, light, band, xcc, below):
     """The light iteration passes (quantile windows + BH cut from the histogram of step-up ranks) on many small random
     problems: REO_LIGHT_MIN_G lets small gene counts use them, and a window of 1-3 ranks makes windows lose their order
     statistic now and then, so the fall-back to the sorting path and the hand-over of the tally state between the two
     kinds of pass are exercised too.  More passes than usual (n_conv = 0 forces them); different padj / pval cut-offs;
     tie-heavy data puts many equal delta1 values around the quantiles.  light = 1: two launches per pass (the default), 3: one
-    launch per pass (round 4: bracketed p-values, the cut from the listed genes' exact ranks), 2: the persistent form."""
+    launch per pass (round 4: bracketed p-values, the cut from the listed genes' exact ranks), 2: the persistent form.
+    below: the two-launch form keeps its rank histogram relative to the last cut, with this many ranks under it (256 in
+    production); 0, 3 and 12 make cuts drop out of the histogram, which must send the pass to the sorting path."""
     monkeypatch.setenv("REO_LIGHT_MIN_G", "64")
     monkeypatch.setenv("REO_LIGHT_WINDOW", window)
     monkeypatch.setenv("REO_LIGHT", light)
     monkeypatch.setenv("REO_XCC_LOCAL", xcc)   # 1: rank histogram per XCD with atomics that stay in its L2 (if the self-test passes); 0: device-coherent atomics
     monkeypatch.setenv("REO_LIGHT_BAND", band)  # half width of the list of genes near the BH cut: 0 and 2 make the cut leave it
+    monkeypatch.setenv("REO_HIST_BELOW", below)
     rng = np.random.default_rng(4242 + int(window) * 7 + int(light))
     light_batches = 0
     for case_no in range(14):
@@ -1376,7 +1381,7 @@ def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monke
         ref0 = pkg.synth.ref_mask(G, max(3, G // 3), cs["seed"])
         n_iter, n_conv = int(rng.integers(6, 14)), int(rng.choice([0, 0, 1]))
         pval_deg, padj_deg = float(rng.choice([1.0, 1.0, 0.2])), float(rng.choice([0.05, 0.3, 0.9]))
-        tag = (window, light, band, xcc, case_no, cs["kind"], G, cs["S"], cs["ng"], n_iter, n_conv, pval_deg, padj_deg)
+        tag = (window, light, band, xcc, below, case_no, cs["kind"], G, cs["S"], cs["ng"], n_iter, n_conv, pval_deg, padj_deg)
         run = pkg.run_identify_degs(X, labels, list(range(G)), cs["pval_reo"], pval_deg, padj_deg, ref0, n_iter, n_conv,
                                     seed=cs["seed"], device=0, profile=True)
         Xf = np.asarray(X, dtype=np.float64)
@@ -1405,13 +1410,14 @@ def test_sorting_passes_only_and_large_cuts_at_a_size_that_uses_light_passes(pkg
     group = pkg.synth.groups(S)
     ref0 = pkg.synth.ref_mask(G, 3000, seed)
     out = {}
-    for mode in ("3", "1", "0"):
-        monkeypatch.setenv("REO_LIGHT", mode)
+    for mode in ("3", "1", "1/2", "0"):   # "1/2": the two-launch form with two ranks of histogram under the last cut (cuts drop out of it)
+        monkeypatch.setenv("REO_LIGHT", mode[0])
+        monkeypatch.setenv("REO_HIST_BELOW", mode[2:] or "256")
         with pkg.Context(device=0, seed=seed) as ctx:
             gid, lev = pkg.encode_groups(group)
             ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01); ctx.build_pairs(0)
             out[mode] = [ctx.identify_degs(ref0, 1.0, padj, 16, 0) for padj in (0.05, 0.9)]
-    for mode in ("3", "1"):
+    for mode in ("3", "1", "1/2"):
         for (r1, i1, t1), (r0, i0, t0) in zip(out[mode], out["0"]):
             assert i1 == i0 == 16 and t1 == t0, mode
             assert np.array_equal(r1[:, 2:11], r0[:, 2:11]), mode
