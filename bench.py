@@ -78,6 +78,7 @@ def main() -> None:
     ap.add_argument("--no-tie-rich", action="store_true")
     ap.add_argument("--no-float64", action="store_true", help="skip the Float64-input block")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE config 4 block (30 000 x 4 000)")
+    ap.add_argument("--no-cycle-watch", action="store_true", help="skip the blocks that time the library's default (cycle watch on)")
     ap.add_argument("--cpu-genes", type=int, default=8000)
     ap.add_argument("--debug-gloo-one-gpu", action="store_true",
                     help="debug only: every rank uses cuda:0 and the table exchange goes through gloo via the host")
@@ -152,7 +153,10 @@ def main() -> None:
                     ctx.comm_init_rank(box[0], rank, world)
         return ctx
 
-    def run_family(family: str, steps: int, warmup: int, n_conv_list, G=G, S=S, seed=seed, gid=gid, ref0=ref0):
+    def run_family(family: str, steps: int, warmup: int, n_conv_list, G=G, S=S, seed=seed, gid=gid, ref0=ref0, cycle="0"):
+        # cycle="0": every pass of the loop is executed (REO_CYCLE=0: the headline and every block that earlier rounds reported);
+        # "1": the library's default -- a reference set that returns lets the call skip whole periods (block "cycle_watch")
+        os.environ["REO_CYCLE"] = cycle   # (read by reo_create)
         gen = {"t0": pkg.synth.t0_ranks, "t1": pkg.synth.t1_counts, "float": pkg.synth.float_expr}[family]
         X = gen(G, S, seed)                                   # Int64, like Matrix(df_expr) of count data (Float64: log-like expression)
         Xd = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)  # (S, G) row-major == G x S column-major, ld = G
@@ -236,7 +240,8 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": f"BASELINE config 3: synthetic {G} genes x {S} samples ({args.family.upper()} family, Int64 input), "
                                f"2 groups, ref_gene_max=3000, n_iter={args.n_iter}, n_conv=0 (exactly {iters} iterations)",
-                   "genes": G, "samples": S, "iterations": iters, "sharding": f"pair tiles over {world} GPU(s)"},
+                   "genes": G, "samples": S, "iterations": iters, "sharding": f"pair tiles over {world} GPU(s)",
+                   "cycle_watch": "off for this line (REO_CYCLE=0): all %d passes are executed; the library's default is in the block cycle_watch" % iters},
         "converged": {"value": units * args.steps / dtc, "ms_per_step": dtc / args.steps * 1e3,
                       "n_conv": 5, "iterations": iters_c, "final_trace": list(trace_c[-1]) if trace_c else None},
         "stages_ms_per_step": {k: tm[k] / args.steps for k in ("transform_ms", "k1_ms", "k2_full_ms", "iter_ms", "exchange_ms")},
@@ -258,6 +263,18 @@ def main() -> None:
         out["collective"] = ("one ncclAllGather per reo_build_pairs, in-library RCCL: every rank sends the forward words of its own pair "
                              "tiles (about %d MB over all ranks; the whole table is %d MB), mirror words are derived on arrival; "
                              "exchange_ms_per_build = pack + collective + unpack") % (G * info["Gp"] // 4 // 1000000, G * info["Gp"] // 2 // 1000000)
+
+    if not args.no_cycle_watch:
+        # the library as it ships: the forced loop ends in a cycle of reference sets (period 4 here), the light passes find it and the
+        # call skips whole periods -- the same iters_run, trace and result (compared below), fewer executed passes
+        stc = max(3, args.steps // 2)
+        _, (fc,), infoc = run_family(args.family, stc, 1, [0], cycle="1")
+        dtw, itw, trw, tmw, resw = fc
+        out["cycle_watch"] = {"workload": "the headline workload with the cycle watch on (the default)", "ms_per_step": dtw / stc * 1e3, "value": units * stc / dtw,
+                              "steps": stc, "iterations_reported": itw, "period": infoc["cycle_period"], "found_in_front_of_pass": infoc["cycle_found_at_pass"],
+                              "passes_skipped": infoc["cycle_passes_skipped"], "iter_ms": tmw["iter_ms"] / stc,
+                              "same_trace_as_all_passes_executed": bool(trw == trace and itw == iters),
+                              "same_result_as_all_passes_executed": bool(np.array_equal(resw, res, equal_nan=True))}
 
     if not args.no_tie_rich and args.family == "t0":
         st = max(3, args.steps // 4)
@@ -313,6 +330,12 @@ def main() -> None:
                           "stages_ms_per_step": {k: tm4[k] / st4 for k in ("transform_ms", "k1_ms", "k2_full_ms", "iter_ms", "exchange_ms")},
                           "roofline": r4, "final_trace": list(tr4[-1]) if tr4 else None,
                           "thresholds": [pkg._ffi.threshold(S4 // 2), pkg._ffi.threshold(S4 - S4 // 2)]}
+        if not args.no_cycle_watch:
+            _, (w4,), infow4 = run_family("t0", st4, 1, [0], G=G4, S=S4, seed=seed4, gid=gid4, ref0=ref4, cycle="1")
+            dtw4, itw4, trw4, tmw4, _ = w4
+            out["config4"]["cycle_watch"] = {"ms_per_step": dtw4 / st4 * 1e3, "value": units4 * st4 / dtw4, "iter_ms": tmw4["iter_ms"] / st4,
+                                             "period": infow4["cycle_period"], "found_in_front_of_pass": infow4["cycle_found_at_pass"],
+                                             "passes_skipped": infow4["cycle_passes_skipped"], "same_trace_as_all_passes_executed": bool(trw4 == tr4 and itw4 == it4)}
         pr4 = per_rank(tm4, info4, st4)
         if pr4:
             out["config4"]["ranks"] = pr4

@@ -178,7 +178,11 @@ int32_t reo_tally(reo_ctx *ctx, const uint8_t *ref_mask, int32_t *cont);
  * iters_run = number of executed passes of the while loop (:400); trace is
  * n_iter x 2 int32, (#DEG, #non-DEG) per pass (the :418 log line); either may
  * be NULL.  REO_EINVAL when the reference would throw (G < 10: the slice of
- * :411 is out of bounds). */
+ * :411 is out of bounds).
+ * A loop that does not converge repeats itself sooner or later: a pass depends on its reference set alone, so once the set in
+ * front of a pass equals an earlier one (checked exactly, bit for bit) the remaining passes are the last period over and over.
+ * The call then skips whole periods and executes only the remainder -- iters_run, trace and result are what n_iter executed
+ * passes give (reo_get_info 16-18 says what happened; REO_CYCLE=0 in the environment executes every pass). */
 int32_t reo_identify_degs(reo_ctx *ctx, const uint8_t *ref0, double pval_deg, double padj_deg,
                           int32_t n_iter, int32_t n_conv, double *result,
                           int32_t *iters_run, int32_t *trace);
@@ -231,7 +235,9 @@ int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);
  * every group once and keep the counts in HBM; REO_SHARE_GROUP_COUNTS=0 in the
  * environment recounts per comparison), 13 bytes held by those counts, 14 the last transform ranked every sample
  * inside one workgroup, 15 the iteration passes keep their rank histogram per XCD (the self-test of reo_create passed;
- * REO_XCC_LOCAL=0 switches it off). */
+ * REO_XCC_LOCAL=0 switches it off), 16-18 the last reo_identify_degs: the period p of the cycle its iteration was found in
+ * (0: none found), the pass in front of which the reference set equalled that of p passes earlier, and the passes that
+ * were then skipped instead of executed (see reo_identify_degs; REO_CYCLE=0 switches the watch off). */
 int32_t reo_get_info(reo_ctx *ctx, int64_t *info, int32_t n);
 
 #ifdef __cplusplus

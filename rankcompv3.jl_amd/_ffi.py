@@ -358,9 +358,10 @@ class Context:
                 "k2_full_launches": int(ms[9]), "k2_delta_ms": ms[10]}
 
     def info(self) -> dict:
-        v = np.zeros(16, dtype=np.int64)
-        check(self._L.reo_get_info(self._h, _ptr(v), 16))
+        v = np.zeros(19, dtype=np.int64)
+        check(self._L.reo_get_info(self._h, _ptr(v), 19))
         return {"G": int(v[0]), "S": int(v[1]), "Gp": int(v[2]), "table_bytes": int(v[3]), "has_ties": int(v[4]),
                 "tiles_owned": int(v[5]), "tiles_total": int(v[6]), "tile_i": int(v[7]), "chunk_j": int(v[8]),
                 "chunks_per_panel": int(v[9]), "unit_h": int(v[10]), "sample_slots": int(v[11]),
-                "shared_group_counts": int(v[12]), "group_count_bytes": int(v[13]), "transform_in_lds": int(v[14]), "xcc_local_histograms": int(v[15])}
+                "shared_group_counts": int(v[12]), "group_count_bytes": int(v[13]), "transform_in_lds": int(v[14]), "xcc_local_histograms": int(v[15]),
+                "cycle_period": int(v[16]), "cycle_found_at_pass": int(v[17]), "cycle_passes_skipped": int(v[18])}

@@ -333,6 +333,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (const char *e = getenv("REO_SHARE_GROUP_COUNTS")) c->share_counts = (e[0] != '0');
     if (const char *e = getenv("REO_LIGHT_BAND")) c->light_band = std::max(0, atoi(e));
     if (const char *e = getenv("REO_HIST_BELOW")) c->hist_below = std::max(0, atoi(e));
+    if (const char *e = getenv("REO_CYCLE")) c->cycle_watch = atoi(e) != 0;
     if (const char *e = getenv("REO_LIGHT")) c->light_mode = e[0] == '0' ? 0 : (e[0] == '2' ? 2 : (e[0] == '3' ? 3 : 1));
     c->light_window = light_window(); c->light_min_g = light_min_genes();
     if (const char *e = getenv("REO_LIGHT_WINDOW")) c->light_window = std::max(1, std::min(31, atoi(e)));  // 2 W + 1 <= 64 window members
@@ -687,8 +688,17 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         st.need_full = 1;
         st.raw_pass = -1;
         st.kstar = -1;
+        st.cyc_period = -1;  // (set to "watching" below, once the form of the light passes is known)
         *c->host_state = st;
     }
+    // cycle watch (kernels.hip, kl_head): the two-launch light passes notice when the reference set of a pass equals that of an
+    // earlier pass; the loop below then skips whole periods.  Off: REO_CYCLE=0, the other forms of light pass, sorting passes only.
+    const bool watch = c->cycle_watch && c->light_mode != 0 && (c->light_mode == 1 || G > 65535) && G >= c->light_min_g && n_iter > 0;
+    if (watch) {
+        if ((rc = c->snap.ensure(2 * static_cast<size_t>(c->Gp)))) return rc;
+        c->host_state->cyc_period = 0;
+    }
+    c->it_cycle_period = 0; c->it_cycle_at = 0; c->it_cycle_skipped = 0;
     if ((rc = launch_iter_init(c, c->host_ref, c->host_state))) return rc;
     c->it_pval_deg = pval_deg; c->it_padj_deg = padj_deg; c->it_n_iter = n_iter; c->it_n_conv = n_conv;
     c->it_a0 = static_cast<int>(a - 1); c->it_b0 = static_cast<int>(b - 1);
@@ -761,6 +771,21 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         passes = c->host_state->passes;
         seen_need_full = c->host_state->need_full;
         if (c->host_state->done || passes >= n_iter) break;  // :419-422
+        if (c->host_state->cyc_period > 0) {
+            // The reference set in front of pass `passes` equals the one p passes earlier, and a pass is a function of its reference
+            // set alone (:401-424: the table is fixed, the convergence test compares consecutive sets): from here on the loop repeats
+            // its last p passes for ever -- it has not converged within them, so it never will.  Whole periods are therefore skipped:
+            // the pass counter moves on, the trace of the skipped passes is the last period's, and the passes that remain run as usual.
+            // (An even number of passes: mask, delta list and tally state are double-buffered by the parity of the pass index.  At
+            //  least one pass is left to execute: the batch stopped with the tallies of pass `passes` already made, and the replay
+            //  below wants the loop to end the way it always does, with the tallies of the LAST executed pass in place.)
+            const int p = c->host_state->cyc_period, P = (p & 1) ? 2 * p : p;
+            const int skip = (n_iter - passes - 1) / P * P;
+            if ((rc = launch_cycle_skip(c, skip, p))) return rc;   // (also ends the watch)
+            c->it_cycle_period = p; c->it_cycle_at = passes; c->it_cycle_skipped = skip;
+            if (c->debug_passes) fprintf(stderr, "cycle: the reference set in front of pass %d equals that of pass %d; %d passes skipped\n", passes, passes - p, skip);
+            passes += skip;
+        }
     }
     if (passes > 0 && !c->host_state->last_full) {
         // the loop ended on a light pass: delta2, se, z1, the tallies and padj of that pass come from the sorting path
@@ -847,11 +872,12 @@ int32_t reo_get_timings(reo_ctx *c, double *ms, int32_t n)
 int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
 {
     if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
-    const int64_t v[16] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
+    const int64_t v[19] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
                            c->tiles_owned, c->tiles_total, kTileI, c->k1_cj, c->k1_q, kUnitH,
                            c->goff32.empty() ? 0 : c->goff32.back(), c->last_k1_shared,
-                           static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t)), c->transform_in_lds, c->xcc_local};
-    for (int i = 0; i < n && i < 16; ++i) info[i] = v[i];
+                           static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t)), c->transform_in_lds, c->xcc_local,
+                           c->it_cycle_period, c->it_cycle_at, c->it_cycle_skipped};
+    for (int i = 0; i < n && i < 19; ++i) info[i] = v[i];
     return REO_OK;
 }
 

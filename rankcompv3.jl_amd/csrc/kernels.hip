@@ -1342,6 +1342,7 @@ struct IterArgs {
     int xcc_local;               // light passes: the histogram atomics may stay in the XCD's L2 (reo_create's self-test passed)
     int32_t *olist;              // one-launch light passes: [2][kOneStride] genes near the BH cut with their delta1, by workgroup
     int hist_below;              // light passes, two-launch form: see hist_first
+    uint8_t *snap;               // [2][Gp] light passes, two-launch form: mask snapshots of the cycle watch (kl_head)
     int32_t *clist; int band;    // light passes: genes near the BH cut listed by kl_rank ([2][kListStride]); half width of "near" in ranks
     int window, light_min_g;     // light passes: ranks on either side of a quantile that its window is made to hold; smallest G that uses them
     unsigned long long *stamps;  // diagnostic builds (-DREO_STAMPS): s_memrealtime marks of workgroup 0, else unused
@@ -1865,6 +1866,7 @@ __device__ __forceinline__ int publish_mask(const IterArgs &a, int t, int i, boo
     a.trace[2 * t] = a.G - nn;
     a.trace[2 * t + 1] = nn;
     st->passes = t + 1;
+    st->cyc_pow = 0;  // (cycle watch of the light passes: this mask step is not in its books -- the next light pass starts a new snapshot)
     st->nref_prev = st->nref;
     const int diff = st->nref - nn;
     if ((diff < 0 ? -diff : diff) < a.n_conv) {
@@ -2370,7 +2372,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     // ---- everything whose address does not depend on loaded data is requested first: the launch is a chain of
     // dependent round trips otherwise (measured: 22 us with the loads where they are used, most of it waiting)
     LightRec r;
-    int bfail = 0, sig = 0, nlow = 0;
+    int bfail = 0, sig = 0, nlow = 0, cdiff = 0, cfound = 0;
     int hv[4][8];
     int4 hx[kHistParts][2];
     int4 mv[kHeadPre];
@@ -2379,6 +2381,10 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     int own_m = 0;
     int4 r0 = make_int4(0, 0, 0, 0), r1 = make_int4(0, 0, 0, 0);
     double win[4];
+    uint32_t cyc_w[kDeltaMax / 64];   // cycle watch (workgroup 0, wave 0): changed genes and their snapshot bytes
+    uint8_t cyc_s[kDeltaMax / 64];
+    int cyc_open = 0;                 // > 0: a comparison with the snapshot is under way, the period it would prove; -1: it cannot be made
+    bool cyc_renew = false;
     const int nrow = (G + 255) >> 8;
     if (b > 0) {
         // the histogram of the BH ranks is kept as one partial histogram per XCD (kl_rank), relative to the last cut
@@ -2417,7 +2423,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     }
     if (b > 0) {  // (after the vector loads: its values are needed in scalar registers, which waits for them)
         const LightSlot *ps = &ls->slot[b - 1];
-        r = ps->rec; bfail = ps->bfail;
+        r = ps->rec; bfail = ps->bfail; cdiff = ps->cdiff; cfound = ps->cfound;
 #pragma unroll
         for (int q = 0; q < kSpread; ++q) { sig += ps->lc.sig[q][0]; nlow += ps->lc.nlow[q][0]; }
 #pragma unroll
@@ -2434,6 +2440,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         const IterState *st = a.st;  // no light launch writes IterState except the TAIL
         r.t = st->passes; r.nref = st->nref; r.nref_prev = st->nref_prev; r.done = st->done; r.need_full = st->need_full;
         r.raw_pass = st->raw_pass; r.ran = 0; r.dcnt = st->delta_cnt[r.t & 1]; r.kstar = -1;
+        r.cper = st->cyc_period; r.cpow = st->cyc_pow; r.clam = st->cyc_lam; r.csel = st->cyc_sel; cdiff = st->cyc_ndiff;
         r.active = (!r.done && r.t < a.n_iter && !r.need_full) ? 1 : 0;
         if (r.active) {
             n = r.raw_pass == r.t ? 0 : min(r.dcnt, kDeltaMax);  // (need_full == 0 implies dcnt <= kDeltaMax)
@@ -2443,6 +2450,8 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         }
     } else if (r.active && bfail) {
         r.active = 0; r.need_full = 1;  // pass r.t lost a quantile window: the sorting path redoes it (its tallies are in place)
+    } else if (r.active && cfound) {
+        r.active = 0; r.cper = cfound;  // the mask in front of pass r.t equals the one cfound passes earlier: the host takes it from here (cycle watch)
     } else if (r.active) {
         // ---- the mask step of pass r.t (:413-424)
         const int t = r.t, cur = t & 1, nxt = cur ^ 1;
@@ -2551,11 +2560,58 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
         inref = ind;
         n = min(chg, kDeltaMax);
         stepped = true;
+        // ---- cycle watch.  The mask of the next pass is a function of this pass's mask alone (the table is fixed), so a mask
+        // that returns makes everything after it periodic: Brent's search keeps ONE snapshot of the mask, renewed after 1, 2, 4, ..
+        // steps, and the number of bits in which the current mask differs from it -- updated from the list of changed genes, which
+        // every mask step has anyway (workgroup 0, wave 0; the snapshot bytes are asked for here and looked at when the launch has
+        // nothing else left to do).  No differing bit <=> the masks are EQUAL: exact, no hashing.  What follows from a period: api.hip.
+        if (r.cper == 0) {
+            const bool fresh = r.cpow == 0;   // no snapshot to compare with: this mask becomes the first
+            if (!fresh) r.clam += 1;
+            if (!fresh && blockIdx.x == 0 && wave == 0) {
+                const uint8_t *snap = a.snap + static_cast<size_t>(r.csel) * Gp;
+#pragma unroll
+                for (int q = 0; q < kDeltaMax / 64; ++q) {
+                    const int e = lane + 64 * q;
+                    cyc_w[q] = e < n ? dl[e] : 0xFFFFFFFFu;
+                    cyc_s[q] = e < n ? snap[cyc_w[q] >> 1] : 0;
+                }
+                cyc_open = chg <= kDeltaMax ? r.clam : -1;   // (more changes than the list holds: the pass after this one sorts, which drops the snapshot)
+            }
+            if (fresh || r.clam == r.cpow) {  // (workgroup-uniform) this mask is the new snapshot -- in the OTHER buffer: workgroup 0 may still be reading the old one
+                r.cpow = fresh ? 1 : 2 * r.cpow; r.clam = 0; r.csel ^= 1;
+                if (i < Gp) a.snap[static_cast<size_t>(r.csel) * Gp + i] = ind ? 1 : 0;
+                cyc_renew = true;
+            }
+        }
         }
     }
+    // cycle watch, the end of it (workgroup 0, wave 0): the differing bits after this launch's mask step, and the period if there are none
+    auto cyc_close = [&]() {
+        if (cyc_open > 0) {
+            int d = 0;
+#pragma unroll
+            for (int q = 0; q < kDeltaMax / 64; ++q)   // a changed gene agreed with the snapshot before the step iff its new bit differs from the snapshot's
+                if (cyc_w[q] != 0xFFFFFFFFu) d += ((cyc_s[q] != 0) == ((cyc_w[q] & 1u) != 0)) ? -1 : 1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            cdiff += d;
+            cfound = cdiff == 0 ? cyc_open : 0;
+        } else if (cyc_open < 0) {
+            cdiff = 0x40000000; cfound = 0;   // unknown (never zero again before the snapshot is renewed)
+        } else {
+            cfound = stepped ? 0 : cfound;
+        }
+        if (cyc_renew) cdiff = 0;
+    };
     if (TAIL) {
+        if (blockIdx.x == 0 && wave == 0) {
+            cyc_close();
+            if (cfound) r.cper = cfound;
+        }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             IterState *st = a.st;
+            st->cyc_period = r.cper; st->cyc_pow = r.cpow; st->cyc_lam = r.clam; st->cyc_sel = r.csel; st->cyc_ndiff = cdiff;
             st->passes = r.t; st->nref = r.nref; st->nref_prev = r.nref_prev; st->done = r.done; st->need_full = r.need_full;
             st->i_iter = r.t - (r.done ? 1 : 0);
             st->raw_pass = r.raw_pass;
@@ -2565,6 +2621,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
             if (a.host_st) {
                 IterState *h = a.host_st;
                 h->passes = r.t; h->done = r.done; h->need_full = r.need_full; h->delta_cnt[r.t & 1] = r.dcnt;
+                h->cyc_period = r.cper;
                 if (r.ran) h->last_full = 0;
             }
         }
@@ -2572,7 +2629,10 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     }
     if (r.active) r.raw_pass = r.t;  // the tallies of pass r.t are made below
     if (blockIdx.x == 0 && threadIdx.x == 0) ls->slot[b].rec = r;
-    if (!r.active || static_cast<int>(blockIdx.x) * 256 >= G) return;
+    if (!r.active || static_cast<int>(blockIdx.x) * 256 >= G) {
+        if (blockIdx.x == 0 && wave == 0) { cyc_close(); if (lane == 0) { ls->slot[b].cdiff = cdiff; ls->slot[b].cfound = cfound; } }
+        return;
+    }
     // ---- pass r.t: tallies from the changed rows, delta1, window bookkeeping
     const int pbuf = b & 1;
     LightCnt *lc = &ls->slot[b].lc;
@@ -2635,6 +2695,7 @@ __global__ __launch_bounds__(256) void kl_head(IterArgs a, LightState *ls, int b
     if (inA) { const int at = baseA + __popcll(mA & lt); if (at < kCandMax) a.cand[at] = v; }
     if (inB) { const int at = baseB + __popcll(mB & lt); if (at < kCandMax) a.cand[kCandMax + at] = v; }
     if (!TAIL) STAMP(a, 7);
+    if (blockIdx.x == 0 && wave == 0) { cyc_close(); if (lane == 0) { ls->slot[b].cdiff = cdiff; ls->slot[b].cfound = cfound; } }
 }
 
 // second launch of a two-launch light pass: every workgroup finishes the selection for itself (slice_std), then p-values
@@ -3955,6 +4016,33 @@ int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits)
     return REO_OK;
 }
 
+// cycle watch (kl_head found the reference set of pass T equal to that of pass T - period; api.hip decides how much to skip): the
+// state of pass T is the state of pass T + skip when skip is a multiple of the period -- and even, for the buffers indexed by
+// the parity of the pass.  The skipped passes' trace entries (:418) are the last period's.
+__global__ void k_cycle_skip(IterState *st, IterState *host_st, int32_t *trace, int skip, int period)
+{
+    const int T = st->passes;
+    for (int u = T + static_cast<int>(threadIdx.x); u < T + skip; u += static_cast<int>(blockDim.x)) {
+        const int src = T - period + (u - T) % period;   // (>= 0: the snapshot was taken at pass T - period)
+        trace[2 * u] = trace[2 * src]; trace[2 * u + 1] = trace[2 * src + 1];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    st->passes = T + skip;
+    if (st->raw_pass >= 0) st->raw_pass += skip;
+    st->i_iter += skip;
+    st->cyc_period = -1;
+    if (host_st) { host_st->passes = T + skip; host_st->cyc_period = -1; }
+}
+
+int32_t launch_cycle_skip(reo_ctx *c, int skip, int period)
+{
+    if (skip < 0 || period < 1 || skip % period != 0 || (skip & 1)) { set_error("launch_cycle_skip: skip %d, period %d", skip, period); return REO_EINVAL; }
+    k_cycle_skip<<<1, 256, 0, c->stream>>>(c->state.p, c->state_mirror ? c->host_state : nullptr, c->trace.p, skip, period);
+    REO_HIP_CHECK(hipGetLastError());
+    return REO_OK;
+}
+
 int32_t launch_iter_init(reo_ctx *c, const uint8_t *host_ref, const IterState *host_state)
 {
     IterInitArgs a;
@@ -4000,7 +4088,7 @@ static IterArgs iter_args(reo_ctx *c, int replay)
     a.trace = c->trace.p; a.modes = nullptr;
     a.cand = c->cand.p; a.hist = c->hist.p; a.hist_stride = static_cast<int>(c->hist.n / (3 * kHistParts)); a.mrank = c->mrank.p;
     a.replay = replay; a.k2_idx = 0;
-    a.clist = c->clist.p; a.olist = c->olist.p; a.band = c->light_band; a.hist_below = c->hist_below; a.xcc_local = c->xcc_local;
+    a.clist = c->clist.p; a.olist = c->olist.p; a.band = c->light_band; a.hist_below = c->hist_below; a.snap = c->snap.p; a.xcc_local = c->xcc_local;
     // (no light passes -- switched off, or given up by the running call: the sorting path then leaves need_full set, else its
     //  launches would wait for light passes that nobody enqueues)
     a.window = c->light_window; a.light_min_g = (c->it_no_light || c->light_mode == 0) ? 0x7FFFFFFF : c->light_min_g;

@@ -41,7 +41,13 @@ struct IterState {
     int32_t fault;     // 0, or why the passes cannot be trusted (codes below); api.hip answers REO_EHIP
     int32_t kstar;     // the BH cut (number of genes with padj <= padj_deg) of the last executed pass (-1: unknown)
     int32_t kcut_acc;  // running count for kstar (sorting path)
-    int32_t pad[1];
+    // cycle watch of the light passes (kernels.hip, "cycle watch"): Brent's search for a pass whose mask equals an earlier one
+    int32_t cyc_period; // 0: watching; p > 0: the mask in front of pass `passes` equals the one p passes earlier; -1: not watching
+    int32_t cyc_pow;    // passes until the snapshot is renewed (0: no snapshot yet, or a sorting pass has stepped the mask since)
+    int32_t cyc_lam;    // mask steps since the snapshot
+    int32_t cyc_sel;    // which of the two snapshot buffers holds it
+    int32_t cyc_ndiff;  // genes whose mask bit differs from the snapshot's
+    int32_t pad[4];
 };
 constexpr int kFaultBarrier = 1;   // the persistent light kernel gave up at a grid barrier (bounded spin expired)
 constexpr int kFaultTallies = 2;   // a gene's tallies broke their invariant: not a class table (kernels.hip, tallies_from)
@@ -58,6 +64,7 @@ struct LightRec {
     int32_t ran;        // a light pass of this batch has been completed
     int32_t dcnt;       // genes whose mask bit changed in front of pass t
     int32_t kstar;      // the BH cut of the mask step that made this record (-1: none, the record comes from a sorting pass)
+    int32_t cper, cpow, clam, csel;  // cycle watch, as IterState::cyc_*
 };                      // (no padding array inside: copying one through registers made the compiler keep it in LDS, indexed by a
                         //  thread id that it computed from the dispatch packet -- a 3 us read of host memory at kernel start)
 // Counters of one light pass.  A launch cannot end before its atomics have been performed, and atomics on one address
@@ -87,11 +94,13 @@ struct LightCnt {
 struct LightSlot {
     LightRec rec;
     int32_t bfail;      // pass b lost a quantile window: it is redone on the sorting path
+    int32_t cdiff;      // cycle watch: mask bits that differ from the snapshot after launch b's mask step (workgroup 0 keeps it)
+    int32_t cfound;     // ... and, when none does, the period (the launch after this one stops the batch)
     int32_t pad0[5];
     double wnext[4];    // quantile windows for the pass after pass b
     double se_base;     // one-launch form: the se that launch b bracketed its genes' p-values around (the se of the pass before)
     double eta;         // ... and the half width of the bracket, relative
-    double pad1[2];
+    double pad1[15];
     LightCnt lc;
 };
 struct LightState { LightSlot slot[kLightBatch + 2]; };
@@ -248,6 +257,9 @@ struct reo_ctx {
     reo::DevBuf<reo::LightState> lstate;  // [1] batch log of the two-launch light passes
     reo::DevBuf<int32_t> clist;         // [2][256 + 256 * kListCap * 2] genes near the BH cut, by workgroup (kernels.hip, kl_rank)
     int light_band = 32;                // REO_LIGHT_BAND (tests)
+    bool cycle_watch = true;            // REO_CYCLE=0 switches the cycle watch of the light passes off (every pass is then executed)
+    reo::DevBuf<uint8_t> snap;          // [2][Gp] cycle watch: mask snapshots
+    int it_cycle_period = 0, it_cycle_at = 0, it_cycle_skipped = 0;  // the last reo_identify_degs: period found (0: none), in front of which pass, passes skipped
     int hist_below = 256;               // REO_HIST_BELOW (tests): ranks under the last cut that keep a histogram bin (kernels.hip, hist_first)
     int xcc_local = 0;                  // the per-XCD histogram atomics may stay in the XCD's L2 (checked once per context: kernels.hip, xcc_selftest)
     int light_window = 24, light_min_g = 4096;  // set from kernels.hip's constants in reo_create (REO_LIGHT_WINDOW, REO_LIGHT_MIN_G)
@@ -293,6 +305,7 @@ int32_t launch_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
 int32_t launch_check_table(reo_ctx *c, int *bad);  // consistency of an exchanged class table (kernels.hip, k_check_table)
 int32_t launch_decode(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint8_t *d_code);
 int32_t launch_pack_ref(reo_ctx *c, const uint8_t *d_bytes, uint32_t *d_bits);
+int32_t launch_cycle_skip(reo_ctx *c, int skip, int period);  // cycle watch: move the loop state `skip` passes on (whole periods), fill their trace, end the watch
 int32_t launch_iter_init(reo_ctx *c, const uint8_t *host_ref, const IterState *host_state);  // mask + loop state from pinned host memory, clears
 int32_t launch_tally(reo_ctx *c, int nref);
 int32_t launch_full_pass(reo_ctx *c, bool replay);

@@ -1401,6 +1401,72 @@ def test_light_passes_on_random_problems_incl_window_failures(pkg, oracle, monke
         assert run.info["xcc_local_histograms"] == 1  # (the self-test of reo_create passes on an MI355X)
 
 
+@pytest.mark.parametrize("window,below", [("12", "256"), ("3", "256"), ("12", "2")])
+def test_cycle_watch_skips_whole_periods_and_changes_nothing(pkg, oracle, monkeypatch, window, below):
+    """A loop that does not converge ends in a cycle of reference sets; the light passes notice the first set that returns
+    (Brent's search, compared bit for bit) and the host skips whole periods.  iters_run, the trace of every pass and the
+    result must be what the oracle gets by executing all n_iter passes -- for cycles of any period (fixed points are
+    period 1: an even number of passes is skipped all the same), for n_iter values that leave every remainder, with
+    window failures and lost cuts sending passes to the sorting path in between (which drops the snapshot), and with
+    n_conv = 1 (a fixed point converges before it is a cycle)."""
+    monkeypatch.setenv("REO_LIGHT_MIN_G", "64")
+    monkeypatch.setenv("REO_LIGHT_WINDOW", window)
+    monkeypatch.setenv("REO_HIST_BELOW", below)
+    rng = np.random.default_rng(77001 + int(window))
+    found, skipped, periods = 0, 0, set()
+    for case_no in range(16):
+        cs = _random_case(rng)
+        G = max(cs["G"], 120) if cs["G"] >= 120 else 120 + cs["G"]
+        X = cs["X"] if cs["X"].shape[0] == G else np.vstack([cs["X"], rng.permutation(cs["X"], axis=0)])[:G] if cs["X"].shape[0] * 2 >= G else None
+        if X is None:
+            X = rng.integers(0, 9, size=(G, cs["S"]))
+        labels = cs["labels"]
+        gid, lev = pkg.encode_groups(labels)
+        ref0 = pkg.synth.ref_mask(G, max(3, G // 3), cs["seed"])
+        n_iter, n_conv = int(rng.integers(30, 71)), int(rng.choice([0, 0, 0, 1]))
+        pval_deg, padj_deg = float(rng.choice([1.0, 1.0, 0.2])), float(rng.choice([0.05, 0.3, 0.9]))
+        tag = (window, below, case_no, cs["kind"], G, cs["S"], cs["ng"], n_iter, n_conv, pval_deg, padj_deg)
+        run = pkg.run_identify_degs(X, labels, list(range(G)), cs["pval_reo"], pval_deg, padj_deg, ref0, n_iter, n_conv,
+                                    seed=cs["seed"], device=0, profile=True)
+        Xf = np.asarray(X, dtype=np.float64)
+        for cm in run.comparisons:
+            exp, iters, trace = oracle.identify_degs(Xf, gid, len(lev), cs["pval_reo"], pval_deg, padj_deg, ref0, n_iter, n_conv,
+                                                     cs["seed"], k=cm["k"])
+            assert cm["iters_run"] == iters and cm["trace"] == trace, tag
+            assert np.array_equal(cm["result"][:, 2:11], exp[:, 2:11]), tag
+            ok = np.isfinite(exp).all(axis=1)
+            assert np.allclose(cm["result"][ok][:, :2], exp[ok][:, :2], rtol=0, atol=P_ATOL), tag
+            assert np.allclose(cm["result"][ok][:, 11:], exp[ok][:, 11:], rtol=STAT_RTOL, atol=1e-9), tag
+        info = run.info   # (of the last comparison)
+        if info["cycle_period"] > 0:
+            found += 1; skipped += info["cycle_passes_skipped"]; periods.add(info["cycle_period"])
+            assert info["cycle_passes_skipped"] % info["cycle_period"] == 0 and info["cycle_passes_skipped"] % 2 == 0, tag
+            assert info["cycle_found_at_pass"] + info["cycle_passes_skipped"] <= n_iter, tag
+    assert found > 0 and skipped > 0, (found, skipped, periods)
+
+
+def test_cycle_watch_at_twenty_thousand_genes_equals_every_pass_executed(pkg, monkeypatch):
+    """20 000 genes (the production size of the light passes), 45 forced passes, both data families: with the cycle watch the
+    call returns the trace and the result of the call that executes every pass (REO_CYCLE=0), bit for bit."""
+    G, S = 20000, 64
+    for fam, seed in (("t0", 0x5EED00A1), ("t1", 0x5EED00A2)):
+        X = (pkg.synth.t1_counts if fam == "t1" else pkg.synth.t0_ranks)(G, S, seed)
+        gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+        ref0 = pkg.synth.ref_mask(G, 3000, seed)
+        out, info = {}, {}
+        for cyc in ("1", "0"):
+            monkeypatch.setenv("REO_CYCLE", cyc)
+            with pkg.Context(device=0, seed=seed) as ctx:
+                ctx.set_matrix(X); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01); ctx.build_pairs(0)
+                out[cyc] = [ctx.identify_degs(ref0, 1.0, 0.05, n_iter, 0) for n_iter in (45, 46, 47)]
+                info[cyc] = ctx.info()
+        assert info["0"]["cycle_period"] == 0
+        assert info["1"]["cycle_period"] > 0 and info["1"]["cycle_passes_skipped"] > 0, (fam, info["1"])
+        for (r1, i1, t1), (r0, i0, t0) in zip(out["1"], out["0"]):
+            assert i1 == i0 and t1 == t0, fam
+            assert np.array_equal(r1, r0, equal_nan=True), fam
+
+
 def test_sorting_passes_only_and_large_cuts_at_a_size_that_uses_light_passes(pkg, monkeypatch):
     """REO_LIGHT=0 (sorting passes only) on a problem large enough for light passes -- the sorting path must then keep
     asking for itself (a call once waited for ever for light passes that nobody enqueued) -- and cut-offs that put
