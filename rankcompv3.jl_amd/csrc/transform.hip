@@ -150,6 +150,12 @@ constexpr unsigned kWideBits = 24, kWideExact = 13;
 constexpr int kWideBins = 1 << 14, kWideScan = 128;   // codes; largest lossy bucket that is still scanned
 constexpr size_t kWideWords = static_cast<size_t>(kWideBins) + (kWideBins >> 5);
 
+// diagnostic builds (-DREO_STAMPS): time marks of workgroup 0 behind the flags (REO_DEBUG_STAMPS=1 prints them)
+#ifdef REO_STAMPS
+#define TSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(flags + 8)[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
 template <class T, int IPT>
 __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
                                                  const int32_t *__restrict__ slots, int G, int Gp, int S,
@@ -171,20 +177,25 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     const T *col = X + static_cast<int64_t>(colmap[c]) * ld;
     const int slot = slots[c];
     int32_t *anytie = flags + 1;
+    TSTAMP(0);
     // the sample's own varying key bits (against its first gene): only those are sorted
     const uint64_t key0 = Codec<T>::enc(col[0]);
-    constexpr bool kKeep = IPT <= 24;  // keep the 64-bit codes in registers, or read the column a second time (L2)
-    uint64_t kk[kKeep ? IPT : 1], diff = 0;
+    // The low 32 bits of every code stay in registers (one word per item, reused below for key | arrival): the varying bits
+    // of count data and ranks lie there, and the column is then read once.  (64-bit codes in registers -- 40 to 64 of them
+    // at a 128-VGPR budget -- were spilled; the form without them read the column a second time: 20 of 60 us per sample at
+    // 30 000 genes.)  If the varying bits reach beyond bit 31 the keys come from a second read.
+    uint32_t kw[IPT];
+    uint64_t diff = 0;
     bool bad = false;
 #pragma unroll
     for (int e = 0; e < IPT; ++e) {
         const int i = e * 1024 + t;  // coalesced; which item holds which gene does not matter to the sort
-        if (kKeep) kk[e] = key0;
+        kw[e] = static_cast<uint32_t>(key0);
         if (i < G) {
             const T x = col[i];
             bad |= !Codec<T>::finite(x);
             const uint64_t code = Codec<T>::enc(x);
-            if (kKeep) kk[e] = code;
+            kw[e] = static_cast<uint32_t>(code);
             diff |= code ^ key0;
         }
     }
@@ -205,6 +216,10 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         return;
     }
     const uint32_t mask = (1u << nbits) - 1u;
+    const bool in_regs = begin_bit + nbits <= 32u;   // (workgroup-uniform) the kept words hold every varying bit
+    auto key_of = [&](uint32_t kept, int i) -> uint32_t {
+        return in_regs ? (kept >> begin_bit) & mask : static_cast<uint32_t>(Codec<T>::enc(col[i]) >> begin_bit) & mask;
+    };
     if (kCountingPath<T> && nbits <= kCountBits) {
         // Integer data whose varying key bits number at most 15 (ranks, small counts): ties are equalities, so a band is
         // a key value, and positions follow from a histogram -- first position of the band = number of smaller keys,
@@ -215,19 +230,20 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
         auto at = [](uint32_t b) { return b + (b >> 5); };
         const int nbin = 1 << nbits;
+        TSTAMP(1);
         for (int b = t; b < nbin; b += 1024) hist[at(b)] = 0;
         __syncthreads();
-        uint32_t key[IPT], arrival[IPT];
+        TSTAMP(2);
 #pragma unroll
-        for (int e = 0; e < IPT; ++e) {
+        for (int e = 0; e < IPT; ++e) {   // kw[e] becomes key | arrival << 16 (a key has at most 15 bits, an arrival is below 32 768)
             const int i = e * 1024 + t;
-            key[e] = 0; arrival[e] = 0;
             if (i < G) {
-                key[e] = static_cast<uint32_t>((kKeep ? kk[e] : Codec<T>::enc(col[i])) >> begin_bit) & mask;
-                arrival[e] = atomicAdd(&hist[at(key[e])], 1u);
+                const uint32_t key = key_of(kw[e], i);
+                kw[e] = key | (atomicAdd(&hist[at(key)], 1u) << 16);
             }
         }
         __syncthreads();
+        TSTAMP(3);
         // exclusive prefix sums of the bins, in place: thread t owns bins [t per, t per + per)
         const int per = nbin >= 1024 ? nbin / 1024 : 1;
         uint32_t cnt[kCountPer], tot = 0;
@@ -248,20 +264,23 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         for (int u = 0; u < kCountPer; ++u)
             if (u < per && t * per + u < nbin) { hist[at(t * per + u)] = run; run += cnt[u]; }
         __syncthreads();
+        TSTAMP(4);
         bool tied = false;
         uint16_t *prow = pos + static_cast<size_t>(slot) * Gp, *lrow = lo + static_cast<size_t>(slot) * Gp, *hrow = hi + static_cast<size_t>(slot) * Gp;
 #pragma unroll
         for (int e = 0; e < IPT; ++e) {
             const int i = e * 1024 + t;
             if (i >= G) continue;
-            const uint32_t l = hist[at(key[e])], h = static_cast<int>(key[e]) + 1 < nbin ? hist[at(key[e] + 1)] : static_cast<uint32_t>(G);
+            const uint32_t key = kw[e] & 0xFFFFu;
+            const uint32_t l = hist[at(key)], h = static_cast<int>(key) + 1 < nbin ? hist[at(key + 1)] : static_cast<uint32_t>(G);
             tied |= h - l > 1u;
-            prow[i] = static_cast<uint16_t>(l + arrival[e]);
+            prow[i] = static_cast<uint16_t>(l + (kw[e] >> 16));
             lrow[i] = static_cast<uint16_t>(l);
             hrow[i] = static_cast<uint16_t>(h);
         }
         for (int g = G + t; g < Gp; g += 1024) { prow[g] = 0; lrow[g] = 0; hrow[g] = 0; }  // padded genes are below no band edge
         if (tied && *anytie == 0) atomicOr(anytie, 1);
+        TSTAMP(5);
         return;
     }
     if (kCountingPath<T> && nbits <= kWideBits) {
@@ -280,20 +299,20 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         for (int b = t; b < static_cast<int>(kWideWords); b += 1024) hist[b] = 0;
         if (t < 32) wtot[t] = 0;
         __syncthreads();
-        uint32_t code[IPT], low[IPT], arrival[IPT];
+        uint32_t low[IPT];   // kw[e] becomes code | arrival << 16 (a code has 14 bits)
 #pragma unroll
         for (int e = 0; e < IPT; ++e) {
             const int i = e * 1024 + t;
-            code[e] = 0; low[e] = 0; arrival[e] = 0;
+            low[e] = 0;
             if (i < G) {
-                const uint32_t k = static_cast<uint32_t>((kKeep ? kk[e] : Codec<T>::enc(col[i])) >> begin_bit) & mask;
-                if (k < (1u << kWideExact)) code[e] = k;
-                else {
+                const uint32_t k = key_of(kw[e], i);
+                uint32_t code = k;
+                if (k >= (1u << kWideExact)) {
                     const unsigned ex = 31u - static_cast<unsigned>(__builtin_clz(k)), d = ex - mb;  // ex >= 13 > mb
-                    code[e] = (1u << kWideExact) + ((ex - kWideExact) << mb) + ((k >> d) & ((1u << mb) - 1u));
+                    code = (1u << kWideExact) + ((ex - kWideExact) << mb) + ((k >> d) & ((1u << mb) - 1u));
                     low[e] = (k & ((1u << d) - 1u)) | 0x10000u;   // bit 16: the bucket dropped bits
                 }
-                arrival[e] = atomicAdd(&hist[at(code[e])], 1u);
+                kw[e] = code | (atomicAdd(&hist[at(code)], 1u) << 16);
             }
         }
         __syncthreads();
@@ -312,18 +331,19 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
 #pragma unroll
         for (int u = 0; u < per; ++u) { hist[at(t * per + u)] = run; run += cnt[u]; }
         __syncthreads();
-        uint32_t s0[IPT], s1[IPT], crowd = 0;
+        uint32_t crowd = 0;
+        auto bucket = [&](uint32_t code, uint32_t &s0, uint32_t &s1) {   // (read again where they are needed: two more arrays of IPT words were spilled)
+            s0 = hist[at(code)];
+            s1 = code + 1 < static_cast<uint32_t>(kWideBins) ? hist[at(code + 1)] : static_cast<uint32_t>(G);
+        };
 #pragma unroll
         for (int e = 0; e < IPT; ++e) {
             const int i = e * 1024 + t;
-            s0[e] = s1[e] = 0;
-            if (i >= G) continue;
-            s0[e] = hist[at(code[e])];
-            s1[e] = code[e] + 1 < static_cast<uint32_t>(kWideBins) ? hist[at(code[e] + 1)] : static_cast<uint32_t>(G);
-            if (low[e] >> 16) {
-                skey[s0[e] + arrival[e]] = static_cast<uint16_t>(low[e]);
-                crowd = max(crowd, s1[e] - s0[e]);
-            }
+            if (i >= G || !(low[e] >> 16)) continue;
+            uint32_t s0, s1;
+            bucket(kw[e] & 0xFFFFu, s0, s1);
+            skey[s0 + (kw[e] >> 16)] = static_cast<uint16_t>(low[e]);
+            crowd = max(crowd, s1 - s0);
         }
         if (__ballot(crowd > static_cast<uint32_t>(kWideScan)) != 0 && (t & 63) == 0) atomicOr(&wtot[16], 1u);
         __syncthreads();
@@ -334,15 +354,17 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
             for (int e = 0; e < IPT; ++e) {
                 const int i = e * 1024 + t;
                 if (i >= G) continue;
-                uint32_t l = s0[e], h = s1[e], p = s0[e] + arrival[e];
-                if ((low[e] >> 16) && s1[e] - s0[e] > 1u) {  // rank inside the bucket: members with smaller / equal low bits
-                    const uint32_t mine = low[e] & 0xFFFFu, me = s0[e] + arrival[e];
+                uint32_t s0, s1;
+                bucket(kw[e] & 0xFFFFu, s0, s1);
+                uint32_t l = s0, h = s1, p = s0 + (kw[e] >> 16);
+                if ((low[e] >> 16) && s1 - s0 > 1u) {  // rank inside the bucket: members with smaller / equal low bits
+                    const uint32_t mine = low[e] & 0xFFFFu, me = p;
                     uint32_t smaller = 0, equal = 0, before = 0;
-                    for (uint32_t q = s0[e]; q < s1[e]; ++q) {
+                    for (uint32_t q = s0; q < s1; ++q) {
                         const uint32_t o = skey[q];
                         smaller += o < mine; equal += o == mine; before += (o == mine) & (q < me);
                     }
-                    l = s0[e] + smaller; h = l + equal; p = l + before;
+                    l = s0 + smaller; h = l + equal; p = l + before;
                 }
                 tied |= h - l > 1u;
                 prow[i] = static_cast<uint16_t>(p);
@@ -387,11 +409,6 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
 // Never gives up: a crowded bucket only costs its own members a longer scan.  Arrival slot, bucket and the 16 offset bits are
 // parked in the gene's pos / lo / hi rows between the phases (a thread reads back what it wrote itself).
 // flags: 0 non-finite input, 1 some tie.
-#ifdef REO_STAMPS
-#define TSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(flags + 8)[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define TSTAMP(k) do { } while (0)
-#endif
 constexpr int kSplit1 = 1024;                 // splitters (= threads)
 template <int IPT> constexpr int kWideLogSub = IPT <= 20 ? 4 : (IPT <= 24 ? 3 : 2);   // sub-buckets per splitter interval (what fits the LDS beside 4 B per gene)
 
@@ -926,6 +943,13 @@ int32_t transform_impl(reo_ctx *c)
                 fprintf(stderr, "stamps t_sample_wide (max + flags, sample sort, histogram, prefix sums, scatter, ranks in slot order, into gene order + rows):");
                 for (int k = 1; k <= 5; ++k) fprintf(stderr, " %lld", (long long)(stv[k] - stv[k - 1]));
                 fprintf(stderr, " %lld %lld", (long long)(stv[7] - stv[5]), (long long)(stv[6] - stv[7]));
+                fprintf(stderr, "  (x 10 ns)\n");
+            }
+            if (c->debug_stamps && !wide) {  // ... of t_sample's histogram form
+                unsigned long long stv[6];
+                REO_HIP_CHECK(hipMemcpy(stv, d_flags.p + 8, sizeof stv, hipMemcpyDeviceToHost));
+                fprintf(stderr, "stamps t_sample, histogram form (column read + varying bits, clear, keys + histogram, prefix sums, rows out):");
+                for (int k = 1; k <= 5; ++k) fprintf(stderr, " %lld", (long long)(stv[k] - stv[k - 1]));
                 fprintf(stderr, "  (x 10 ns)\n");
             }
             if (!fl[4] && !fl[5]) {
