@@ -160,7 +160,8 @@ template <class T, int IPT>
 __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
                                                  const int32_t *__restrict__ slots, int G, int Gp, int S,
                                                  uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
-                                                 uint16_t *__restrict__ hi, int32_t *__restrict__ flags)
+                                                 uint16_t *__restrict__ hi, int32_t *__restrict__ flags,
+                                                 uint16_t *__restrict__ skey_rows)   // [S][Gp] scratch, IPT > 32 only (else null)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -220,7 +221,73 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
     auto key_of = [&](uint32_t kept, int i) -> uint32_t {
         return in_regs ? (kept >> begin_bit) & mask : static_cast<uint32_t>(Codec<T>::enc(col[i]) >> begin_bit) & mask;
     };
-    if (kCountingPath<T> && nbits <= kCountBits) {
+    if constexpr (IPT > 32) {
+        // 32 769 .. 65 535 genes: the histogram form with 16-BIT bins, two to a word (a count, and a prefix sum, is at most
+        // G <= 65 535), for keys of up to 16 varying bits -- ranks of up to 65 535 genes are such keys.  The same LDS as the
+        // 32-bit histogram of 15-bit keys.  17 to 24 bits: the compressed histogram below.
+        if (kCountingPath<T> && nbits <= kCountBits + 1) {
+            uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+            auto at = [](uint32_t w) { return w + (w >> 5); };
+            const int nword = max(1 << nbits, 2048) / 2;   // (at least one word per thread in the prefix sums)
+            TSTAMP(1);
+            for (int w = t; w < nword; w += 1024) hist[at(w)] = 0;
+            __syncthreads();
+            TSTAMP(2);
+#pragma unroll
+            for (int e = 0; e < IPT; ++e) {   // kw[e] becomes key | arrival << 16
+                const int i = e * 1024 + t;
+                if (i < G) {
+                    const uint32_t key = key_of(kw[e], i), sh = (key & 1u) * 16u;
+                    const uint32_t old = atomicAdd(&hist[at(key >> 1)], 1u << sh);   // (no carry into the upper bin: a count stays below 65 536)
+                    kw[e] = key | (((old >> sh) & 0xFFFFu) << 16);
+                }
+            }
+            __syncthreads();
+            TSTAMP(3);
+            // exclusive prefix sums of the bins, in place: thread t owns words [t wper, t wper + wper)
+            const int wper = nword / 1024;
+            uint32_t tot = 0;
+            for (int u = 0; u < wper; ++u) { const uint32_t w = hist[at(t * wper + u)]; tot += (w & 0xFFFFu) + (w >> 16); }
+            uint32_t inc = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += up; }
+            uint32_t *wtot = hist + kCountWords;  // 16 words behind the histogram (part of the dynamic allocation)
+            if ((t & 63) == 63) wtot[t >> 6] = inc;
+            __syncthreads();
+            uint32_t run = inc - tot;
+            for (int w = 0; w < (t >> 6); ++w) run += wtot[w];
+            for (int u = 0; u < wper; ++u) {
+                const uint32_t w = hist[at(t * wper + u)], a = run, b = run + (w & 0xFFFFu);
+                hist[at(t * wper + u)] = a | (b << 16);   // (a prefix sum is at most G: 16 bits)
+                run = b + (w >> 16);
+            }
+            __syncthreads();
+            TSTAMP(4);
+            auto below = [&](uint32_t key) -> uint32_t {   // genes with a smaller key
+                if (static_cast<int>(key) >= 2 * nword) return static_cast<uint32_t>(G);
+                return (hist[at(key >> 1)] >> ((key & 1u) * 16u)) & 0xFFFFu;
+            };
+            bool tied = false;
+            uint16_t *prow = pos + static_cast<size_t>(slot) * Gp, *lrow = lo + static_cast<size_t>(slot) * Gp, *hrow = hi + static_cast<size_t>(slot) * Gp;
+#pragma unroll
+            for (int e = 0; e < IPT; ++e) {
+                const int i = e * 1024 + t;
+                if (i >= G) continue;
+                const uint32_t key = kw[e] & 0xFFFFu;
+                // (the bins behind the last key hold G, except when no bin is behind it)
+                const uint32_t l = below(key), h = below(key + 1);
+                tied |= h - l > 1u;
+                prow[i] = static_cast<uint16_t>(l + (kw[e] >> 16));
+                lrow[i] = static_cast<uint16_t>(l);
+                hrow[i] = static_cast<uint16_t>(h);
+            }
+            for (int g = G + t; g < Gp; g += 1024) { prow[g] = 0; lrow[g] = 0; hrow[g] = 0; }  // padded genes are below no band edge
+            if (tied && *anytie == 0) atomicOr(anytie, 1);
+            TSTAMP(5);
+            return;
+        }
+    }
+    if (IPT <= 32 && kCountingPath<T> && nbits <= kCountBits) {
         // Integer data whose varying key bits number at most 15 (ranks, small counts): ties are equalities, so a band is
         // a key value, and positions follow from a histogram -- first position of the band = number of smaller keys,
         // position inside the band = order of arrival at the histogram (any order inside a band gives the same counts:
@@ -293,7 +360,9 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
         auto at = [](uint32_t b) { return b + (b >> 5); };
         uint32_t *wtot = hist + kWideWords;                       // 16 wave totals, then the largest lossy bucket
-        uint16_t *skey = reinterpret_cast<uint16_t *>(wtot + 32);  // [Gp] low bits of the genes of lossy buckets, by slot
+        // [Gp] low bits of the genes of lossy buckets, by slot: in LDS up to 32 768 genes, above that in a scratch row (L2: a gene
+        // of a lossy bucket reads its few neighbours)
+        uint16_t *skey = IPT > 32 ? skey_rows + static_cast<size_t>(c) * Gp : reinterpret_cast<uint16_t *>(wtot + 32);
         const unsigned oct = nbits - kWideExact;                  // octaves above the exact range (3 .. 11)
         const unsigned mb = 31u - static_cast<unsigned>(__builtin_clz(kWideBins / 2 / oct));  // mantissa bits kept per octave
         for (int b = t; b < static_cast<int>(kWideWords); b += 1024) hist[b] = 0;
@@ -778,12 +847,19 @@ __global__ __launch_bounds__(256) void t_slice_big(const uint32_t *__restrict__ 
 template <class T, int IPT>
 int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
 {
-    const size_t lds = std::max({sizeof(uint32_t) * kCountWords + 64,
-                                 sizeof(uint32_t) * (kWideWords + 32) + sizeof(uint16_t) * static_cast<size_t>(c->Gp)});
+    const size_t lds = IPT > 32 ? sizeof(uint32_t) * kCountWords + 64   // (above 32 768 genes: the 16-bit-bin histogram only)
+                                : std::max({sizeof(uint32_t) * kCountWords + 64,
+                                            sizeof(uint32_t) * (kWideWords + 32) + sizeof(uint16_t) * static_cast<size_t>(c->Gp)});
     // every time: the attribute belongs to the (function, device) pair and a process may use several devices
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample<T, IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    uint16_t *skey_rows = nullptr;
+    if (IPT > 32) {  // (the segmented path's buffer: it is not running)
+        int32_t rc;
+        if ((rc = c->t_vin.ensure(static_cast<size_t>(c->S) * c->Gp))) return rc;
+        skey_rows = c->t_vin.p;
+    }
     t_sample<T, IPT><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,  // (a workgroup per slot: samples, then padding)
-                                                                            static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags);
+                                                                            static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, skey_rows);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -815,7 +891,8 @@ int32_t launch_lds_ranking(reo_ctx *c, const T *X, const int32_t *d_order, int32
             if (G <= 8 * 1024) return launch_sample<T, 8>(c, X, d_order, d_flags);
             if (G <= 20 * 1024) return launch_sample<T, 20>(c, X, d_order, d_flags);
             if (G <= 24 * 1024) return launch_sample<T, 24>(c, X, d_order, d_flags);
-            return launch_sample<T, 32>(c, X, d_order, d_flags);
+            if (G <= 32 * 1024) return launch_sample<T, 32>(c, X, d_order, d_flags);
+            return launch_sample<T, 64>(c, X, d_order, d_flags);   // (16-bit bins; the compressed histogram keeps its low-bit rows in L2)
         }
     }
     if (G <= 20 * 1024) return launch_sample_wide<T, 20>(c, X, d_order, d_flags);
@@ -913,7 +990,11 @@ int32_t transform_impl(reo_ctx *c)
     // varying bits, t_sample_wide's buckets for everything else (Float64; wider keys; a crowded lossy bucket)
     const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort; "wide": never the histogram forms (A/B tests)
     c->transform_in_lds = 0;
-    if (G <= 32 * 1024 && !(env && env[0] == 's')) {
+    // (t_sample_wide keeps 4 bytes per gene in LDS: up to 32 768 genes; t_sample's histogram forms take Int64 keys of at most 24
+    //  varying bits -- ranks, counts -- up to 65 535 genes; above 32 768 genes everything else is sorted by the library)
+    const bool wide_fits = G <= 32 * 1024;
+    const bool count_fits = kCountingPath<T> && G <= 65535 && !(env && env[0] == 'w');
+    if ((wide_fits || count_fits) && !(env && env[0] == 's')) {
         if (!c->host_flags) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t)));
         if (!c->ev_flags) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming));
         int32_t *fl = c->host_flags;
@@ -957,8 +1038,8 @@ int32_t transform_impl(reo_ctx *c)
                 return finish(fl[1], true);
             }
             REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
-            if (wide || fl[4]) break;  // a crowded bucket of different values: the segmented sort
-            wide = true;               // some sample needs the bucket form: all of them take it
+            if (wide || fl[4] || !wide_fits) break;  // a crowded bucket of different values, or too many genes for the bucket form: the segmented sort
+            wide = true;                             // some sample needs the bucket form: all of them take it
         }
     }
     if (!big) {  // the segmented path writes the genes of the samples only: padding slots and padded genes read as zero

@@ -596,6 +596,56 @@ def _counts_blocks(pkg, X, gid, ngroups, blocks, seed=3):
         return out, ctx.info()
 
 
+def _varying_key_bits(X):
+    """the widest window of key bits that varies inside one sample (what t_sample sorts by): bit length of the OR of
+    x ^ x[0] over the sample, minus its trailing zeros"""
+    worst = 0
+    for s in range(X.shape[1]):
+        col = X[:, s].astype(np.int64)
+        d = int(np.bitwise_or.reduce(col ^ col[0]))
+        if d:
+            worst = max(worst, d.bit_length() - ((d & -d).bit_length() - 1))
+    return worst
+
+
+@pytest.mark.parametrize("G,family", [(32769, "t0"), (50001, "t0"), (65535, "t0"), (40000, "small"), (65535, "t1"), (45000, "tail"), (65535, "tail")])
+def test_histogram_ranking_up_to_65535_genes(pkg, oracle, G, family, monkeypatch):
+    """Above 32 768 genes the per-sample ranking in LDS is the histogram form with 16-bit bins (Int64 keys of at most 16
+    varying bits: ranks of up to 65 535 genes, small counts) or the compressed histogram with its low-bit rows in L2 (17-24
+    bits: counts); everything else still goes through the segmented sort.  All must give the oracle's counts -- at the first
+    gene count above the 32-bit-bin form, in the middle, and at the u16 limit."""
+    S, seed = 12, 0x5EED0017
+    if family == "t0":
+        X = pkg.synth.t0_ranks(G, S, seed)
+    elif family == "t1":
+        X = pkg.synth.t1_counts(G, S, seed)
+    elif family == "tail":   # counts with a long tail (up to 22 bits): dense and repeated at small values, a few genes per octave far out
+        rng = np.random.default_rng(seed)
+        X = np.floor(np.exp(rng.normal(3.0, 2.6, size=(G, S)))).astype(np.int64)
+        X = np.minimum(X, (1 << 22) - 1)
+        X[rng.random((G, S)) < 0.3] = 0
+    else:
+        X = np.random.default_rng(seed).integers(0, 9, size=(G, S))   # nine values: bands of thousands of genes
+    gid = np.array([0, 1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 0], dtype=np.int32)
+    blocks = [(0, 40, 0, 40), (G - 40, G, G - 40, G), (G // 2, G // 2 + 24, 8, 40), (min(32760, G - 24), min(32760, G - 24) + 24, G - 64, G)]
+    monkeypatch.delenv("REO_TRANSFORM", raising=False)
+    a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
+    # ranks and small counts: the 16-bit-bin histogram; T1 counts (17-24 varying bits): the compressed histogram, unless a sample
+    # has a crowded lossy bucket (then every sample goes through the segmented sort: t_sample_wide stops at 32 768 genes)
+    assert _varying_key_bits(X) <= (16 if family not in ("t1", "tail") else 24), _varying_key_bits(X)
+    assert 17 <= _varying_key_bits(X) or family != "tail"
+    assert info_a["transform_in_lds"] == 1 or (family == "t1" and info_a["transform_in_lds"] == 0)
+    print("transform_in_lds", info_a["transform_in_lds"], "varying key bits", _varying_key_bits(X))
+    monkeypatch.setenv("REO_TRANSFORM", "segmented")
+    b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
+    assert info_b["transform_in_lds"] == 0
+    Xf = X.astype(np.float64)
+    for blk, (ga, ea), (gb, eb) in zip(blocks, a, b):
+        egt, eeq = oracle.pair_counts(Xf, gid, 2, *blk)
+        assert np.array_equal(ga, gb) and np.array_equal(ea, eb)
+        assert np.array_equal(ga, egt) and np.array_equal(ea, eeq)
+
+
 @pytest.mark.parametrize("G", [8192, 8193, 20480, 20481, 24576, 24577, 32768, 32769])
 def test_transform_in_lds_and_segmented_agree_at_the_size_limits(pkg, oracle, G, monkeypatch):
     """The per-sample ranking in LDS (<= 32 768 genes) and the device-wide segmented sort must give the same counts,
@@ -607,7 +657,7 @@ def test_transform_in_lds_and_segmented_agree_at_the_size_limits(pkg, oracle, G,
     blocks = [(0, 40, 0, 40), (G - 40, G, G - 40, G), (G // 2, G // 2 + 24, 8, 40)]
     monkeypatch.delenv("REO_TRANSFORM", raising=False)
     a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
-    assert info_a["transform_in_lds"] == (1 if G <= 32768 else 0)
+    assert info_a["transform_in_lds"] == 1 or G > 32768   # (above 32 768 genes: the histogram forms if no bucket is crowded, else the segmented sort)
     monkeypatch.setenv("REO_TRANSFORM", "segmented")
     b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
     assert info_b["transform_in_lds"] == 0
@@ -1055,8 +1105,8 @@ def test_maximum_gene_count_65535(pkg, oracle):
 
 
 def test_full_identify_degs_at_65535_genes(pkg, oracle):
-    """The whole path at the u16 limit (G = 65535, tie-rich counts, 16 samples): transform on the segmented
-    path, tie-rich K1, 64 sort chunks in K3; trace and tallies bit-exact, statistics within tolerance."""
+    """The whole path at the u16 limit (G = 65535, tie-rich counts, 16 samples): transform (the 16-bit-bin histogram form
+    if the counts have at most 16 varying bits, else the segmented path), tie-rich K1, 64 sort chunks in K3; trace and tallies bit-exact, statistics within tolerance."""
     G, S, seed = 65535, 16, 0x5EED0021
     X = pkg.synth.t1_counts(G, S, seed)
     group = np.array(["a", "b"] * 8, dtype=object)
@@ -1065,7 +1115,7 @@ def test_full_identify_degs_at_65535_genes(pkg, oracle):
     run = pkg.run_identify_degs(X, group, list(range(G)), 0.05, 1.0, 0.05, ref0, 12, 5, seed=seed, device=0)
     exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.05, 1.0, 0.05, ref0, 12, 5, seed)
     assert run.iters_run == iters and run.trace == trace and iters >= 2
-    assert run.info["transform_in_lds"] == 0 and run.info["has_ties"] == 1
+    assert run.info["transform_in_lds"] in (0, 1) and run.info["has_ties"] == 1
     _check_result(run.result, exp)
 
 
