@@ -25,6 +25,7 @@ rank 0's JSON line through and exits with the launcher's status; under an extern
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import shutil
@@ -153,6 +154,8 @@ def main() -> None:
                     ctx.comm_init_rank(box[0], rank, world)
         return ctx
 
+    step_walls = {}   # per-step wall times of every timed leg (ms): the blocks report their median beside the mean
+
     def run_family(family: str, steps: int, warmup: int, n_conv_list, G=G, S=S, seed=seed, gid=gid, ref0=ref0, cycle="0"):
         # cycle="0": every pass of the loop is executed (REO_CYCLE=0: the headline and every block that earlier rounds reported);
         # "1": the library's default -- a reference set that returns lets the call skip whole periods (block "cycle_watch")
@@ -165,6 +168,14 @@ def main() -> None:
         dt_name = "f64" if X.dtype == np.float64 else "i64"
 
         def step(n_conv: int):
+            if os.environ.get("REO_BENCH_DEBUG_WALLS"):   # where inside a step the wall time goes (stderr)
+                t = [time.perf_counter()]
+                ctx.set_matrix_device(Xd.data_ptr(), G, S, G, dt_name); t.append(time.perf_counter())
+                ctx.set_groups(gid, len(lev)); ctx.compute_thresholds(0.01); t.append(time.perf_counter())
+                ctx.build_pairs(0); t.append(time.perf_counter())
+                r = ctx.identify_degs(ref0, 1.0, 0.05, args.n_iter, n_conv); t.append(time.perf_counter())
+                print(family, "set_matrix %.2f groups+thresholds %.2f build_pairs %.2f identify_degs %.2f ms" % tuple((b - a) * 1e3 for a, b in zip(t[:-1], t[1:])), file=sys.stderr)
+                return r
             ctx.set_matrix_device(Xd.data_ptr(), G, S, G, dt_name)
             ctx.set_groups(gid, len(lev))
             ctx.compute_thresholds(0.01)
@@ -173,12 +184,22 @@ def main() -> None:
 
         def timed(n_conv: int, steps: int):
             ctx.reset_timings()
+            # the interpreter's cyclic garbage collector is off inside a timed region, as in the standard library's timeit: a
+            # generation-2 collection walks every container object torch has created (40-60 ms, measured: one step of the Float64 leg
+            # took 52 ms instead of 8.9 -- inside the Python stub, not in the library: REO_DEBUG_PASSES shows the library's waits)
+            gc.collect()
+            gc.disable()
             barrier()
             t0 = time.perf_counter()
+            walls = []
             for _ in range(steps):
+                ts = time.perf_counter()
                 res, iters, trace = step(n_conv)
+                walls.append((time.perf_counter() - ts) * 1e3)   # (a step ends with a blocking copy of the result: its wall time is the step's)
             barrier()
             dt = time.perf_counter() - t0
+            gc.enable()
+            step_walls[(family, n_conv, cycle, G)] = walls
             if world > 1:
                 t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.debug_gloo_one_gpu else dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,6 +270,7 @@ def main() -> None:
         "final_trace": list(trace[-1]) if trace else None,
         "has_ties": info["has_ties"],
     }
+    out["step_walls_ms"] = {"%s n_conv=%d cycle=%s G=%d" % k: [round(w, 3) for w in v] for k, v in step_walls.items()}
     out["stages_ms_per_step"]["iteration_passes_us_each"] = tm["iter_ms"] / args.steps / max(iters, 1) * 1e3
 
     if world > 1 or force_comm:  # what each rank did (the driver computes the scaling efficiency from the per-N values itself)
@@ -340,6 +362,7 @@ def main() -> None:
         if pr4:
             out["config4"]["ranks"] = pr4
 
+    out["step_walls_ms"] = {"%s n_conv=%d cycle=%s G=%d" % k: [round(w, 3) for w in v] for k, v in step_walls.items()}   # (every timed leg, per step)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oracle = ge.load_oracle()
         refs_all = ref0.copy()

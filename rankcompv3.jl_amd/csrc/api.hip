@@ -1,5 +1,6 @@
 // C ABI of libreo_hip.so (include/reo_hip.h): context, host-side driver of the
 // iteration loop of /root/reference/src/RankCompV3.jl:396-425, error plumbing.
+#include <ctime>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -107,6 +108,14 @@ static hipError_t stream_wait(reo_ctx *c)
 
 // The wait of a call that may be the first to see an asynchronous failure of the pair kernel (reo_build_pairs returns with
 // it in flight on one GPU): the table cannot be trusted then, and a retry must rebuild it.
+// REO_DEBUG_PASSES: host wall clock of the calls that can block inside reo_identify_degs (microseconds, stderr)
+static double wall_us()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
 static int32_t wait_or_drop_table(reo_ctx *c)
 {
     const hipError_t e = stream_wait(c);
@@ -722,6 +731,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     int passes = 0, seen_need_full = 1, light_batches = 0, idle_light = 0, idle_any = 0;  // idle_light: light batches in a row that completed no pass
     while (n_iter > 0) {  // :400
         const int remaining = n_iter - passes;
+        const double w_loop = c->debug_passes ? wall_us() : 0.0;
         // the state read after the last batch says which kind of pass is due: sorting launches are enqueued only then
         // (they would return at once otherwise: seven idle launches each), light launches only behind a pass that left
         // windows.  The first light batch is short, because a run that converges does so within a few passes and every
@@ -741,7 +751,9 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         }
         toc(c);
         if (!c->state_mirror) REO_HIP_CHECK(hipMemcpyAsync(c->host_state, c->state.p, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
+        const double w0 = c->debug_passes ? wall_us() : 0.0;
         if ((rc = wait_or_drop_table(c))) return rc;
+        if (c->debug_passes) fprintf(stderr, "  waited %.0f us for the batch (enqueueing it took %.0f us)\n", wall_us() - w0, w0 - w_loop);
         if (c->debug_passes && nlight > 0 && light_form == 3) {  // which check of the one-launch form ended the batch
             static LightState hs;  // (half a megabyte: not on the stack)
             if (hipMemcpy(&hs, c->lstate.p, sizeof hs, hipMemcpyDeviceToHost) == hipSuccess)
@@ -818,8 +830,11 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         fprintf(stderr, "  (x 10 ns)\n");
     }
     if (iters_run) *iters_run = passes;
+    const double w_copy = c->debug_passes ? wall_us() : 0.0;
     REO_HIP_CHECK(hipMemcpyAsync(result, c->result.p, sizeof(double) * 15 * G, hipMemcpyDeviceToHost, c->stream));
+    const double w_copied = c->debug_passes ? wall_us() : 0.0;
     if ((rc = wait_or_drop_table(c))) return rc;
+    if (c->debug_passes) fprintf(stderr, "  result copy: enqueued in %.0f us, waited %.0f us\n", w_copied - w_copy, wall_us() - w_copied);
     collect_timings(c);
     return pass_fault(c);  // (the replay, too, derives every gene's tallies)
 }
