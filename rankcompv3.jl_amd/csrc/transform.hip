@@ -479,7 +479,6 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
 // parked in the gene's pos / lo / hi rows between the phases (a thread reads back what it wrote itself).
 // flags: 0 non-finite input, 1 some tie.
 constexpr int kSplit1 = 1024;                 // splitters (= threads)
-template <int IPT> constexpr int kWideLogSub = IPT <= 20 ? 4 : (IPT <= 24 ? 3 : 2);   // sub-buckets per splitter interval (what fits the LDS beside 4 B per gene)
 
 // bytes of LDS in front of the two per-gene arrays: splitters + 16 wave maxima, NB bins (skewed) + end word + wave totals; 16-byte aligned
 __host__ __device__ constexpr size_t wide_lds_head(size_t nb) { return (8 * (kSplit1 + 16) + 4 * (nb + (nb >> 5) + 1 + 17) + 15) / 16 * 16; }
@@ -523,12 +522,15 @@ __device__ __forceinline__ uint64_t band_edge_code(double x, uint64_t cx)
     return in;
 }
 
-template <class T, int LOGSUB>
+// GENL: the by-slot gene row lives in LDS beside the offset row (4 bytes per gene: up to 32 768 genes); else in a scratch row (L2) --
+// 2 bytes per gene in LDS: up to 65 535 genes, and finer buckets below that.
+template <class T, int LOGSUB, bool GENL>
 __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
                                                       const int32_t *__restrict__ slots, int G, int Gp, int S,
                                                       uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
                                                       uint16_t *__restrict__ hi, int32_t *__restrict__ flags,
-                                                      uint64_t *__restrict__ oslot, uint16_t *__restrict__ bslot)
+                                                      uint64_t *__restrict__ oslot, uint16_t *__restrict__ bslot,
+                                                      uint16_t *__restrict__ gslot)
 {
     constexpr int SUB = 1 << LOGSUB, PER = SUB + 1, NB = kSplit1 * PER;   // per splitter: SUB pieces of the interval below it + its equality bucket
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     uint32_t *hist = reinterpret_cast<uint32_t *>(spl + kSplit1 + 16);         // [NB] bins, skewed by one word in 32; then one end word
     uint32_t *wtot = hist + NB + (NB >> 5) + 1;                               // 16 wave totals
     uint16_t *rem = reinterpret_cast<uint16_t *>(smem + wide_lds_head(NB));   // [Gp] by slot: 16 bits of the code's offset inside its bucket
-    uint16_t *gen = rem + Gp;                                                 // [Gp] by slot: the gene
+    uint16_t *gen = GENL ? rem + Gp : gslot + static_cast<size_t>(blockIdx.x) * Gp;   // [Gp] by slot: the gene (LDS, or this sample's scratch row)
     auto at = [](uint32_t b) { return b + (b >> 5); };
     const int t = threadIdx.x;
     const int c = blockIdx.x;
@@ -622,8 +624,8 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
         const uint64_t k = Codec<T>::enc(col[i]);
         uint32_t b, r; bool ex;
         locate(k, b, r, ex);
-        prow[i] = static_cast<uint16_t>(atomicAdd(&hist[at(b)], 1u) | (ex ? 0x8000u : 0u));   // (a slot is below 32 768)
-        lrow[i] = static_cast<uint16_t>(b);
+        prow[i] = static_cast<uint16_t>(atomicAdd(&hist[at(b)], 1u));   // (arrival inside the bucket: below 65 536)
+        lrow[i] = static_cast<uint16_t>(b | (ex ? 0x8000u : 0u));      // (a bucket index is below 2^15: 1 024 x 17)
         hrow[i] = static_cast<uint16_t>(r);
     }
     __syncthreads();
@@ -650,10 +652,10 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     uint64_t *os = oslot + static_cast<size_t>(c) * Gp;      // by slot: gene | pos << 16 | lo << 32 | hi << 48
 #pragma unroll 4
     for (int i = t; i < G; i += 1024) {
-        const uint32_t b = lrow[i], pk = prow[i], sl = hist[at(b)] + (pk & 0x7FFFu);
+        const uint32_t bw = lrow[i], sl = hist[at(bw & 0x7FFFu)] + prow[i];
         rem[sl] = hrow[i];
         gen[sl] = static_cast<uint16_t>(i);
-        bs[sl] = static_cast<uint16_t>(b | (pk & 0x8000u));   // (a bucket index is below 2^15: 1 024 x 17)
+        bs[sl] = static_cast<uint16_t>(bw);
     }
     __syncthreads();
     // number of genes whose code is below cq (le: below or equal)
@@ -723,21 +725,28 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     }
     TSTAMP(7);
     __syncthreads();   // every query is done: the LDS behind the splitters becomes pos16 / lo16 / hi16, indexed by gene
-    {   // two rows at a time (4 Gp bytes always fit behind the splitters), then the third
+    {   // a row at a time through 2 Gp bytes behind the splitters (with the gene row in LDS two rows fit: pos and lo go together)
         uint16_t *a16 = reinterpret_cast<uint16_t *>(hist), *b16 = a16 + Gp;
-        for (int g = G + t; g < Gp; g += 1024) { a16[g] = 0; b16[g] = 0; }  // padded genes are below no band edge
+        for (int g = G + t; g < Gp; g += 1024) { a16[g] = 0; if (GENL) b16[g] = 0; }  // padded genes are below no band edge
         for (int sl = t; sl < G; sl += 1024) {
             const uint64_t o = os[sl];
             const uint32_t gene = static_cast<uint32_t>(o & 0xFFFFu);
-            a16[gene] = static_cast<uint16_t>(o >> 16); b16[gene] = static_cast<uint16_t>(o >> 32);
+            a16[gene] = static_cast<uint16_t>(o >> 16);
+            if (GENL) b16[gene] = static_cast<uint16_t>(o >> 32);
         }
         __syncthreads();
         for (int q = t; q < Gp / 8; q += 1024) {
             reinterpret_cast<uint4 *>(prow)[q] = reinterpret_cast<const uint4 *>(a16)[q];
-            reinterpret_cast<uint4 *>(lrow)[q] = reinterpret_cast<const uint4 *>(b16)[q];
+            if (GENL) reinterpret_cast<uint4 *>(lrow)[q] = reinterpret_cast<const uint4 *>(b16)[q];
         }
         __syncthreads();
-        for (int sl = t; sl < G; sl += 1024) { const uint64_t o = os[sl]; a16[o & 0xFFFFu] = static_cast<uint16_t>(o >> 48); }   // (the padded genes' zeros are still there)
+        if (!GENL) {
+            for (int sl = t; sl < G; sl += 1024) { const uint64_t o = os[sl]; a16[o & 0xFFFFu] = static_cast<uint16_t>(o >> 32); }   // (the padded genes' zeros are still there)
+            __syncthreads();
+            for (int q = t; q < Gp / 8; q += 1024) reinterpret_cast<uint4 *>(lrow)[q] = reinterpret_cast<const uint4 *>(a16)[q];
+            __syncthreads();
+        }
+        for (int sl = t; sl < G; sl += 1024) { const uint64_t o = os[sl]; a16[o & 0xFFFFu] = static_cast<uint16_t>(o >> 48); }
         __syncthreads();
         for (int q = t; q < Gp / 8; q += 1024) reinterpret_cast<uint4 *>(hrow)[q] = reinterpret_cast<const uint4 *>(a16)[q];
     }
@@ -864,19 +873,21 @@ int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d
     return REO_OK;
 }
 
-template <class T, int IPT>
+template <class T, int LOGSUB, bool GENL>
 int32_t launch_sample_wide(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
 {
-    constexpr int LOGSUB = kWideLogSub<IPT>;
     constexpr size_t NB = static_cast<size_t>(kSplit1) * ((1 << LOGSUB) + 1);
-    const size_t lds = wide_lds_head(NB) + sizeof(uint16_t) * 2 * static_cast<size_t>(c->Gp);
-    REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample_wide<T, LOGSUB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t lds = wide_lds_head(NB) + sizeof(uint16_t) * (GENL ? 2 : 1) * static_cast<size_t>(c->Gp);
+    if (lds > 160 * 1024) { set_error("t_sample_wide: %zu bytes of LDS for %d genes", lds, c->Gp); return REO_EINVAL; }
+    REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample_wide<T, LOGSUB, GENL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // by-slot scratch rows of every sample (the segmented path's buffers: it is not running)
     int32_t rc;
     const size_t n = static_cast<size_t>(c->S) * c->Gp;
     if ((rc = c->t_kin.ensure(n)) || (rc = c->t_vin.ensure(n))) return rc;
-    t_sample_wide<T, LOGSUB><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
-                                                                                    static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, c->t_kin.p, c->t_vin.p);
+    if (!GENL && (rc = c->t_vout.ensure(n))) return rc;
+    t_sample_wide<T, LOGSUB, GENL><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
+                                                                                    static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, c->t_kin.p, c->t_vin.p,
+                                                                                    GENL ? nullptr : c->t_vout.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -895,9 +906,16 @@ int32_t launch_lds_ranking(reo_ctx *c, const T *X, const int32_t *d_order, int32
             return launch_sample<T, 64>(c, X, d_order, d_flags);   // (16-bit bins; the compressed histogram keeps its low-bit rows in L2)
         }
     }
-    if (G <= 20 * 1024) return launch_sample_wide<T, 20>(c, X, d_order, d_flags);
-    if (G <= 24 * 1024) return launch_sample_wide<T, 24>(c, X, d_order, d_flags);
-    return launch_sample_wide<T, 32>(c, X, d_order, d_flags);
+    // sub-buckets per splitter interval: what fits the LDS beside the by-slot rows -- 4 bytes per gene up to 32 768 genes, 2 above
+    // (the gene row then lives in L2)
+    auto fits = [&](int logsub) { return wide_lds_head(static_cast<size_t>(kSplit1) * ((1 << logsub) + 1)) + sizeof(uint16_t) * static_cast<size_t>(c->Gp) <= 160 * 1024; };
+    // (measured, Float64 x 1 000 samples: 24 000 genes 1.37 ms with <3, true> against 1.44 with <4, false>; 30 000 genes 2.28 with
+    //  <2, true> against 1.99 with <4, false>; 40 000 / 50 000 / 60 000 genes 2.97 / 4.54 / 7.57 ms, the library's segmented sort 8.9 at 60 000)
+    if (G <= 20 * 1024) return launch_sample_wide<T, 4, true>(c, X, d_order, d_flags);
+    if (G <= 24 * 1024) return launch_sample_wide<T, 3, true>(c, X, d_order, d_flags);
+    if (fits(4)) return launch_sample_wide<T, 4, false>(c, X, d_order, d_flags);   // (up to 41 472 genes)
+    if (fits(3)) return launch_sample_wide<T, 3, false>(c, X, d_order, d_flags);   // (up to 58 368)
+    return launch_sample_wide<T, 2, false>(c, X, d_order, d_flags);
 }
 
 struct SegOff {
@@ -990,11 +1008,9 @@ int32_t transform_impl(reo_ctx *c)
     // varying bits, t_sample_wide's buckets for everything else (Float64; wider keys; a crowded lossy bucket)
     const char *env = getenv("REO_TRANSFORM");  // "segmented": always the device-wide segmented sort; "wide": never the histogram forms (A/B tests)
     c->transform_in_lds = 0;
-    // (t_sample_wide keeps 4 bytes per gene in LDS: up to 32 768 genes; t_sample's histogram forms take Int64 keys of at most 24
-    //  varying bits -- ranks, counts -- up to 65 535 genes; above 32 768 genes everything else is sorted by the library)
-    const bool wide_fits = G <= 32 * 1024;
-    const bool count_fits = kCountingPath<T> && G <= 65535 && !(env && env[0] == 'w');
-    if ((wide_fits || count_fits) && !(env && env[0] == 's')) {
+    // (up to 65 535 genes: positions are 16-bit numbers.  Above 32 768 genes the histogram forms use 16-bit bins / keep their low-bit
+    //  rows in L2, and the bucket form keeps its gene row in L2.)
+    if (G <= 65535 && !(env && env[0] == 's')) {
         if (!c->host_flags) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t)));
         if (!c->ev_flags) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming));
         int32_t *fl = c->host_flags;
@@ -1038,8 +1054,8 @@ int32_t transform_impl(reo_ctx *c)
                 return finish(fl[1], true);
             }
             REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
-            if (wide || fl[4] || !wide_fits) break;  // a crowded bucket of different values, or too many genes for the bucket form: the segmented sort
-            wide = true;                             // some sample needs the bucket form: all of them take it
+            if (wide || fl[4]) break;  // a crowded bucket of different values: the segmented sort
+            wide = true;               // some sample needs the bucket form: all of them take it
         }
     }
     if (!big) {  // the segmented path writes the genes of the samples only: padding slots and padded genes read as zero

@@ -631,10 +631,10 @@ def test_histogram_ranking_up_to_65535_genes(pkg, oracle, G, family, monkeypatch
     monkeypatch.delenv("REO_TRANSFORM", raising=False)
     a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
     # ranks and small counts: the 16-bit-bin histogram; T1 counts (17-24 varying bits): the compressed histogram, unless a sample
-    # has a crowded lossy bucket (then every sample goes through the segmented sort: t_sample_wide stops at 32 768 genes)
+    # has a crowded lossy bucket (then every sample takes the bucket form)
     assert _varying_key_bits(X) <= (16 if family not in ("t1", "tail") else 24), _varying_key_bits(X)
     assert 17 <= _varying_key_bits(X) or family != "tail"
-    assert info_a["transform_in_lds"] == 1 or (family == "t1" and info_a["transform_in_lds"] == 0)
+    assert info_a["transform_in_lds"] == 1 or (family == "t1" and info_a["transform_in_lds"] == 2)
     print("transform_in_lds", info_a["transform_in_lds"], "varying key bits", _varying_key_bits(X))
     monkeypatch.setenv("REO_TRANSFORM", "segmented")
     b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
@@ -657,17 +657,17 @@ def test_transform_in_lds_and_segmented_agree_at_the_size_limits(pkg, oracle, G,
     blocks = [(0, 40, 0, 40), (G - 40, G, G - 40, G), (G // 2, G // 2 + 24, 8, 40)]
     monkeypatch.delenv("REO_TRANSFORM", raising=False)
     a, info_a = _counts_blocks(pkg, X, gid, 2, blocks)
-    assert info_a["transform_in_lds"] == 1 or G > 32768   # (above 32 768 genes: the histogram forms if no bucket is crowded, else the segmented sort)
+    assert info_a["transform_in_lds"] in (1, 2)   # (2: a crowded lossy bucket sent every sample to the bucket form)
     monkeypatch.setenv("REO_TRANSFORM", "segmented")
     b, info_b = _counts_blocks(pkg, X, gid, 2, blocks)
     assert info_b["transform_in_lds"] == 0
     Xf = X.astype(np.float64)
     monkeypatch.setenv("REO_TRANSFORM", "wide")
     w, info_w = _counts_blocks(pkg, X, gid, 2, blocks)
-    assert info_w["transform_in_lds"] == (2 if G <= 32768 else 0)
+    assert info_w["transform_in_lds"] == 2
     monkeypatch.delenv("REO_TRANSFORM", raising=False)
     f, info_f = _counts_blocks(pkg, np.log2(1.0 + Xf), gid, 2, blocks)   # a monotone map: ties stay equalities or widen into 0.1 bands
-    assert info_f["transform_in_lds"] == (2 if G <= 32768 else 0)
+    assert info_f["transform_in_lds"] == 2
     for blk, (ga, ea), (gb, eb), (gw, ew), (gf, ef) in zip(blocks, a, b, w, f):
         egt, eeq = oracle.pair_counts(Xf, gid, 2, *blk)
         assert np.array_equal(ga, gb) and np.array_equal(ea, eb)
@@ -709,7 +709,7 @@ def test_transform_key_width_decides_the_path(pkg, oracle, monkeypatch):
         assert np.array_equal(out[0], egt) and np.array_equal(out[1], eeq), name
 
 
-@pytest.mark.parametrize("G", [700, 9000, 20000, 32768])
+@pytest.mark.parametrize("G", [700, 9000, 20000, 32768, 32769, 47000, 50000, 65535])
 def test_transform_bucket_ranking_of_float64(pkg, oracle, G, monkeypatch):
     """t_sample_wide on Float64 (transform.hip): the 0.1 band of is_greater (:72) found in code space with the
     reference's own predicate.  Samples built to hit its corners: many exact zeros (an equality bucket of one value),
@@ -1115,7 +1115,7 @@ def test_full_identify_degs_at_65535_genes(pkg, oracle):
     run = pkg.run_identify_degs(X, group, list(range(G)), 0.05, 1.0, 0.05, ref0, 12, 5, seed=seed, device=0)
     exp, iters, trace = oracle.identify_degs(X.astype(np.float64), gid, 2, 0.05, 1.0, 0.05, ref0, 12, 5, seed)
     assert run.iters_run == iters and run.trace == trace and iters >= 2
-    assert run.info["transform_in_lds"] in (0, 1) and run.info["has_ties"] == 1
+    assert run.info["transform_in_lds"] in (1, 2) and run.info["has_ties"] == 1
     _check_result(run.result, exp)
 
 
