@@ -106,8 +106,6 @@ static hipError_t stream_wait(reo_ctx *c)
     }
 }
 
-// The wait of a call that may be the first to see an asynchronous failure of the pair kernel (reo_build_pairs returns with
-// it in flight on one GPU): the table cannot be trusted then, and a retry must rebuild it.
 // REO_DEBUG_PASSES: host wall clock of the calls that can block inside reo_identify_degs (microseconds, stderr)
 static double wall_us()
 {
@@ -116,6 +114,8 @@ static double wall_us()
     return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 
+// The wait of a call that may be the first to see an asynchronous failure of the pair kernel (reo_build_pairs returns with
+// it in flight on one GPU): the table cannot be trusted then, and a retry must rebuild it.
 static int32_t wait_or_drop_table(reo_ctx *c)
 {
     const hipError_t e = stream_wait(c);
