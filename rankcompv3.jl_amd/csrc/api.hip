@@ -1,5 +1,9 @@
 // C ABI of libreo_hip.so (include/reo_hip.h): context, host-side driver of the
 // iteration loop of /root/reference/src/RankCompV3.jl:396-425, error plumbing.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <ctime>
 #include <algorithm>
 #include <chrono>
@@ -104,6 +108,38 @@ static hipError_t stream_wait(reo_ctx *c)
         if (q != hipErrorNotReady) return q;
         if (spin > (1u << 22)) return hipStreamSynchronize(c->stream);  // a long wait after all: stop burning the core
     }
+}
+
+// REO_DEBUG_SEGV=1 (diagnostics; tools/fuzz_*.py set it): a native backtrace on SIGSEGV / SIGBUS / SIGABRT before the process dies --
+// Python's faulthandler shows the Python frames only, and the one host crash of this project (tools/fuzz_gpu.py, rounds 1 and 4:
+// profiles/faults/) came and went without a native stack.  Async-signal-safe calls only; the default action follows.
+static struct sigaction g_old_action[3];   // SIGSEGV, SIGBUS, SIGABRT: what was installed before (Python's faulthandler, usually)
+
+static void segv_backtrace(int sig)
+{
+    static const char head[] = "libreo_hip: fatal signal, native backtrace of the faulting thread:\n";
+    (void)!write(2, head, sizeof head - 1);
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    sigaction(sig, &g_old_action[sig == SIGSEGV ? 0 : (sig == SIGBUS ? 1 : 2)], nullptr);   // then whoever was there before (or the default action)
+    raise(sig);
+}
+
+static void install_segv_backtrace()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    void *warm[2];
+    (void)backtrace(warm, 2);   // (loads libgcc now: not from inside the handler)
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = segv_backtrace;
+    sa.sa_flags = SA_NODEFER;
+    sigaction(SIGSEGV, &sa, &g_old_action[0]);
+    sigaction(SIGBUS, &sa, &g_old_action[1]);
+    sigaction(SIGABRT, &sa, &g_old_action[2]);
 }
 
 // REO_DEBUG_PASSES: host wall clock of the calls that can block inside reo_identify_degs (microseconds, stderr)
@@ -313,6 +349,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
 {
     if (!out) { set_error("out is null"); return REO_EINVAL; }
     *out = nullptr;
+    if (getenv("REO_DEBUG_SEGV")) install_segv_backtrace();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         set_error("no HIP device visible: libreo_hip has no CPU fallback");

@@ -1,7 +1,8 @@
 """Long randomized parity run (not part of the test suite): N random cases of the same generator the GPU
 test uses, larger G range, every comparison checked against the oracle.  python tools/fuzz_gpu.py [N] [seed]"""
-import sys, time, faulthandler, numpy as np
+import os, sys, time, faulthandler, numpy as np
 faulthandler.enable()
+os.environ.setdefault("REO_DEBUG_SEGV", "1")   # a native backtrace if the host side ever crashes again (api.hip)
 sys.path.insert(0, '.')
 import __graft_entry__ as ge
 pkg = ge.load_pkg(); oracle = ge.load_oracle()

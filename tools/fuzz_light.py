@@ -4,6 +4,7 @@ comparison checked against the oracle -- trace of every pass, tallies bit for bi
 python tools/fuzz_light.py [N] [seed]"""
 import os, sys, time, faulthandler, numpy as np
 faulthandler.enable()
+os.environ.setdefault("REO_DEBUG_SEGV", "1")   # a native backtrace if the host side ever crashes again (api.hip)
 sys.path.insert(0, '.')
 import __graft_entry__ as ge
 pkg = ge.load_pkg(); oracle = ge.load_oracle()

@@ -2,7 +2,8 @@
 2 and 4 column chunks, tie-free and tie-rich widths -- comes up), random shard counts, the gather exchange through a
 thread-barrier hook on one GPU; every shard's complete table must equal the unsharded one, code for code.
 python tools/fuzz_shards.py [N] [seed]"""
-import sys, threading, numpy as np
+import os, sys, threading, numpy as np
+os.environ.setdefault("REO_DEBUG_SEGV", "1")   # a native backtrace if the host side ever crashes again (api.hip)
 sys.path.insert(0, '.')
 import __graft_entry__ as ge
 pkg = ge.load_pkg()
