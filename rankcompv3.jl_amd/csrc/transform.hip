@@ -481,7 +481,12 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
 constexpr int kSplit1 = 1024;                 // splitters (= threads)
 
 // bytes of LDS in front of the two per-gene arrays: splitters + 16 wave maxima, NB bins (skewed) + end word + wave totals; 16-byte aligned
-__host__ __device__ constexpr size_t wide_lds_head(size_t nb) { return (8 * (kSplit1 + 16) + 4 * (nb + (nb >> 5) + 1 + 17) + 15) / 16 * 16; }
+// (h16: the bins are 16-bit numbers, two to a word -- a count and a prefix sum are at most G <= 65 535)
+__host__ __device__ constexpr size_t wide_lds_head(size_t nb, bool h16 = false)
+{
+    const size_t words = h16 ? nb / 2 + 1 : nb + 1;
+    return (8 * (kSplit1 + 16) + 4 * (words + (words >> 5) + 1 + 17) + 15) / 16 * 16;
+}
 
 template <class T>
 __device__ __forceinline__ bool code_tied(uint64_t c, T x) { return Codec<T>::tie(Codec<T>::dec(c), x); }
@@ -530,16 +535,24 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
                                                       uint16_t *__restrict__ pos, uint16_t *__restrict__ lo,
                                                       uint16_t *__restrict__ hi, int32_t *__restrict__ flags,
                                                       uint64_t *__restrict__ oslot, uint16_t *__restrict__ bslot,
-                                                      uint16_t *__restrict__ gslot)
+                                                      uint32_t *__restrict__ bgslot)   // !GENL: [S][Gp] by slot: bucket | exact << 15 | gene << 16
 {
     constexpr int SUB = 1 << LOGSUB, PER = SUB + 1, NB = kSplit1 * PER;   // per splitter: SUB pieces of the interval below it + its equality bucket
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *spl = reinterpret_cast<unsigned long long *>(smem);   // [1024] sorted splitters; [1024..1039] wave maxima
     uint32_t *hist = reinterpret_cast<uint32_t *>(spl + kSplit1 + 16);         // [NB] bins, skewed by one word in 32; then one end word
-    uint32_t *wtot = hist + NB + (NB >> 5) + 1;                               // 16 wave totals
-    uint16_t *rem = reinterpret_cast<uint16_t *>(smem + wide_lds_head(NB));   // [Gp] by slot: 16 bits of the code's offset inside its bucket
-    uint16_t *gen = GENL ? rem + Gp : gslot + static_cast<size_t>(blockIdx.x) * Gp;   // [Gp] by slot: the gene (LDS, or this sample's scratch row)
-    auto at = [](uint32_t b) { return b + (b >> 5); };
+    constexpr bool H16 = !GENL;                                               // 16-bit bins: twice as many buckets in the same LDS
+    constexpr int HW = H16 ? NB / 2 + 1 : NB + 1;                             // words of the histogram (unskewed), incl. the end bin
+    uint32_t *wtot = hist + HW + (HW >> 5) + 1;                               // 16 wave totals
+    uint16_t *rem = reinterpret_cast<uint16_t *>(smem + wide_lds_head(NB, H16));   // [Gp] by slot: 16 bits of the code's offset inside its bucket
+    uint16_t *gen = rem + Gp;                                                 // GENL: [Gp] by slot: the gene
+    uint32_t *bg = GENL ? nullptr : bgslot + static_cast<size_t>(blockIdx.x) * Gp;   // !GENL: bucket word and gene of a slot in one scratch word (ONE scattered store per gene)
+    auto gene_at = [&](uint32_t q) -> uint32_t { if constexpr (GENL) return gen[q]; else return bg[q] >> 16; };
+    auto at = [](uint32_t b) { return b + (b >> 5); };   // word index, skewed by one word in 32
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(hist);
+    auto at16 = [](uint32_t b) { return ((b >> 1) + (b >> 6)) * 2 + (b & 1u); };   // 16-bit bin b: half (b & 1) of skewed word b >> 1
+    // bin b after the prefix sums: the number of genes in the buckets before b
+    auto HB = [&](uint32_t b) -> uint32_t { if constexpr (H16) return h16[at16(b)]; else return hist[at(b)]; };
     const int t = threadIdx.x;
     const int c = blockIdx.x;
     if (c >= S) {  // one workgroup per padding slot too: rows of zeros -- lo = hi = 0 is below no position
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     for (int o = 32; o > 0; o >>= 1) { const uint64_t b = __shfl_xor(kmax, o, 64); kmax = b > kmax ? b : kmax; }
     if ((t & 63) == 0) spl[kSplit1 + (t >> 6)] = kmax;
     if (__ballot(bad) != 0 && (t & 63) == 0) atomicOr(flags, 1);
-    for (int b = t; b < NB + (NB >> 5) + 1; b += 1024) hist[b] = 0;
+    for (int b = t; b < HW + (HW >> 5) + 1; b += 1024) hist[b] = 0;
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 16; ++w) { const uint64_t b = spl[kSplit1 + w]; kmax = b > kmax ? b : kmax; }
@@ -624,7 +637,10 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
         const uint64_t k = Codec<T>::enc(col[i]);
         uint32_t b, r; bool ex;
         locate(k, b, r, ex);
-        prow[i] = static_cast<uint16_t>(atomicAdd(&hist[at(b)], 1u));   // (arrival inside the bucket: below 65 536)
+        uint32_t arrival;   // (inside the bucket: below 65 536)
+        if constexpr (H16) { const uint32_t sh = (b & 1u) * 16u; arrival = (atomicAdd(&hist[at(b >> 1)], 1u << sh) >> sh) & 0xFFFFu; }   // (no carry into the upper bin: a count stays below 65 536)
+        else arrival = atomicAdd(&hist[at(b)], 1u);
+        prow[i] = static_cast<uint16_t>(arrival);
         lrow[i] = static_cast<uint16_t>(b | (ex ? 0x8000u : 0u));      // (a bucket index is below 2^15: 1 024 x 17)
         hrow[i] = static_cast<uint16_t>(r);
     }
@@ -633,7 +649,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     {   // exclusive prefix sums of the bins, in place: thread t owns the PER bins of splitter t
         uint32_t cnt[PER], tot = 0;
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { cnt[u] = hist[at(t * PER + u)]; tot += cnt[u]; }
+        for (int u = 0; u < PER; ++u) { cnt[u] = HB(t * PER + u); tot += cnt[u]; }   // (16-bit bins: two threads share a word at their border -- all reads are in front of the barrier, all writes behind it)
         uint32_t inc = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += up; }
@@ -642,8 +658,11 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
         uint32_t run = inc - tot;
         for (int w = 0; w < (t >> 6); ++w) run += wtot[w];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { hist[at(t * PER + u)] = run; run += cnt[u]; }
-        if (t == kSplit1 - 1) hist[at(NB)] = static_cast<uint32_t>(G);
+        for (int u = 0; u < PER; ++u) {
+            if constexpr (H16) h16[at16(t * PER + u)] = static_cast<uint16_t>(run); else hist[at(t * PER + u)] = run;
+            run += cnt[u];
+        }
+        if (t == kSplit1 - 1) { if constexpr (H16) h16[at16(NB)] = static_cast<uint16_t>(G); else hist[at(NB)] = static_cast<uint32_t>(G); }
     }
     __syncthreads();
     TSTAMP(4);
@@ -652,10 +671,10 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     uint64_t *os = oslot + static_cast<size_t>(c) * Gp;      // by slot: gene | pos << 16 | lo << 32 | hi << 48
 #pragma unroll 4
     for (int i = t; i < G; i += 1024) {
-        const uint32_t bw = lrow[i], sl = hist[at(bw & 0x7FFFu)] + prow[i];
+        const uint32_t bw = lrow[i], sl = HB(bw & 0x7FFFu) + prow[i];
         rem[sl] = hrow[i];
-        gen[sl] = static_cast<uint16_t>(i);
-        bs[sl] = static_cast<uint16_t>(bw);
+        if constexpr (GENL) { gen[sl] = static_cast<uint16_t>(i); bs[sl] = static_cast<uint16_t>(bw); }
+        else bg[sl] = bw | (static_cast<uint32_t>(i) << 16);
     }
     __syncthreads();
     // number of genes whose code is below cq (le: below or equal)
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
         if (cq > kmax) return static_cast<uint32_t>(G);
         uint32_t b, cr; bool exact;
         locate(cq, b, cr, exact);
-        const uint32_t s0 = hist[at(b)], s1 = hist[at(b + 1)];
+        const uint32_t s0 = HB(b), s1 = HB(b + 1);
         if (b % PER == SUB) return le ? s1 : s0;   // an equality bucket: every member is cq
         uint32_t n = 0;
         for (uint32_t q = s0; q < s1; ++q) {
@@ -671,7 +690,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
             if (r < cr) ++n;
             else if (r == cr) {
                 if (exact) n += le ? 1u : 0u;
-                else { const uint64_t k = Codec<T>::enc(col[gen[q]]); n += (k < cq || (le && k == cq)) ? 1u : 0u; }
+                else { const uint64_t k = Codec<T>::enc(col[gene_at(q)]); n += (k < cq || (le && k == cq)) ? 1u : 0u; }
             }
         }
         return s0 + n;
@@ -684,11 +703,13 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     bool tied = false;
 #pragma unroll 1
     for (int sl = t; sl < G; sl += 1024) {   // (fetching the next slot's value one iteration ahead changed nothing: 102 against 103 us)
-        const uint32_t gene = gen[sl], bw = bs[sl], b = bw & 0x7FFFu, mr = rem[sl], me = static_cast<uint32_t>(sl);
+        uint32_t gene, bw;
+        if constexpr (GENL) { gene = gen[sl]; bw = bs[sl]; } else { const uint32_t w = bg[sl]; gene = w >> 16; bw = w & 0xFFFFu; }
+        const uint32_t b = bw & 0x7FFFu, mr = rem[sl], me = static_cast<uint32_t>(sl);
         const bool exact = (bw & 0x8000u) != 0;
         const T x = col[gene];
         const uint64_t k = Codec<T>::enc(x);
-        const uint32_t s0 = hist[at(b)], s1 = hist[at(b + 1)];
+        const uint32_t s0 = HB(b), s1 = HB(b + 1);
         uint32_t l, h, p;
         if (b % PER == SUB) {  // one value: slot order
             l = s0; h = s1; p = me;
@@ -703,13 +724,13 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
                 if (r == mr && q != me) {
                     if (exact) { ++equal; before += q < me ? 1u : 0u; }
                     else if (namb < 4) amb[namb++] = q;
-                    else { const uint64_t kq = Codec<T>::enc(col[gen[q]]); smaller += kq < k ? 1u : 0u; equal += kq == k ? 1u : 0u; before += (kq == k && q < me) ? 1u : 0u; }
+                    else { const uint64_t kq = Codec<T>::enc(col[gene_at(q)]); smaller += kq < k ? 1u : 0u; equal += kq == k ? 1u : 0u; before += (kq == k && q < me) ? 1u : 0u; }
                 }
             }
             if (namb) {
                 uint64_t kq[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) kq[u] = u < static_cast<int>(namb) ? Codec<T>::enc(col[gen[amb[u]]]) : 0ULL;
+                for (int u = 0; u < 4; ++u) kq[u] = u < static_cast<int>(namb) ? Codec<T>::enc(col[gene_at(amb[u])]) : 0ULL;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (u < static_cast<int>(namb)) { smaller += kq[u] < k ? 1u : 0u; equal += kq[u] == k ? 1u : 0u; before += (kq[u] == k && amb[u] < me) ? 1u : 0u; }
@@ -877,17 +898,17 @@ template <class T, int LOGSUB, bool GENL>
 int32_t launch_sample_wide(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
 {
     constexpr size_t NB = static_cast<size_t>(kSplit1) * ((1 << LOGSUB) + 1);
-    const size_t lds = wide_lds_head(NB) + sizeof(uint16_t) * (GENL ? 2 : 1) * static_cast<size_t>(c->Gp);
+    const size_t lds = wide_lds_head(NB, !GENL) + sizeof(uint16_t) * (GENL ? 2 : 1) * static_cast<size_t>(c->Gp);
     if (lds > 160 * 1024) { set_error("t_sample_wide: %zu bytes of LDS for %d genes", lds, c->Gp); return REO_EINVAL; }
     REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample_wide<T, LOGSUB, GENL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // by-slot scratch rows of every sample (the segmented path's buffers: it is not running)
     int32_t rc;
     const size_t n = static_cast<size_t>(c->S) * c->Gp;
-    if ((rc = c->t_kin.ensure(n)) || (rc = c->t_vin.ensure(n))) return rc;
-    if (!GENL && (rc = c->t_vout.ensure(n))) return rc;
+    if ((rc = c->t_kin.ensure(n))) return rc;
+    if (GENL ? (rc = c->t_vin.ensure(n)) : (rc = c->t_vin32.ensure(n))) return rc;
     t_sample_wide<T, LOGSUB, GENL><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
                                                                                     static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, c->t_kin.p, c->t_vin.p,
-                                                                                    GENL ? nullptr : c->t_vout.p);
+                                                                                    GENL ? nullptr : c->t_vin32.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
@@ -906,16 +927,16 @@ int32_t launch_lds_ranking(reo_ctx *c, const T *X, const int32_t *d_order, int32
             return launch_sample<T, 64>(c, X, d_order, d_flags);   // (16-bit bins; the compressed histogram keeps its low-bit rows in L2)
         }
     }
-    // sub-buckets per splitter interval: what fits the LDS beside the by-slot rows -- 4 bytes per gene up to 32 768 genes, 2 above
-    // (the gene row then lives in L2)
-    auto fits = [&](int logsub) { return wide_lds_head(static_cast<size_t>(kSplit1) * ((1 << logsub) + 1)) + sizeof(uint16_t) * static_cast<size_t>(c->Gp) <= 160 * 1024; };
-    // (measured, Float64 x 1 000 samples: 24 000 genes 1.37 ms with <3, true> against 1.44 with <4, false>; 30 000 genes 2.28 with
-    //  <2, true> against 1.99 with <4, false>; 40 000 / 50 000 / 60 000 genes 2.97 / 4.54 / 7.57 ms, the library's segmented sort 8.9 at 60 000)
+    // sub-buckets per splitter interval: what fits the LDS beside the by-slot rows -- 4 bytes per gene up to 24 576 genes, 2 above
+    // (the gene ids then live in L2, packed with the bucket word, and the bins are 16-bit numbers)
+    auto fits = [&](int logsub) { return wide_lds_head(static_cast<size_t>(kSplit1) * ((1 << logsub) + 1), true) + sizeof(uint16_t) * static_cast<size_t>(c->Gp) <= 160 * 1024; };
+    // (measured, Float64 x 1 000 samples, <LOGSUB, GENL>: 20 000 genes 1.00 ms with <4, true> against 1.07 with <4, false>; 24 000 genes
+    //  1.35 against 1.34; 30 000 genes 2.28 with <2, true> (round 4's first form) against 1.80 with <4, false>; 40 000 / 50 000 / 60 000 /
+    //  65 535 genes 2.61 / 3.44 / 5.41 / 6.19 ms; the library's segmented sort: 8.9 at 60 000)
     if (G <= 20 * 1024) return launch_sample_wide<T, 4, true>(c, X, d_order, d_flags);
     if (G <= 24 * 1024) return launch_sample_wide<T, 3, true>(c, X, d_order, d_flags);
-    if (fits(4)) return launch_sample_wide<T, 4, false>(c, X, d_order, d_flags);   // (up to 41 472 genes)
-    if (fits(3)) return launch_sample_wide<T, 3, false>(c, X, d_order, d_flags);   // (up to 58 368)
-    return launch_sample_wide<T, 2, false>(c, X, d_order, d_flags);
+    if (fits(4)) return launch_sample_wide<T, 4, false>(c, X, d_order, d_flags);   // (up to 59 392 genes: 16-bit bins)
+    return launch_sample_wide<T, 3, false>(c, X, d_order, d_flags);
 }
 
 struct SegOff {
