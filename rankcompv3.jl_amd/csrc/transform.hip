@@ -685,14 +685,23 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
         const uint32_t s0 = HB(b), s1 = HB(b + 1);
         if (b % PER == SUB) return le ? s1 : s0;   // an equality bucket: every member is cq
         uint32_t n = 0;
-        for (uint32_t q = s0; q < s1; ++q) {
-            const uint32_t r = rem[q];
-            if (r < cr) ++n;
-            else if (r == cr) {
-                if (exact) n += le ? 1u : 0u;
-                else { const uint64_t k = Codec<T>::enc(col[gene_at(q)]); n += (k < cq || (le && k == cq)) ? 1u : 0u; }
-            }
+        auto same = [&](uint32_t q) -> uint32_t {   // a member with cq's 16 offset bits: equal when the bucket is narrower than 2^16 codes, else the whole key decides
+            if (exact) return le ? 1u : 0u;
+            const uint64_t k = Codec<T>::enc(col[gene_at(q)]);
+            return (k < cq || (le && k == cq)) ? 1u : 0u;
+        };
+        uint32_t q = s0;
+        for (; q < s1 && (q & 3u); ++q) { const uint32_t r = rem[q]; n += r < cr ? 1u : (r == cr ? same(q) : 0u); }
+        for (; q + 4 <= s1; q += 4) {   // four offsets per LDS access (the row is 8-byte aligned at multiples of four)
+            const uint2 w = *reinterpret_cast<const uint2 *>(rem + q);
+            const uint32_t r0 = w.x & 0xFFFFu, r1 = w.x >> 16, r2 = w.y & 0xFFFFu, r3 = w.y >> 16;
+            n += (r0 < cr ? 1u : 0u) + (r1 < cr ? 1u : 0u) + (r2 < cr ? 1u : 0u) + (r3 < cr ? 1u : 0u);
+            if (r0 == cr) n += same(q);
+            if (r1 == cr) n += same(q + 1);
+            if (r2 == cr) n += same(q + 2);
+            if (r3 == cr) n += same(q + 3);
         }
+        for (; q < s1; ++q) { const uint32_t r = rem[q]; n += r < cr ? 1u : (r == cr ? same(q) : 0u); }
         return s0 + n;
     };
     // ---- 4. pos, lo, hi, slot by slot: the lanes of a wave take CONSECUTIVE slots, i.e. members of the same or of neighbouring
@@ -738,7 +747,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
             l = s0 + smaller; h = l + equal; p = l + before;
         }
         if constexpr (std::is_same<T, double>::value) {  // the band is wider than the equal values: two more rank queries
-            l = rank_of(band_edge_code<false>(x, k), false);
+l = rank_of(band_edge_code<false>(x, k), false);
             h = rank_of(band_edge_code<true>(x, k), true);
         }
         tied |= h - l > 1u;
