@@ -851,6 +851,11 @@ def test_reoa_bundled_test_data_end_to_end(pkg, oracle, tmp_path):
     _check_result(run.result, exp)
     from oracle import reo_numpy as rn
     assert df["group1_vs_group2"].tolist() == rn.labels(exp, 1.0, 0.05).tolist()
+    # README.md:38-55 displays eleven genes, all "up": made by a predecessor of :412-416 (see
+    # tests/test_oracle.py::test_readme_quick_start_display_against_the_oracle), so not these labels -- but "up" needs z1 > 0
+    # (:428) in either version, and the GPU's z1 of those eleven genes is positive (chance: 0.49^11 = 4e-4)
+    shown = [prep["gene_names"].index(n) for n in ("DE1", "DE2", "DE3", "DE4", "DE5", "DE6", "EE19996", "EE19997", "EE19998", "EE19999", "EE20000")]
+    assert (run.result[shown, 14] > 3.0).all() and 0.45 < (run.result[:, 14] > 0).mean() < 0.55
 
 
 def test_pseudobulk_kernels_dense_and_csc(pkg, rn):

@@ -173,3 +173,50 @@ def test_tuned_table_functions_agree_with_the_plain_oracle(oracle, pkg):
             exp, eit, etr = oracle.iterate(code, ref0, 1.0, 0.05, n_iter, n_conv)
             res, it, tr = oracle.tuned_iterate(T, ref0, 1.0, 0.05, n_iter, n_conv)
             assert it == eit and tr == etr and np.array_equal(res, exp)
+
+
+README_QUICK_START_GENES = ["DE1", "DE2", "DE3", "DE4", "DE5", "DE6", "EE19996", "EE19997", "EE19998", "EE19999", "EE20000"]
+
+
+@pytest.mark.parametrize("seed", [0x5EED0001, 1, 2])
+def test_readme_quick_start_display_against_the_oracle(oracle, rn, pkg, seed):
+    """The second (and last) output of its own that the reference holds: README.md:38-55 prints
+    reoa(use_testdata="yes") -- rows 1-6 (DE1..DE6) and 19995-19999 (EE19996..EE20000), ALL ELEVEN "up".
+
+    What the current code path (src/RankCompV3.jl:396-429, restated by the oracle) gives on the same bundled files:
+    DE1..DE6 come out "no change" (padj 0.3-0.8 after the recalibration of :409-416) -- ten of the eleven displayed
+    labels differ, for every seed of the unseeded draws (ties, the 3000 random reference genes).  So the display is NOT
+    reproduced as labels, and cannot be: it was made by a version that took padj from McCullagh's OWN p-value -- the
+    line still sits there commented out, `# padj = adjust(result[:,1], BenjaminiHochberg())` (:414), and result[:,1] was
+    the pval that McCullagh_test returns (:255,405) until :415 began to overwrite it.  Two things follow that a test can
+    hold on to:
+      (1) sign: "up" needs z1 > 0 (:428) in either version.  All eleven have z1 > 0 on the converged run (3.9 ... 97);
+          49 % of all genes do, so eleven out of eleven by chance is 0.49^11 = 4e-4.  That pins the DIRECTION of
+          everything upstream of the p-value rule together: class table (:363-392), tallies (:403), McCullagh's
+          delta1 / z1 (:225-259).
+      (2) the predecessor's rule on the same state: p = two-sided normal p of z1 (:255), padj = BH(p) (:414 as it
+          was), "up" iff z1 > 0 and padj <= 0.05 -- all eleven come out "up", the README's display.
+    (The predecessor's own ITERATION -- the rule of (2) feeding :417-424 -- calls about 90 % of the genes DEGs and ends
+    with ten or eleven of the eleven "up", depending on the unseeded draws: tools/readme_predecessor_rule.py, DESIGN
+    section 2.  Its trajectory depends on those draws too much to assert more than this.)
+    """
+    import importlib
+    import os
+    from scipy import stats
+    R = importlib.import_module(pkg.__name__ + ".reoa")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    prep = R.prepare(os.path.join(gold, "fn_expr.txt"), os.path.join(gold, "fn_meta.txt"), seed=seed, use_hk_genes="no")
+    assert len(prep["gene_names"]) == 19999                       # README.md:39
+    rows = [prep["gene_names"].index(n) for n in README_QUICK_START_GENES]
+    assert rows == [0, 1, 2, 3, 4, 5, 19994, 19995, 19996, 19997, 19998]   # the displayed row numbers, 0-based
+    gid, lev = pkg.encode_groups(prep["sample_groups"])
+    res, iters, _ = oracle.identify_degs(prep["data"].astype(np.float64), gid, len(lev), 0.01, 1.0, 0.05, prep["ref"], 128, 5, seed)
+    z1 = res[:, 14]
+    assert iters < 128                                                     # converged (n_conv = 5, the default of :552)
+    assert (z1[rows] > 3.0).all(), z1[rows]                                # (1)
+    assert 0.45 < (z1 > 0).mean() < 0.55                                   # ... which is not a property of every gene
+    p_own = np.minimum(1.0, 2.0 * np.minimum(stats.norm.cdf(z1), stats.norm.sf(z1)))   # McCullagh_test's own pval (:255)
+    padj_own = rn.bh(p_own)                                                # :414 before it was commented out
+    assert ((padj_own[rows] <= 0.05) & (z1[rows] > 0)).all()               # (2): eleven times "up", as displayed
+    lab = rn.labels(res, 1.0, 0.05)                                        # the current rule: not the display
+    assert (lab[rows[:6]] == "no change").all()
