@@ -73,7 +73,8 @@ void reo_destroy(reo_ctx *ctx);
  * (a) one process, all GPUs: reo_create_multi(&ctx, n_gpus (0 = all visible), seed) returns a context that is
  *     used exactly like a one-GPU context; it drives one device context each; inside reo_build_pairs the peers pack
  *     the table words of their own pair tiles and hand them to device 0 (grouped ncclSend / ncclRecv), which unpacks
- *     them, derives the mirror words and runs the passes.  NOT yet run on more than one GPU (no such box in this
+ *     them, derives the mirror words and runs the passes.  This form is NOT pipelined (the hand-over starts when every
+ *     device has finished its tiles) and the passes run on the leader only: for throughput use (b).  NOT yet run on more than one GPU (no such box in this
  *     project's pool): the orchestration is tested with the shards sharing one device (REO_MULTI_ONE_DEVICE=1).
  * (b) one process per GPU: rank 0 calls reo_comm_unique_id and hands the 128 bytes to the other ranks by any
  *     means; every rank calls reo_comm_init_rank(ctx, id, rank, world) (ncclCommInitRank + reo_set_shard).
@@ -112,7 +113,14 @@ int32_t reo_set_allreduce(reo_ctx *ctx, reo_allreduce_fn fn, void *user);
  * other gene, src/RankCompV3.jl:386) itself.  The hook is an all-gather: `bytes_per_rank` bytes at device pointer
  * `send` of every shard have to arrive at `recv + r * bytes_per_rank` of every shard, r = the sender's shard number,
  * ordered on `stream` like the sum above (RCCL: ncclAllGather(send, recv, bytes_per_rank, ncclUint8, comm, stream)).
- * When both hooks are set this one is used. */
+ * When both hooks are set this one is used.
+ * CALLED SEVERAL TIMES PER BUILD, ON ANOTHER STREAM: with two groups the shard's pair tiles are counted in up to 8 waves
+ * (REO_EXCHANGE_WAVES, default 4) and the hook is called once per wave -- `bytes_per_rank` differs from call to call but is the
+ * same on every shard for the same call -- with `stream` = the context's EXCHANGE stream, not the stream of other calls; the
+ * ordering rule above holds per call, on the stream that call names.  Every shard must make the same number of calls: the
+ * number of waves follows from REO_EXCHANGE_WAVES / REO_K1_STAMPS / REO_K1_WAVE in the environment, which must therefore be
+ * equal on all shards (the in-library communicator checks that in reo_comm_init_rank and answers REO_EINVAL; with a caller's
+ * hook the caller has to see to it).  REO_EXCHANGE_WAVES=1: one call per build, on the context's own stream. */
 typedef int32_t (*reo_allgather_fn)(const void *send, void *recv, int64_t bytes_per_rank, void *stream, void *user);
 int32_t reo_set_allgather(reo_ctx *ctx, reo_allgather_fn fn, void *user);
 

@@ -162,6 +162,24 @@ static int32_t wait_or_drop_table(reo_ctx *c)
     return REO_EHIP;
 }
 
+// Every call that enqueues an asynchronous copy from or into CALLER memory (or a local) holds one of these: whatever way the call
+// ends -- a failing REO_HIP_CHECK between the enqueue and the wait included -- the stream has been waited for before the caller
+// gets its arrays back (include/reo_hip.h: "no host pointer is retained after return").  A call that has done its own wait
+// dismisses the guard; the extra wait of an error path costs nothing that matters.
+struct DrainOnExit {
+    reo_ctx *c;
+    bool armed = true;
+    explicit DrainOnExit(reo_ctx *ctx) : c(ctx) {}
+    DrainOnExit(const DrainOnExit &) = delete;
+    DrainOnExit &operator=(const DrainOnExit &) = delete;
+    void dismiss() { armed = false; }
+    ~DrainOnExit()
+    {
+        if (!armed || !c || !c->stream) return;
+        (void)hipStreamSynchronize(c->stream);
+    }
+};
+
 static int32_t use(reo_ctx *c)
 {
     if (!c) { set_error("null context"); return REO_EINVAL; }
@@ -193,8 +211,10 @@ static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64
         c->dX_owned.release();
     } else {
         if ((rc = c->dX_owned.ensure(static_cast<size_t>(G) * S * 8))) return rc;
+        DrainOnExit drain(c);
         REO_HIP_CHECK(hipMemcpy2DAsync(c->dX_owned.p, G * 8, X, ld * 8, G * 8, S, hipMemcpyHostToDevice, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        drain.dismiss();
         c->dX = c->dX_owned.p; c->ld = G;
     }
     return REO_OK;
@@ -413,7 +433,13 @@ void reo_destroy(reo_ctx *c)
     for (reo_ctx *p : c->peers) reo_destroy(p);
     c->peers.clear();
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);  // nothing of the communicator's is still queued when it goes
+    // Nothing of this context may still be queued or running when its buffers, its pinned mirrors (host_state, host_flags, host_ref:
+    // kernels write the first two) and its communicator go: ALL of its streams are waited for -- the pair-kernel streams and the
+    // exchange stream of the pipelined exchange as well (an error exit of launch_k1 joins them into c->stream, but a context can
+    // also be destroyed right after a failure of the join itself).
+    for (int q = 0; q < 2; ++q) if (c->k1s[q]) (void)hipStreamSynchronize(c->k1s[q]);
+    if (c->xs) (void)hipStreamSynchronize(c->xs);
+    (void)hipStreamSynchronize(c->stream);
     comm_release(c);
     collect_timings(c);
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -643,6 +669,7 @@ int32_t reo_pair_counts(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t 
     const size_t n = static_cast<size_t>(i1 - i0) * (j1 - j0) * c->ngroups;
     DevBuf<uint16_t> dg, de;
     if ((rc = dg.ensure(n)) || (rc = de.ensure(n))) return rc;
+    DrainOnExit drain(c);   // (declared after the buffers: the wait comes before their release)
     rc = launch_counts(c, i0, i1, j0, j1, dg.p, de.p);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(n_gt, dg.p, n * 2, hipMemcpyDeviceToHost, c->stream);
@@ -665,6 +692,7 @@ int32_t reo_get_codes(reo_ctx *c, int64_t i0, int64_t i1, int64_t j0, int64_t j1
     const size_t n = static_cast<size_t>(i1 - i0) * (j1 - j0);
     DevBuf<uint8_t> d;
     if ((rc = d.ensure(n))) return rc;
+    DrainOnExit drain(c);
     rc = launch_decode(c, i0, i1, j0, j1, d.p);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(code, d.p, n, hipMemcpyDeviceToHost, c->stream);
@@ -682,12 +710,14 @@ int32_t reo_tally(reo_ctx *c, const uint8_t *ref_mask, int32_t *cont)
     if ((rc = need_complete_table(c))) return rc;
     if (!ref_mask || !cont) { set_error("null argument"); return REO_EINVAL; }
     if ((rc = ensure_iter_buffers(c))) return rc;
+    DrainOnExit drain(c);   // ref_mask in, cont out
     int32_t nref = 0;
     if ((rc = upload_ref(c, ref_mask, 0, &nref))) return rc;
     if ((rc = init_state(c, nref))) return rc;
     if ((rc = launch_tally(c, nref))) return rc;
     REO_HIP_CHECK(hipMemcpyAsync(cont, c->cont.p, sizeof(int32_t) * 9 * c->G, hipMemcpyDeviceToHost, c->stream));
     REO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    drain.dismiss();
     collect_timings(c);
     return REO_OK;
 }
@@ -745,6 +775,9 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         c->host_state->cyc_period = 0;
     }
     c->it_cycle_period = 0; c->it_cycle_at = 0; c->it_cycle_skipped = 0;
+    // from here on launches are queued that write the pinned mirrors, and -- at the end -- copies into the caller's trace and result:
+    // no exit of this call leaves any of them in flight
+    DrainOnExit drain(c);
     if ((rc = launch_iter_init(c, c->host_ref, c->host_state))) return rc;
     c->it_pval_deg = pval_deg; c->it_padj_deg = padj_deg; c->it_n_iter = n_iter; c->it_n_conv = n_conv;
     c->it_a0 = static_cast<int>(a - 1); c->it_b0 = static_cast<int>(b - 1);
@@ -755,9 +788,6 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // the sorting path -- needed for the first pass, whenever the reference set changed by more genes than a tally
     // update takes, and when a quantile window lost its order statistic -- and the light path.  A batch = two
     // sorting passes, or a run of light passes; small problems sort every pass.
-    // (more than 65 535 genes: sorting passes only -- the light passes keep per-workgroup lists and sums for at most 256
-    //  workgroups of 256 genes)
-
     // light passes above 65 535 genes: the two-launch form only (its lists and block moments are sized for 1 024 workgroups of 256
     // genes; the persistent form needs every workgroup resident, the one-launch form packs 16-bit state)
     const int light_form = (G > 65535 && c->light_mode != 0) ? 1 : c->light_mode;
@@ -817,6 +847,12 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
             small = true;
             c->it_no_light = true;
         }
+        if (c->host_state->passes < passes || c->host_state->passes > n_iter) {
+            // (the device never counts past n_iter -- every pass kernel checks -- but this number sizes a copy into the CALLER's trace
+            //  array below: it is not taken on trust)
+            set_error("the iteration's pass counter reads %d after %d of %d passes: loop control fault", c->host_state->passes, passes, n_iter);
+            return REO_EHIP;
+        }
         passes = c->host_state->passes;
         seen_need_full = c->host_state->need_full;
         if (c->host_state->done || passes >= n_iter) break;  // :419-422
@@ -846,6 +882,8 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
         REO_HIP_CHECK(hipMemcpyAsync(trace, c->trace.p, sizeof(int32_t) * 2 * passes, hipMemcpyDeviceToHost, c->stream));
     const int nk2 = std::min<int>(c->k2_idx, static_cast<int>(c->modes.n));
     if (c->profiling && nk2 > 0) {
+        // (sized before the copy is enqueued and not touched again until collect_timings, behind the wait below; an error exit in
+        //  between waits through `drain`)
         c->k2_modes.assign(c->k2_idx, 0);
         REO_HIP_CHECK(hipMemcpyAsync(c->k2_modes.data(), c->modes.p, sizeof(int32_t) * nk2, hipMemcpyDeviceToHost, c->stream));
     }
@@ -871,6 +909,7 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     REO_HIP_CHECK(hipMemcpyAsync(result, c->result.p, sizeof(double) * 15 * G, hipMemcpyDeviceToHost, c->stream));
     const double w_copied = c->debug_passes ? wall_us() : 0.0;
     if ((rc = wait_or_drop_table(c))) return rc;
+    drain.dismiss();
     if (c->debug_passes) fprintf(stderr, "  result copy: enqueued in %.0f us, waited %.0f us\n", w_copied - w_copy, wall_us() - w_copied);
     collect_timings(c);
     return pass_fault(c);  // (the replay, too, derives every gene's tallies)
@@ -884,6 +923,7 @@ int32_t reo_mccullagh(reo_ctx *c, const int32_t *cont, int64_t n, double *out)
     DevBuf<int32_t> dc;
     DevBuf<double> dout;
     if ((rc = dc.ensure(n * 9)) || (rc = dout.ensure(n * 5))) return rc;
+    DrainOnExit drain(c);
     hipError_t e = hipMemcpyAsync(dc.p, cont, sizeof(int32_t) * 9 * n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         rc = launch_mccullagh(c, dc.p, n, dout.p);

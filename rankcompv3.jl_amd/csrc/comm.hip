@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <vector>
 
 #include "reo_internal.h"
 
@@ -116,6 +117,29 @@ int32_t reo_comm_init_rank(reo_ctx *c, const void *id, int32_t rank, int32_t wor
     ncclComm_t comm = nullptr;
     REO_NCCL_CHECK(ncclCommInitRank(&comm, world, u, rank));
     c->comm = comm;
+    // Every rank must issue the same sequence of collectives.  How many all-gathers a build makes (the waves of the pipelined
+    // exchange, kernels.hip launch_k1) follows from per-process switches -- REO_EXCHANGE_WAVES, REO_K1_STAMPS, REO_K1_WAVE -- so
+    // ranks started with different environments would wait for each other until the watchdog fires.  The switches are compared
+    // here, once, with the communicator's first collective (which also shows that the ranks reach each other at all).
+    const int32_t mine = c->x_waves | (c->k1_stamps ? 0x100 : 0) | (c->k1_wave ? 0x200 : 0);
+    DevBuf<int32_t> cfg;
+    if ((rc = cfg.ensure(static_cast<size_t>(world) + 1))) { comm_abort(c); return rc; }
+    std::vector<int32_t> all(static_cast<size_t>(world), 0);
+    hipError_t e = hipMemcpyAsync(cfg.p + world, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const ncclResult_t r = ncclAllGather(cfg.p + world, cfg.p, 1, ncclInt32, comm, c->stream);
+        if (r != ncclSuccess) { set_error("ncclAllGather (agreement on the exchange switches) failed: %s", ncclGetErrorString(r)); (void)hipStreamSynchronize(c->stream); comm_abort(c); return REO_ECOMM; }
+        e = hipMemcpyAsync(all.data(), cfg.p, sizeof(int32_t) * world, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e != hipSuccess) { set_error("reo_comm_init_rank: %s", hipGetErrorString(e)); (void)hipStreamSynchronize(c->stream); comm_abort(c); return REO_EHIP; }
+    if ((rc = comm_wait(c))) return rc;   // (watches the communicator: a peer that never arrives ends in REO_ECOMM, not in a hang; `mine` and `all` are locals)
+    for (int r = 0; r < world; ++r)
+        if (all[r] != mine) {
+            set_error("rank %d runs with exchange switches %#x, rank %d with %#x (REO_EXCHANGE_WAVES | REO_K1_STAMPS << 8 | REO_K1_WAVE << 9): every "
+                      "rank must be started with the same environment", rank, mine, r, all[r]);
+            comm_abort(c);
+            return REO_EINVAL;
+        }
     return REO_OK;
 }
 

@@ -3810,20 +3810,29 @@ int32_t launch_k1(reo_ctx *c, int k)
         c->table_prezeroed = false;
         c->last_k1_shared = 0;
         tic(c, 1);
-        REO_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
-        for (int q = 0; q < 2; ++q) REO_HIP_CHECK(hipStreamWaitEvent(c->k1s[q], c->ev_fork, 0));
-        REO_HIP_CHECK(hipStreamWaitEvent(c->xs, c->ev_fork, 0));
-        hipStream_t main_stream = c->stream;
+        // From the fork to the join nothing returns: whatever fails in between, the two pair-kernel streams and the exchange stream
+        // are joined into c->stream afterwards, so that everything queued on them is ordered before whatever the caller does next
+        // on the context's stream -- its waits, and reo_destroy's frees (an early return here used to leave pair and exchange
+        // kernels, or an RCCL all-gather, queued on streams that nothing waited for).  The first failure is kept in xrc.
         int32_t xrc = REO_OK;
+        auto hip_ok = [&](hipError_t e, const char *what) {
+            if (e == hipSuccess || xrc) return e == hipSuccess;
+            set_error("%s failed: %s (pipelined exchange)", what, hipGetErrorString(e));
+            xrc = e == hipErrorOutOfMemory ? REO_ENOMEM : REO_EHIP;
+            return false;
+        };
+        hipStream_t main_stream = c->stream;
+        bool forked = hip_ok(hipEventRecord(c->ev_fork, c->stream), "hipEventRecord(fork)");
+        for (int q = 0; q < 2 && forked; ++q) forked = hip_ok(hipStreamWaitEvent(c->k1s[q], c->ev_fork, 0), "hipStreamWaitEvent(fork)");
+        if (forked) forked = hip_ok(hipStreamWaitEvent(c->xs, c->ev_fork, 0), "hipStreamWaitEvent(fork)");
         for (int w = 0; w < nwaves && !xrc; ++w) {
             hipStream_t ks = c->k1s[w & 1];
             c->stream = ks;   // (the launchers below enqueue on the context's stream)
             a.items = c->k1_wave_items[w].buf.p; c->k1_items_n = c->k1_wave_items[w].n;
             if (c->k1_items_n) dispatch();
             c->stream = main_stream;
-            if (hipGetLastError() != hipSuccess) { set_error("pair kernel launch failed (wave %d)", w); xrc = REO_EHIP; break; }
-            REO_HIP_CHECK(hipEventRecord(c->ev_k1[w], ks));
-            REO_HIP_CHECK(hipStreamWaitEvent(c->xs, c->ev_k1[w], 0));
+            if (!hip_ok(hipGetLastError(), "pair kernel launch")) break;
+            if (!hip_ok(hipEventRecord(c->ev_k1[w], ks), "hipEventRecord(wave)") || !hip_ok(hipStreamWaitEvent(c->xs, c->ev_k1[w], 0), "hipStreamWaitEvent(wave)")) break;
             const int m0 = w * mw, mc = std::max(0, std::min(mw, maxu_x - m0));
             if (mc == 0) continue;
             uint32_t *send = c->xsend.p + uw * mw * w, *recv = c->xrecv.p + uw * mw * w * c->world;
@@ -3837,16 +3846,19 @@ int32_t launch_k1(reo_ctx *c, int k)
             if ((xrc = launch_expand_units(c, m0, mc, recv, c->xs))) break;
         }
         // join: the pair kernels first (their makespan is the K1 stage time), then the exchange stream (what is left of it: the
-        // exposed part of the exchange)
-        for (int q = 0; q < 2; ++q) {
-            REO_HIP_CHECK(hipEventRecord(c->ev_k1_join[q], c->k1s[q]));
-            REO_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_k1_join[q], 0));
-        }
+        // exposed part of the exchange).  A join that cannot even be queued falls back to host waits for the side streams.
+        bool joined = true;
+        for (int q = 0; q < 2; ++q)
+            if (hipEventRecord(c->ev_k1_join[q], c->k1s[q]) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_k1_join[q], 0) != hipSuccess) joined = false;
         toc(c);
         tic(c, 6);
-        REO_HIP_CHECK(hipEventRecord(c->ev_x, c->xs));
-        REO_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_x, 0));
+        if (hipEventRecord(c->ev_x, c->xs) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_x, 0) != hipSuccess) joined = false;
         toc(c);
+        if (!joined) {
+            for (int q = 0; q < 2; ++q) (void)hipStreamSynchronize(c->k1s[q]);
+            (void)hipStreamSynchronize(c->xs);
+            if (!xrc) { set_error("joining the streams of the pipelined exchange failed"); xrc = REO_EHIP; }
+        }
         if (xrc) return xrc;
         c->x_pipelined = true;
         return REO_OK;

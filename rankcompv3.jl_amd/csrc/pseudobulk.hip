@@ -120,6 +120,7 @@ int32_t run_dense(reo_ctx *c, const T *X, int64_t G, int64_t C, int64_t ld, cons
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dOut.p, static_cast<size_t>(G) * n_out * sizeof(T), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);   // nothing queued reads or writes the caller's arrays (or these buffers) after return
     dX.release(); dOut.release(); dOrd.release(); dPtr.release();
     if (e != hipSuccess) { set_error("pseudobulk (dense) failed: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? REO_ENOMEM : REO_EHIP; }
     collect_timings(c);
@@ -153,6 +154,7 @@ int32_t run_csc(reo_ctx *c, int64_t G, int64_t C, const int64_t *colptr, const i
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dOut.p, static_cast<size_t>(G) * n_out * sizeof(T), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);   // nothing queued reads or writes the caller's arrays (or these buffers) after return
     dCp.release(); dRi.release(); dVal.release(); dOut.release(); dOrd.release(); dPtr.release();
     if (e != hipSuccess) { set_error("pseudobulk (CSC) failed: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? REO_ENOMEM : REO_EHIP; }
     collect_timings(c);

@@ -18,7 +18,7 @@ constexpr int kPlanes = 4;    // cL cH tL tH
 constexpr int kUnitH = 32;    // i-tiles per K1 work unit
 constexpr int kRJ = 4;        // genes j per lane in the tie-free pair kernel
 constexpr int kRJTies = 2;    // genes j per lane in the tie-rich pair kernel (two band edges per pair)
-constexpr int kMaxGenes = 262143;  // 18 position planes; above 65 535 genes: sorting passes only
+constexpr int kMaxGenes = 262143;  // 18 position planes (above 65 535 genes: 32-bit transform rows, k1w_pairs<17/18>, light passes in the two-launch form)
 constexpr int kGenePad = 1024;  // Gp is a multiple of this (= kTileJ * kRJ: every lane's genes exist)
 constexpr int kRaw = 8;       // raw tally counters per gene (see k2_tally)
 constexpr int kDeltaMax = 128;   // at most this many changed reference genes: update the tallies incrementally
@@ -75,6 +75,7 @@ constexpr int kHistParts = 8;   // partial histograms of the BH ranks, one per X
 constexpr int kSpread = 8;
 constexpr int kListCap = 16;   // genes near the BH cut that one workgroup of kl_rank can list
 constexpr int kListWgs = 1024;  // workgroups of 256 genes that the lists and the block moments are sized for (262 144 genes)
+static_assert(kMaxGenes <= kListWgs * 256, "the light passes' lists and block moments (clist, part) hold kListWgs workgroups of 256 genes");
 constexpr int kPartPer = kListWgs / 256;  // block moments per thread when every workgroup combines all of them
 constexpr int kListStride = kListWgs + kListWgs * kListCap * 2;  // int32 per parity: counts by workgroup, then (word, gene) pairs
 constexpr int kOneListCap = 16;   // one-launch form (kl_one): genes that one workgroup can list per pass ...

@@ -108,11 +108,14 @@ def pseudobulk_group(values: np.ndarray, n_pseudo: int, g_name: str, seed: int, 
 
 def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: int = 0, n_pseudo: int = 0,
             use_hk_genes: str = "yes", hk_file: str | None = None, gene_name_type: str = "ENSEMBL",
-            ref_gene_max: int = 3000, ref_gene_min: int = 100, seed: int = 0, sums=host_sums, align_meta: bool = False):
+            ref_gene_max: int = 3000, ref_gene_min: int = 100, seed: int = 0, sums=host_sums, align_meta: bool | None = None):
     """Everything `reoa` does before `identify_degs` (:565-651).  Returns a dict with the expression
     matrix (genes x samples), the sample table (Name, Group), gene names, group levels and the reference mask.
-    `align_meta` (not in the reference): look every expression column's group up by sample name instead of taking the
-    meta rows in their own order, which is what the reference does (:653) and the default here."""
+    `align_meta` (not in the reference) only matters when the rows of the meta table are NOT in the order of the matrix's columns.
+    The reference then labels column t with the group of meta row t whatever the names say (:653) -- mislabelled samples, wrong
+    DEGs, no message.  Here that case must be decided by the caller: None (the default) raises ArgumentError and names the two
+    choices; False = the reference's behaviour (row t labels column t), with a warning; True = look every column's group up by
+    sample name."""
     import pandas as pd
     if not (os.path.isfile(fn_expr) and os.path.isfile(fn_meta)):  # :565
         raise ArgumentError(f"{fn_expr}, or {fn_meta}, does not exist or is not a regular file.")
@@ -177,10 +180,18 @@ def prepare(fn_expr: str, fn_meta: str, *, min_profiles: int = 0, min_features: 
                 raise ArgumentError("Expression matrix has sample columns that the meta data does not describe")
         else:
             sample_groups = list(kept["Group"])
-            if list(kept["Name"]) != sample_names:
+            if list(kept["Name"]) != sample_names and len(kept) == len(sample_names) and set(kept["Name"]) == set(sample_names):
+                # the same samples in another order: the reference would silently label column t with meta row t (:653)
+                if align_meta is None:
+                    raise ArgumentError("the rows of the meta table are not in the order of the expression matrix's columns.  The reference "
+                                        "(src/RankCompV3.jl:653) labels column t with the group of meta row t whatever the sample names say, "
+                                        "which mislabels samples here.  Pass align_meta=True to match samples by name, or align_meta=False "
+                                        "to do exactly what the reference does.")
                 log.warning("WARN: the rows of the meta table are not in the order of the expression matrix's columns; like the "
-                            "reference (src/RankCompV3.jl:653) the group of row t labels column t.  Pass align_meta=True to "
-                            "match samples by name instead.")
+                            "reference (src/RankCompV3.jl:653) the group of row t labels column t (align_meta=False).")
+            elif list(kept["Name"]) != sample_names:
+                log.warning("WARN: the meta table does not describe the expression matrix's columns one to one; like the reference "
+                            "(src/RankCompV3.jl:653) the group of row t labels column t.  Pass align_meta=True to match samples by name instead.")
     inds = (data > 0).sum(axis=1) > min_features  # :626
     gene_names = [n for n, k in zip(gene_names, inds) if k]
     data = data[inds, :]
@@ -263,7 +274,7 @@ def reoa(fn_expr: str = "fn_expr.txt", fn_meta: str = "fn_meta.txt", *, expr_thr
          min_features: int = 0, pval_reo: float = 0.01, pval_deg: float = 1.0, padj_deg: float = 0.05,
          n_pseudo: int = 0, use_hk_genes: str = "yes", hk_file: str | None = None, gene_name_type: str = "ENSEMBL",
          ref_gene_max: int = 3000, ref_gene_min: int = 100, n_iter: int = 128, n_conv: int = 5, work_dir: str = "./",
-         use_testdata: str = "no", seed: int = 0, device: int = -1, testdata_dir: str | None = None, align_meta: bool = False):
+         use_testdata: str = "no", seed: int = 0, device: int = -1, testdata_dir: str | None = None, align_meta: bool | None = None):
     """reoa(fn_expr, fn_meta; kwargs...) -- src/RankCompV3.jl:536-555.  `expr_threshold` is accepted and
     unused, as in the reference (:539).  Extra keywords: `seed` (the reference's RNG is unseeded),
     `device`, `testdata_dir` (where fn_expr.txt / fn_meta.txt of the reference's test/ directory live), `align_meta`

@@ -159,9 +159,11 @@ def test_df_meta_keeps_the_meta_files_own_row_and_column_order(R, tmp_path):
     file's own row order (here not the expression matrix's column order) and column order survive."""
     e = _write(tmp_path, "e.tsv", "gene\ts1\ts2\ts3\ts4\nA\t1\t0\t3\t4\nB\t1\t0\t5\t6\nC\t2\t0\t1\t1\n")
     m = _write(tmp_path, "m.tsv", "sample\tgrp\tbatch\ns4\ty\tb2\ns2\tx\tb2\ns1\tx\tb1\ns3\ty\tb1\n")
-    p = R.prepare(e, m, use_hk_genes="no")            # s2 has no expressed gene: dropped by the profile filter
+    with pytest.raises(R.ArgumentError, match="align_meta"):   # the silent-wrong-answer case must be decided by the caller
+        R.prepare(e, m, use_hk_genes="no")
+    p = R.prepare(e, m, use_hk_genes="no", align_meta=False)   # s2 has no expressed gene: dropped by the profile filter
     # like the reference (:653) the groups are the meta rows' in THEIR order -- row t labels column t, names unchecked --
-    # so this meta table mislabels s1 and s4 there and here (a warning says so) ...
+    # so this meta table mislabels s1 and s4 there and, with align_meta=False, here (a warning says so) ...
     assert p["sample_names"] == ["s1", "s3", "s4"] and p["sample_groups"] == ["y", "x", "y"]
     assert list(p["meta"].columns) == ["Name", "Group", "batch"]
     assert p["meta"]["Name"].tolist() == ["s4", "s1", "s3"] and p["meta"]["batch"].tolist() == ["b2", "b1", "b1"]
@@ -171,15 +173,21 @@ def test_df_meta_keeps_the_meta_files_own_row_and_column_order(R, tmp_path):
     assert q["meta"]["Name"].tolist() == ["s4", "s1", "s3"]
 
 
-def test_meta_rows_in_another_order_warn_and_fewer_rows_than_columns_fail(R, pkg, tmp_path, caplog):
-    """:653 hands meta_group.Group to identify_degs as it stands; a meta table that describes fewer profiles than the matrix has
-    columns fails there with DimensionMismatch (:355)."""
+def test_meta_rows_in_another_order_must_be_decided_and_fewer_rows_than_columns_fail(R, pkg, tmp_path, caplog):
+    """:653 hands meta_group.Group to identify_degs as it stands: with a permuted meta table that mislabels samples without a
+    word.  Here the caller has to choose (align_meta=None raises; False = the reference's behaviour + a warning; True = by name).
+    A meta table that describes fewer profiles than the matrix has columns fails in identify_degs with DimensionMismatch (:355)."""
     import logging
     e = _write(tmp_path, "e.tsv", "gene\ts1\ts2\ts3\ts4\nA\t1\t2\t3\t4\nB\t1\t1\t5\t6\n")
     m = _write(tmp_path, "m.tsv", "sample\tgrp\ns2\tx\ns1\ty\ns3\tx\ns4\ty\n")
+    with pytest.raises(R.ArgumentError, match="align_meta=True"):
+        R.prepare(e, m, use_hk_genes="no")
     with caplog.at_level(logging.WARNING):
-        p = R.prepare(e, m, use_hk_genes="no")
+        p = R.prepare(e, m, use_hk_genes="no", align_meta=False)
     assert p["sample_groups"] == ["x", "y", "x", "y"] and any("not in the order" in r.message for r in caplog.records)
+    assert R.prepare(e, m, use_hk_genes="no", align_meta=True)["sample_groups"] == ["y", "x", "x", "y"]   # s1 -> y, s2 -> x, by name
+    ordered = _write(tmp_path, "m_ordered.tsv", "sample\tgrp\ns1\ty\ns2\tx\ns3\tx\ns4\ty\n")
+    assert R.prepare(e, ordered, use_hk_genes="no")["sample_groups"] == ["y", "x", "x", "y"]             # in order: nothing to decide
     m2 = _write(tmp_path, "m2.tsv", "sample\tgrp\ns1\tx\ns3\ty\n")   # s2, s4 undescribed: 2 labels for 4 columns
     p2 = R.prepare(e, m2, use_hk_genes="no")
     assert len(p2["sample_groups"]) == 2 and p2["data"].shape[1] == 4
