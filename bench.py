@@ -80,7 +80,8 @@ def main() -> None:
     ap.add_argument("--no-float64", action="store_true", help="skip the Float64-input block")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE config 4 block (30 000 x 4 000)")
     ap.add_argument("--no-cycle-watch", action="store_true", help="skip the blocks that time the library's default (cycle watch on)")
-    ap.add_argument("--cpu-genes", type=int, default=8000)
+    ap.add_argument("--no-from-host", action="store_true", help="skip the from_host block (the drop-in call: the matrix starts in pageable host memory)")
+    ap.add_argument("--cpu-genes", type=int, default=8000, help="R1 sample size when the host has too few cores for the whole workload")
     ap.add_argument("--debug-gloo-one-gpu", action="store_true",
                     help="debug only: every rank uses cuda:0 and the table exchange goes through gloo via the host")
     args = ap.parse_args()
@@ -153,6 +154,48 @@ def main() -> None:
                     dist.broadcast_object_list(box, src=0)
                     ctx.comm_init_rank(box[0], rank, world)
         return ctx
+
+    def table_and_trace_hash(ctx_, G_, ref_, n_iter_=8):
+        """64-bit hash of the whole class table (every ordered pair's class, reo_get_codes) and of the iteration's trace + tallies"""
+        import hashlib
+        h = hashlib.blake2b(digest_size=8)
+        for i0 in range(0, G_, 1024):
+            h.update(ctx_.get_codes(i0, min(G_, i0 + 1024), 0, G_).tobytes())
+        res_, it_, tr_ = ctx_.identify_degs(ref_, 1.0, 0.05, n_iter_, 0)
+        h.update(np.asarray(tr_, dtype=np.int64).tobytes()); h.update(np.ascontiguousarray(res_[:, 2:11]).tobytes())
+        return h.hexdigest()
+
+    sharded_ok = None
+    if world > 1 or force_comm:
+        # The first run with more than one rank must not produce a number from a wrong table: before anything is timed every rank
+        # builds a small problem sharded (the exchange that the timed steps use), rank 0 builds it unsharded as well, and the hashes
+        # of the whole class table + an 8-pass trace + the tallies must agree across ranks and with the unsharded run.
+        Gs_, Ss_, seeds_ = 9000, 64, 0x5EED00C4
+        Xs_ = pkg.synth.t1_counts(Gs_, Ss_, seeds_)
+        gids_, levs_ = pkg.encode_groups(pkg.synth.groups(Ss_))
+        refs_ = pkg.synth.ref_mask(Gs_, 2000, seeds_)
+        def small(ctx_):
+            ctx_.set_matrix(Xs_); ctx_.set_groups(gids_, len(levs_)); ctx_.compute_thresholds(0.01); ctx_.build_pairs(0)
+            return table_and_trace_hash(ctx_, Gs_, refs_)
+        ctxs_ = make_ctx()
+        mine_ = small(ctxs_)
+        ctxs_.close()
+        if rank == 0:
+            ctxu_ = pkg.Context(device=local, seed=seed)
+            whole_ = small(ctxu_)
+            ctxu_.close()
+        else:
+            whole_ = None
+        allh_ = [None] * world
+        dist.all_gather_object(allh_, (mine_, whole_))
+        sharded_ok = all(h[0] == allh_[0][1] for h in allh_)
+        if not sharded_ok:
+            if rank == 0:
+                print(json.dumps({"metric": "gene-pair·sample comparisons/sec at 20k genes × 1k samples", "value": None, "n_gpus": world,
+                                  "sharded_equals_unsharded": False, "hashes_sharded_by_rank": [h[0] for h in allh_], "hash_unsharded": allh_[0][1],
+                                  "error": "the sharded class table / trace differs from the unsharded one: nothing was timed"}))
+            dist.destroy_process_group()
+            raise SystemExit(3)
 
     step_walls = {}   # per-step wall times of every timed leg (ms): the blocks report their median beside the mean
 
@@ -281,6 +324,7 @@ def main() -> None:
         dist.all_gather_object(allr, mine)
         rep = (mine["transform_ms"] + mine["iter_ms"]) / (dt / args.steps * 1e3)
         out["ranks"] = allr
+        out["sharded_equals_unsharded"] = sharded_ok   # checked before timing on 9000 x 64 (class table + 8-pass trace + tallies, every rank)
         out["replicated_stage_share"] = rep     # transform + iteration passes run identically on every rank
         out["collective"] = ("one ncclAllGather per reo_build_pairs, in-library RCCL: every rank sends the forward words of its own pair "
                              "tiles (about %d MB over all ranks; the whole table is %d MB), mirror words are derived on arrival; "
@@ -362,25 +406,96 @@ def main() -> None:
         if pr4:
             out["config4"]["ranks"] = pr4
 
+    if not args.no_from_host and world == 1 and args.family == "t0" and (G, S) == (20000, 1000):
+        # The DROP-IN call: what julia/RankCompV3HIP.jl (and tests/abi/abi_client.c) does at :652 -- the matrix is a pageable
+        # column-major HOST array handed to reo_set_matrix_i64 / _f64.  `value` above never includes this (inputs resident in HBM);
+        # this block says what it costs and how much of it the library hides behind the transform and the pair kernel (groups and
+        # thresholds are set BEFORE the matrix, so reo_set_matrix can rank samples and start the pair kernel's group-1 side while
+        # the rest of the matrix is still on its way).  PCIe spec of the box: 63 GB/s.
+        def from_host(family, Gh, Sh, seedh, steps_h, compute_ms):
+            os.environ["REO_CYCLE"] = "0"
+            gen = {"t0": pkg.synth.t0_ranks, "float": pkg.synth.float_expr}[family]
+            Xh = np.asfortranarray(gen(Gh, Sh, seedh))                       # column-major, pageable: what a Julia Matrix is
+            gidh, levh = pkg.encode_groups(pkg.synth.groups(Sh))
+            refh = pkg.synth.ref_mask(Gh, 3000, seedh)
+            nbytes = Xh.nbytes
+            def call(ctx_, eager=True):
+                if eager:
+                    ctx_.set_groups(gidh, len(levh)); ctx_.compute_thresholds(0.01); ctx_.set_matrix(Xh)
+                else:   # the order of rounds 1-4: the matrix first -- nothing can start before it has arrived
+                    ctx_.set_matrix(Xh); ctx_.set_groups(gidh, len(levh)); ctx_.compute_thresholds(0.01)
+                ctx_.build_pairs(0)
+                return ctx_.identify_degs(refh, 1.0, 0.05, args.n_iter, 0)
+            def timed_walls(fn, n):
+                gc.collect(); gc.disable()
+                w = []
+                for _ in range(n):
+                    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); w.append((time.perf_counter() - t0) * 1e3)
+                gc.enable()
+                return w, r
+            ctxh = pkg.Context(device=local, seed=seedh)
+            plain = pkg.Context(device=local, seed=seedh)                      # (no groups set: reo_set_matrix is the upload alone)
+            plain.set_matrix(Xh)
+            up_w, _ = timed_walls(lambda: plain.set_matrix(Xh), max(3, steps_h))
+            plain.close()
+            call(ctxh); call(ctxh, eager=False)
+            seq_w, rseq = timed_walls(lambda: call(ctxh, eager=False), steps_h)
+            pip_w, rpip = timed_walls(lambda: call(ctxh), steps_h)
+            ctxh.close()
+            def whole_call():                                                  # a context per call, as the Julia shim does it
+                with pkg.Context(device=local, seed=seedh) as c_:
+                    return call(c_)
+            whole_call()
+            all_w, _ = timed_walls(whole_call, steps_h)
+            med = lambda v: float(np.median(v))
+            up = med(up_w)
+            return {"workload": f"{Gh} x {Sh} {'Float64' if Xh.dtype == np.float64 else 'Int64'} from a pageable column-major host array, n_iter={args.n_iter}, n_conv=0, every pass executed",
+                    "upload_ms": up, "upload_GBps": nbytes / up / 1e6, "upload_frac_of_pcie_63GBps": nbytes / up / 1e6 / 63.0, "matrix_MB": nbytes / 1e6,
+                    "compute_ms_device_resident": compute_ms,
+                    "ms_per_step": med(pip_w), "ms_per_step_matrix_first": med(seq_w), "ms_per_call_with_create_and_destroy": med(all_w),
+                    "sum_upload_compute_ms": up + compute_ms, "max_upload_compute_ms": max(up, compute_ms),
+                    "ratio_to_max": med(pip_w) / max(up, compute_ms), "ratio_to_sum": med(pip_w) / (up + compute_ms),
+                    "value": (Gh * (Gh - 1) // 2) * Sh / (med(pip_w) * 1e-3), "steps": steps_h, "walls_ms": [round(x, 3) for x in pip_w],
+                    "same_result_both_orders": bool(np.array_equal(rseq[0], rpip[0], equal_nan=True) and rseq[2] == rpip[2])}
+        sth = max(3, args.steps // 4)
+        out["from_host"] = {"config3_int64": from_host("t0", G, S, seed, sth, out["ms_per_step"])}
+        if "float64" in out:
+            out["from_host"]["config3_float64"] = from_host("float", G, S, seed, sth, out["float64"]["ms_per_step"])
+        if "config4" in out:
+            out["from_host"]["config4_int64"] = from_host("t0", 30000, 4000, 0x5EED0004, 3, out["config4"]["ms_per_step"])
+
     out["step_walls_ms"] = {"%s n_conv=%d cycle=%s G=%d" % k: [round(w, 3) for w in v] for k, v in step_walls.items()}   # (every timed leg, per step)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         oracle = ge.load_oracle()
-        refs_all = ref0.copy()
-        samples = []
-        for Gs in (args.cpu_genes // 2, args.cpu_genes):   # two sizes: the rate per comparison must not depend on G (G^2 S scaling)
-            Gs = min(Gs, G)
-            Xs = X[:Gs].astype(np.float64)
-            refs = refs_all[:Gs].copy(); refs[:10] = True
+        ncores = oracle.num_threads()
+        if ncores >= 32:
+            # R1 on the WHOLE config-3 workload (about 45 s on 128 threads): no sub-sampling, and its trace must be the GPU's
             t0 = time.perf_counter()
-            oracle.identify_degs(Xs, gid, len(lev), 0.01, 1.0, 0.05, refs, args.n_iter, 0, seed)
+            r1res, it1r, tr1r = oracle.identify_degs(X.astype(np.float64), gid, len(lev), 0.01, 1.0, 0.05, ref0, args.n_iter, 0, seed)
             tc = time.perf_counter() - t0
-            samples.append({"genes": Gs, "seconds": tc, "rate": (Gs * (Gs - 1) // 2) * S / tc})
-        big = samples[-1]
-        out["cpu_baseline"] = {"value": big["rate"], "unit": "comparisons/s", "cores": oracle.num_threads(), "kind": "port",
-                               "seconds": big["seconds"], "cpu": cpu_model(), "julia": shutil.which("julia") or "not found",
-                               "sample": f"first {big['genes']} genes x {S} samples of the same matrix, full identify_degs "
-                                         f"(n_iter={args.n_iter}, n_conv=0), C restatement of the reference's loop nest with OpenMP",
-                               "scaling_check": {"sizes": samples, "rate_ratio_big_over_small": big["rate"] / samples[0]["rate"]}}
+            out["cpu_baseline"] = {"value": units / tc, "unit": "comparisons/s", "cores": ncores, "kind": "port", "seconds": tc, "cpu": cpu_model(),
+                                   "julia": shutil.which("julia") or "not found",
+                                   "sample": f"whole workload: all {G} genes x {S} samples, full identify_degs (n_iter={args.n_iter}, n_conv=0), "
+                                             "C restatement of the reference's loop nest with OpenMP",
+                                   "same_trace_as_gpu": bool(tr1r == trace and it1r == iters),
+                                   "same_tallies_as_gpu": bool(np.array_equal(r1res[:, 2:11], res[:, 2:11]))}
+        else:
+            refs_all = ref0.copy()
+            samples = []
+            for Gs in (args.cpu_genes // 2, args.cpu_genes):   # two sizes: the rate per comparison must not depend on G (G^2 S scaling)
+                Gs = min(Gs, G)
+                Xs = X[:Gs].astype(np.float64)
+                refs = refs_all[:Gs].copy(); refs[:10] = True
+                t0 = time.perf_counter()
+                oracle.identify_degs(Xs, gid, len(lev), 0.01, 1.0, 0.05, refs, args.n_iter, 0, seed)
+                tc = time.perf_counter() - t0
+                samples.append({"genes": Gs, "seconds": tc, "rate": (Gs * (Gs - 1) // 2) * S / tc})
+            big = samples[-1]
+            out["cpu_baseline"] = {"value": big["rate"], "unit": "comparisons/s", "cores": ncores, "kind": "port",
+                                   "seconds": big["seconds"], "cpu": cpu_model(), "julia": shutil.which("julia") or "not found",
+                                   "sample": f"first {big['genes']} genes x {S} samples of the same matrix (fewer than 32 host threads: the whole workload "
+                                             f"would take minutes), full identify_degs (n_iter={args.n_iter}, n_conv=0), C restatement of the reference's loop nest with OpenMP",
+                                   "scaling_check": {"sizes": samples, "rate_ratio_big_over_small": big["rate"] / samples[0]["rate"]}}
         if hasattr(oracle, "tuned_identify_degs"):  # R2: fast enough for the whole workload, no sub-sampling
             t0 = time.perf_counter()
             r2, it2, tr2 = oracle.tuned_identify_degs(X.astype(np.float64), gid, len(lev), 0.01, 1.0, 0.05, ref0, args.n_iter, 0, seed)

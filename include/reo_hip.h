@@ -127,9 +127,18 @@ int32_t reo_set_allgather(reo_ctx *ctx, reo_allgather_fn fn, void *user);
 /* Expression matrix, G genes x S samples, column-major with leading dimension
  * ld >= G: the `data` argument of identify_degs (src/RankCompV3.jl:340) as
  * Matrix(df_expr) produces it (:652), eltype Float64 or Int64.  G must be in [2, 262143] and S in [2, 1048576];
- * with more than two groups G and S may not both exceed 65535; values must be finite.  *_host copies from host memory;
- * *_dev uses a buffer already resident in HBM (it must stay valid until
- * reo_build_pairs returns). */
+ * with more than two groups G and S may not both exceed 65535; values must be finite.  reo_set_matrix_f64 / _i64
+ * copy from host memory (pageable is fine) and have read all of it when they return; *_dev uses a buffer already resident in HBM (it
+ * must stay valid until reo_build_pairs returns).
+ * ORDER OF CALLS.  Any order of reo_set_matrix_*, reo_set_groups, reo_compute_thresholds works.  From HOST memory the cheap order is
+ * groups and thresholds FIRST, the matrix last: the call then uploads the columns in chunks and pipelines them with the rest of
+ * the work -- the samples of a chunk are ranked while the next chunk is crossing PCIe, and with two groups on one GPU the pair
+ * kernel's items of a group (its "side" of every pair) start as soon as that group's last column has been ranked, while the other
+ * group is still on its way.  The call still returns only when the whole matrix has been read (no host pointer is retained); the pair
+ * kernel may be running then, exactly as after reo_build_pairs on one GPU, and the reo_build_pairs(ctx, 0) that follows has nothing
+ * left to do (it is still the call that makes the class table current: keep it).  Results are bit-identical in every order.  A
+ * non-finite value is reported (REO_EINVAL) by whichever call reads the matrix: this one in the pipelined case.
+ * REO_EAGER_UPLOAD=0 in the environment switches the pipelining off, =1 keeps it to the ranking. */
 int32_t reo_set_matrix_f64(reo_ctx *ctx, const double *X, int64_t G, int64_t S, int64_t ld);
 int32_t reo_set_matrix_i64(reo_ctx *ctx, const int64_t *X, int64_t G, int64_t S, int64_t ld);
 int32_t reo_set_matrix_dev_f64(reo_ctx *ctx, const void *dX, int64_t G, int64_t S, int64_t ld);
@@ -227,7 +236,8 @@ int32_t reo_pseudobulk_csc_i64(reo_ctx *ctx, int64_t G, int64_t C, const int64_t
  * statistics kernels K3, sum), 4 number of K2 launches (passes enqueued after
  * convergence return at once and are counted too), 5 number of K1 launches,
  * 6 exchange of the class table between shards (HIP events), 7 pseudo-bulk kernel, 8 K2 stage of the passes that scanned the whole table (sum), 9 their
- * number, 10 K2 stage of the passes that updated the tallies incrementally (sum). */
+ * number, 10 K2 stage of the passes that updated the tallies incrementally (sum), 11 host wall time inside reo_set_matrix_f64 / _i64
+ * (the upload from host memory, with whatever was pipelined behind it). */
 enum { REO_NTIMINGS = 12 };
 int32_t reo_set_profiling(reo_ctx *ctx, int32_t on);
 int32_t reo_reset_timings(reo_ctx *ctx);

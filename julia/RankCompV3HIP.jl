@@ -30,6 +30,10 @@ function identify_degs(data::AbstractMatrix, group::AbstractVector, gene_names::
         check(ccall((:reo_create_multi, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, UInt64), ctx, n_gpus, seed))
     end
     try
+        # groups and thresholds BEFORE the matrix: reo_set_matrix_* then ranks samples as their columns arrive and starts the
+        # pair kernel's group-1 side while group 2 is still on its way over PCIe (include/reo_hip.h)
+        check(ccall((:reo_set_groups, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int64, Int32), ctx[], gid, c, length(glev)))
+        check(ccall((:reo_compute_thresholds, LIB), Int32, (Ptr{Cvoid}, Float64), ctx[], pval_reo))           # :362
         if eltype(data) <: Integer
             X = Matrix{Int64}(data)
             check(ccall((:reo_set_matrix_i64, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Int64, Int64), ctx[], X, r, c, r))
@@ -37,8 +41,6 @@ function identify_degs(data::AbstractMatrix, group::AbstractVector, gene_names::
             X = Matrix{Float64}(data)
             check(ccall((:reo_set_matrix_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64), ctx[], X, r, c, r))
         end
-        check(ccall((:reo_set_groups, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int64, Int32), ctx[], gid, c, length(glev)))
-        check(ccall((:reo_compute_thresholds, LIB), Int32, (Ptr{Cvoid}, Float64), ctx[], pval_reo))           # :362
         res = Matrix{Any}(reshape(gene_names, r, 1))
         ref0 = UInt8.(ref_gene)
         for k in 1:length(glev)                                                                               # :396

@@ -355,7 +355,7 @@ class Context:
         check(self._L.reo_get_timings(self._h, _ptr(ms), NTIMINGS))
         return {"transform_ms": ms[0], "k1_ms": ms[1], "k2_ms": ms[2], "iter_ms": ms[3], "k3_ms": max(ms[3] - ms[2], 0.0), "k2_launches": int(ms[4]),
                 "k1_launches": int(ms[5]), "exchange_ms": ms[6], "pseudobulk_ms": ms[7], "k2_full_ms": ms[8],
-                "k2_full_launches": int(ms[9]), "k2_delta_ms": ms[10]}
+                "k2_full_launches": int(ms[9]), "k2_delta_ms": ms[10], "set_matrix_host_wall_ms": ms[11]}
 
     def info(self) -> dict:
         v = np.zeros(19, dtype=np.int64)

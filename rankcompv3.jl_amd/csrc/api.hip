@@ -192,6 +192,7 @@ static void invalidate(reo_ctx *c)
     c->transformed = false;
     c->built_k = -1;
     c->gc_valid = false;
+    c->eager_k1 = false;
 }
 
 static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64_t ld, int dtype, bool on_device)
@@ -211,11 +212,35 @@ static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64
         c->dX_owned.release();
     } else {
         if ((rc = c->dX_owned.ensure(static_cast<size_t>(G) * S * 8))) return rc;
+        c->dX = c->dX_owned.p; c->ld = G;
+        // Groups already set (the order the Julia shim and hotpath.py use): the upload is pipelined with the per-sample transform
+        // and -- two groups, thresholds set, one GPU -- with the pair kernel's group-0 side (transform.hip, eager_upload).
+        const bool lds_ranking = G <= 65535 && !(getenv("REO_TRANSFORM") && getenv("REO_TRANSFORM")[0] == 's');
+        if (c->eager_mode > 0 && lds_ranking && static_cast<int64_t>(c->group_id.size()) == S && !c->in_multi) {
+            const bool k1 = c->eager_mode > 1 && c->ngroups == 2 && c->thr_set && c->world <= 1 && !c->comm && !c->ag && !c->ar && c->k1_wave &&
+                            S <= 65535 && !c->k1_stamps;
+            c->Gp = static_cast<int>((c->G + kGenePad - 1) / kGenePad) * kGenePad;
+            c->Wp = c->Gp / 32;
+            if ((rc = c->table.ensure(static_cast<size_t>(c->G) * kPlanes * c->Wp))) return rc;
+            const double w0 = wall_us();
+            struct DrainUp {   // no exit leaves a copy from the caller's array in flight (the upload stream; c->stream has its own guard below)
+                reo_ctx *c;
+                ~DrainUp() { if (c->up) (void)hipStreamSynchronize(c->up); }
+            } drain_up{c};
+            DrainOnExit drain(c);
+            rc = eager_upload(c, X, ld, k1);
+            if (rc) { invalidate(c); return rc; }
+            drain.dismiss();   // (the pair kernel may still be running, as after reo_build_pairs on one GPU: it reads device memory only)
+            c->t_ms[11] += (wall_us() - w0) * 1e-3;
+            if (c->eager_k1) { c->built_k = 0; c->table_complete = true; }
+            return REO_OK;
+        }
         DrainOnExit drain(c);
+        const double w0 = wall_us();
         REO_HIP_CHECK(hipMemcpy2DAsync(c->dX_owned.p, G * 8, X, ld * 8, G * 8, S, hipMemcpyHostToDevice, c->stream));
         REO_HIP_CHECK(hipStreamSynchronize(c->stream));
         drain.dismiss();
-        c->dX = c->dX_owned.p; c->ld = G;
+        c->t_ms[11] += (wall_us() - w0) * 1e-3;
     }
     return REO_OK;
 }
@@ -407,6 +432,8 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     // (every switch is read here, once: no getenv on the paths a step takes)
     if (const char *e = getenv("REO_STATE_MIRROR")) c->state_mirror_wanted = (e[0] != '0');
     if (const char *e = getenv("REO_EXCHANGE_WAVES")) c->x_waves = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("REO_EAGER_UPLOAD")) c->eager_mode = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("REO_EAGER_CHUNK")) c->eager_chunk = std::max(1, atoi(e));
     c->debug_passes = getenv("REO_DEBUG_PASSES") != nullptr;
     c->debug_stamps = getenv("REO_DEBUG_STAMPS") != nullptr;
     c->k1_stamps = getenv("REO_K1_STAMPS") != nullptr;
@@ -439,6 +466,7 @@ void reo_destroy(reo_ctx *c)
     // also be destroyed right after a failure of the join itself).
     for (int q = 0; q < 2; ++q) if (c->k1s[q]) (void)hipStreamSynchronize(c->k1s[q]);
     if (c->xs) (void)hipStreamSynchronize(c->xs);
+    if (c->up) (void)hipStreamSynchronize(c->up);
     (void)hipStreamSynchronize(c->stream);
     comm_release(c);
     collect_timings(c);
@@ -450,6 +478,9 @@ void reo_destroy(reo_ctx *c)
     for (auto &il : c->k1_wave_items) il.buf.release();
     for (int q = 0; q < 2; ++q) { if (c->k1s[q]) (void)hipStreamDestroy(c->k1s[q]); if (c->ev_k1_join[q]) (void)hipEventDestroy(c->ev_k1_join[q]); }
     if (c->xs) (void)hipStreamDestroy(c->xs);
+    if (c->up) (void)hipStreamDestroy(c->up);
+    for (auto &e : c->ev_up) if (e) (void)hipEventDestroy(e);
+    c->e_lists.release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_x) (void)hipEventDestroy(c->ev_x);
     for (auto &e : c->ev_k1) if (e) (void)hipEventDestroy(e);
@@ -474,6 +505,7 @@ int32_t reo_set_shard(reo_ctx *c, int32_t rank, int32_t world)
     if (!c->peers.empty()) { set_error("a multi-GPU context (reo_create_multi) shards by itself"); return REO_EINVAL; }
     c->rank = rank; c->world = world;
     c->built_k = -1;
+    c->eager_k1 = false;
     c->gc_valid = false;
     c->table_complete = false;
     return REO_OK;
@@ -572,6 +604,7 @@ int32_t reo_compute_thresholds(reo_ctx *c, double pval_reo)
     }
     c->thr_set = true;
     c->built_k = -1;
+    c->eager_k1 = false;
     for (reo_ctx *p : c->peers) { p->thr = c->thr; p->thr_set = true; p->built_k = -1; }
     return REO_OK;
 }
@@ -582,6 +615,7 @@ int32_t reo_set_thresholds(reo_ctx *c, const int32_t *m)
     c->thr.assign(m, m + 2 * c->ngroups);
     c->thr_set = true;
     c->built_k = -1;
+    c->eager_k1 = false;
     for (reo_ctx *p : c->peers) { p->thr = c->thr; p->thr_set = true; p->built_k = -1; }
     return REO_OK;
 }
@@ -622,6 +656,12 @@ int32_t reo_build_pairs(reo_ctx *c, int32_t k)
         if ((rc = multi_build_pairs(c, k, build_local))) return rc;
     } else {
         if (c && c->comm_dead && c->world > 1) { set_error("the communicator of this context was aborted after an earlier failure: attach a new one (reo_comm_init_rank)"); return REO_ECOMM; }
+        if (c && c->eager_k1 && k == 0 && c->built_k == 0 && c->transformed && !c->comm && c->world <= 1 && !c->ag && !c->ar) {
+            // reo_set_matrix (host matrix, groups and thresholds known) has launched this comparison's pair kernel already
+            c->eager_k1 = false;   // (once: a second reo_build_pairs rebuilds, as it always did)
+            c->t_ms[5] += 1.0;
+            return REO_OK;
+        }
         if (c && !c->comm && c->world <= 1 && !c->ag && !c->ar) {
             // one GPU, nothing to exchange: the pair kernel is left running.  Every later call works on the same stream, so
             // reo_identify_degs queues its first passes behind it without a host round trip in between; an asynchronous

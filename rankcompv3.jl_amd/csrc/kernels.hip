@@ -3608,7 +3608,10 @@ static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool
 
 static int32_t exchange_args(reo_ctx *c, XArgs &a, int m0, int mcnt);
 
-int32_t launch_k1(reo_ctx *c, int k)
+// sides (wave form, two groups): which sides' items are launched -- bit 0 the comparison's own group, bit 1 the rest; 3 = the whole
+// table.  keep_table: the class table has been cleared by the caller and holds other sides' planes already (the pipelined upload,
+// transform.hip eager_upload, launches a side as soon as its group's samples are ranked).
+int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table)
 {
     K1Args a;
     a.P = c->pos.p; a.AL = c->lo.p; a.AH = c->hi.p; a.table = c->table.p;
@@ -3633,6 +3636,7 @@ int32_t launch_k1(reo_ctx *c, int k)
     }
     const bool wave = (c->k1_wave || big) && !multi;  // the wave form (two groups; also more than 65 535 samples: k1w_pairs_wide): kRJ genes per lane
     int32_t rc;
+    if (sides != 3 && (!wave || wide || c->world > 1)) { set_error("a single side of the pair kernel: wave form, one shard, at most 65535 samples"); return REO_EINVAL; }
     // > 2 groups: count every group once, then classify per comparison -- if the planes fit
     const size_t plane_elems = static_cast<size_t>(c->Gp) * c->Gp;
     bool shared = multi && c->share_counts && !wide;
@@ -3695,7 +3699,7 @@ int32_t launch_k1(reo_ctx *c, int k)
                                  static_cast<uint64_t>(c->world) << 32 | static_cast<uint32_t>(c->rank),
                                  static_cast<uint64_t>(nsides) << 56 | static_cast<uint64_t>(units.size()) << 24 |
                                      static_cast<uint64_t>(wave ? std::max(a.ce - a.cb, a.te - a.tb) : c->goff32[c->ngroups] / 32),
-                                 static_cast<uint64_t>(part) << 32 | static_cast<uint32_t>(nparts)};
+                                 static_cast<uint64_t>(sides) << 48 | static_cast<uint64_t>(part) << 32 | static_cast<uint32_t>(nparts)};
         if (!cache.buf.p || std::memcmp(key, cache.key, sizeof key) != 0) {
             // Workgroup b runs on XCD b & 7.  An item goes to the list of XCD (wave chunk & 7), and an XCD walks its list
             // group by group of its chunks (as many pos chunks of one side as fit about 2.5 MB of its 4 MiB L2), inside a
@@ -3711,7 +3715,8 @@ int32_t launch_k1(reo_ctx *c, int k)
             const size_t chunk_side_bytes = static_cast<size_t>(CW) * std::max(side_blocks, 1) * 64;
             const int per_group = static_cast<int>(std::max<size_t>(1, (size_t(5) << 19) / chunk_side_bytes));  // chunks of one XCD per group
             for (uint32_t um : units)
-                for (uint32_t side = 0; side < nsides; ++side)
+                for (uint32_t side = 0; side < nsides; ++side) {
+                    if (wave && !((sides >> side) & 1)) continue;
                     for (int t = 0; t < kUnitH; ++t)
                         for (int w = 0; w < QW; ++w) {
                             const int it = static_cast<int>(um & 0xFFFFu) * kUnitH + t, cw = static_cast<int>(um >> 16) * QW + w;
@@ -3720,6 +3725,7 @@ int32_t launch_k1(reo_ctx *c, int k)
                             lists[cw & 7].push_back(side << 31 | static_cast<uint32_t>(cw) << 16 | static_cast<uint32_t>(it));
                             ++total_items;
                         }
+                }
             for (auto &l : lists)
                 std::sort(l.begin(), l.end(), [per_group](uint32_t x, uint32_t y) {
                     const uint32_t cx = (x >> 16) & 0x7FFFu, cy = (y >> 16) & 0x7FFFu;
@@ -3784,7 +3790,7 @@ int32_t launch_k1(reo_ctx *c, int k)
     // kernel only writes words of its own units: the three streams never meet in a word.  (Wave form for two groups only;
     // everything else exchanges behind the pair kernel, as in round 3.)
     const int maxu_x = std::max(1, (static_cast<int>(c->units_all_host.size()) + std::max(c->world, 1) - 1) / std::max(c->world, 1));
-    const int nwaves = (wave && c->world > 1 && (c->comm || c->ag) && !c->in_multi && !c->k1_stamps) ? std::min({c->x_waves, 8, maxu_x}) : 1;   // (a reo_create_multi context hands its packs to the leader itself: comm.hip)
+    const int nwaves = (wave && sides == 3 && c->world > 1 && (c->comm || c->ag) && !c->in_multi && !c->k1_stamps) ? std::min({c->x_waves, 8, maxu_x}) : 1;   // (a reo_create_multi context hands its packs to the leader itself: comm.hip)
     if (nwaves > 1) {
         const int mw = (maxu_x + nwaves - 1) / nwaves;   // slots per wave: the same on every shard
         const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * (static_cast<size_t>(Q) * CJ / 32);
@@ -3864,14 +3870,17 @@ int32_t launch_k1(reo_ctx *c, int k)
         return REO_OK;
     }
     if (wave || (wcounts && !c->gc_valid) || wmulti) {
-        if ((rc = item_list(units, c->k1_wave_items[0], 0, 1))) return rc;
-        a.items = c->k1_wave_items[0].buf.p; c->k1_items_n = c->k1_wave_items[0].n;
+        reo_ctx::ItemList &il = c->k1_wave_items[sides == 3 ? 0 : sides];   // (a side's list keeps its own slot: the two sides of a pipelined upload alternate)
+        if ((rc = item_list(units, il, 0, 1))) return rc;
+        a.items = il.buf.p; c->k1_items_n = il.n;
         if (c->k1_stamps) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), (std::max<size_t>(c->k1_items_n, 1) * 4 + 2) * sizeof(unsigned long long)));
     }
     // (every reader of the table -- the passes, the pack, a sum hook's element count, the scan of a hook's table -- works on
     //  G * kPlanes * Wp words, which is also what the transform's early clear covers; a grow-only buffer may be larger)
-    if (!c->table_prezeroed) REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * kPlanes * c->Wp * sizeof(uint32_t), c->stream));
-    c->table_prezeroed = false;
+    if (!keep_table) {
+        if (!c->table_prezeroed) REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * kPlanes * c->Wp * sizeof(uint32_t), c->stream));
+        c->table_prezeroed = false;
+    }
     if (units.empty()) return REO_OK;
     c->last_k1_shared = shared ? 1 : 0;
     if (a.stamps) k_time_mark<<<1, 64, 0, c->stream>>>(a.stamps + c->k1_items_n * 4);

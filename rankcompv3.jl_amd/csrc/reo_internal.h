@@ -196,6 +196,13 @@ struct reo_ctx {
     const uint32_t *unit_map_uploaded = nullptr;  // ... and into which allocation
     size_t k1_items_n = 0;           // wave form of K1: items of the launch being made (one work item per workgroup: side << 31 | wave chunk << 16 | i-tile; lists: k1_wave_items)
     bool transformed = false;
+    // pipelined upload of a host matrix (transform.hip, eager_upload): chunks on an upload stream, ranked as they arrive
+    int eager_mode = 2;                  // REO_EAGER_UPLOAD: 0 off, 1 transform only, 2 (default) the pair kernel's sides as well
+    int eager_chunk = 0;                 // REO_EAGER_CHUNK: columns per chunk (0: about 8 MB)
+    hipStream_t up = nullptr;            // the upload stream
+    hipEvent_t ev_up[8] = {nullptr};     // chunk k has arrived (ring)
+    reo::DevBuf<int32_t> e_lists;        // [S] columns, [S + padding] slots, in column order
+    bool eager_k1 = false;               // reo_set_matrix has already launched the pair kernel of comparison 0 on this data, groups and thresholds
     int has_ties = 0;
     int transform_in_lds = 0;  // the last transform sorted each sample inside one workgroup's LDS (transform.hip)
 
@@ -295,9 +302,10 @@ namespace reo {
 
 // transform.hip
 int32_t run_transform(reo_ctx *c);
+int32_t eager_upload(reo_ctx *c, const void *hX, int64_t hld, bool with_k1);  // host matrix -> HBM in chunks, ranked (and paired) as they arrive
 
 // kernels.hip
-int32_t launch_k1(reo_ctx *c, int k);
+int32_t launch_k1(reo_ctx *c, int k, int sides = 3, bool keep_table = false);  // sides: bit 0 = the comparison's own group, bit 1 = the rest (wave form; eager_upload)
 int64_t exchange_unit_words(const reo_ctx *c);   // uint32 per packed work unit
 int32_t exchange_units_per_rank(const reo_ctx *c);
 int32_t launch_pack_units(reo_ctx *c, int m0 = 0, int mcnt = -1, uint32_t *send = nullptr, hipStream_t st = nullptr);    // this shard's units (all, or slots m0 .. m0 + mcnt - 1) -> c->xsend / send

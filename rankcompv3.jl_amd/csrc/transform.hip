@@ -794,11 +794,11 @@ l = rank_of(band_edge_code<false>(x, k), false);
 // three sources share a bank issues at half rate).
 __global__ __launch_bounds__(256) void t_slice(const uint16_t *__restrict__ pos, const uint16_t *__restrict__ lo,
                                                const uint16_t *__restrict__ hi, int Gp, uint4 *__restrict__ P,
-                                               uint4 *__restrict__ AL, uint4 *__restrict__ AH)
+                                               uint4 *__restrict__ AL, uint4 *__restrict__ AH, int b0)
 {
     // two adjacent genes per thread: their 32 x (16 + 16) bits of a block are one 32 x 32 bit matrix, transposed in
     // registers by five rounds of masked swaps (480 operations for both genes; picking the bits one by one was 2 x 1024)
-    const int g = (blockIdx.x * 256 + threadIdx.x) * 2, b = blockIdx.y;
+    const int g = (blockIdx.x * 256 + threadIdx.x) * 2, b = blockIdx.y + b0;   // (b0: the first block of a group, when groups are sliced as they complete)
     const size_t row0 = (static_cast<size_t>(b) * 32 * Gp + g) / 2;  // in pairs of 16-bit numbers
     uint32_t w[32];
     auto planes = [&](const uint16_t *__restrict__ src) {
@@ -883,8 +883,16 @@ __global__ __launch_bounds__(256) void t_slice_big(const uint32_t *__restrict__ 
     rows(AH);
 }
 
+// A launch ranks the samples of a LIST: colmap[t] = column of X, slots[t] = its row set in the 16-bit outputs, t < n_samples;
+// entries n_samples .. n_slots - 1 of `slots` are padding slots (rows of zeros).  The whole-matrix transform passes the
+// sorted sample order; the pipelined upload (eager_upload below) passes the columns of one chunk.
+struct SampleList {
+    const int32_t *colmap, *slots;
+    int n_samples, n_slots;
+};
+
 template <class T, int IPT>
-int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
+int32_t launch_sample(reo_ctx *c, const T *X, const SampleList &sl, int32_t *d_flags)
 {
     const size_t lds = IPT > 32 ? sizeof(uint32_t) * kCountWords + 64   // (above 32 768 genes: the 16-bit-bin histogram only)
                                 : std::max({sizeof(uint32_t) * kCountWords + 64,
@@ -897,14 +905,14 @@ int32_t launch_sample(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d
         if ((rc = c->t_vin.ensure(static_cast<size_t>(c->S) * c->Gp))) return rc;
         skey_rows = c->t_vin.p;
     }
-    t_sample<T, IPT><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,  // (a workgroup per slot: samples, then padding)
-                                                                            static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, skey_rows);
+    t_sample<T, IPT><<<static_cast<unsigned>(sl.n_slots), 1024, lds, c->stream>>>(X, c->ld, sl.colmap, sl.slots, static_cast<int>(c->G), c->Gp,  // (a workgroup per slot: samples, then padding)
+                                                                            sl.n_samples, c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, skey_rows);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
 }
 
 template <class T, int LOGSUB, bool GENL>
-int32_t launch_sample_wide(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags)
+int32_t launch_sample_wide(reo_ctx *c, const T *X, const SampleList &sl, int32_t *d_flags)
 {
     constexpr size_t NB = static_cast<size_t>(kSplit1) * ((1 << LOGSUB) + 1);
     const size_t lds = wide_lds_head(NB, !GENL) + sizeof(uint16_t) * (GENL ? 2 : 1) * static_cast<size_t>(c->Gp);
@@ -915,8 +923,8 @@ int32_t launch_sample_wide(reo_ctx *c, const T *X, const int32_t *d_order, int32
     const size_t n = static_cast<size_t>(c->S) * c->Gp;
     if ((rc = c->t_kin.ensure(n))) return rc;
     if (GENL ? (rc = c->t_vin.ensure(n)) : (rc = c->t_vin32.ensure(n))) return rc;
-    t_sample_wide<T, LOGSUB, GENL><<<static_cast<unsigned>(c->goff32[c->ngroups]), 1024, lds, c->stream>>>(X, c->ld, d_order, c->t_slots.p, static_cast<int>(c->G), c->Gp,
-                                                                                    static_cast<int>(c->S), c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, c->t_kin.p, c->t_vin.p,
+    t_sample_wide<T, LOGSUB, GENL><<<static_cast<unsigned>(sl.n_slots), 1024, lds, c->stream>>>(X, c->ld, sl.colmap, sl.slots, static_cast<int>(c->G), c->Gp,
+                                                                                    sl.n_samples, c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, d_flags, c->t_kin.p, c->t_vin.p,
                                                                                     GENL ? nullptr : c->t_vin32.p);
     REO_HIP_CHECK(hipGetLastError());
     return REO_OK;
@@ -924,8 +932,9 @@ int32_t launch_sample_wide(reo_ctx *c, const T *X, const int32_t *d_order, int32
 
 // the in-LDS ranking of every sample: the histogram forms for Int64 (t_sample), the bucket form for everything else
 template <class T>
-int32_t launch_lds_ranking(reo_ctx *c, const T *X, const int32_t *d_order, int32_t *d_flags, bool wide)
+int32_t launch_lds_ranking(reo_ctx *c, const T *X, const SampleList &d_order, int32_t *d_flags, bool wide)
 {
+    if (d_order.n_slots <= 0) return REO_OK;
     const int64_t G = c->G;
     if (!wide) {
         if constexpr (kCountingPath<T>) {
@@ -1023,7 +1032,7 @@ int32_t transform_impl(reo_ctx *c)
     const T *X = static_cast<const T *>(c->dX);
     auto slice = [&]() -> int32_t {
         if (big) t_slice_big<<<dim3(Gp / 256, nblk), 256, 0, st>>>(c->t_pos32.p, c->t_lo32.p, c->t_hi32.p, Gp, c->pos.p, c->lo.p, c->hi.p);
-        else t_slice<<<dim3(Gp / 512, nblk), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p);
+        else t_slice<<<dim3(Gp / 512, nblk), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p, 0);
         REO_HIP_CHECK(hipGetLastError());
         return REO_OK;
     };
@@ -1046,7 +1055,7 @@ int32_t transform_impl(reo_ctx *c)
         int32_t *fl = c->host_flags;
         bool wide = !kCountingPath<T> || (env && env[0] == 'w');
         for (int attempt = 0; attempt < 2; ++attempt) {
-            if ((rc = launch_lds_ranking<T>(c, X, d_order.p, d_flags.p, wide))) return rc;
+            if ((rc = launch_lds_ranking<T>(c, X, SampleList{d_order.p, c->t_slots.p, S, S32}, d_flags.p, wide))) return rc;
             // the slicing is enqueued before the host looks at the flags (it runs while the host wakes up; if the flags send
             // the data elsewhere it is simply done again)
             if ((rc = slice())) return rc;
@@ -1147,7 +1156,153 @@ int32_t transform_impl(reo_ctx *c)
     return finish(flags[1], false);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Pipelined upload (round 5): reo_set_matrix_i64 / _f64 from HOST memory when groups (and thresholds) are already known.
+// The drop-in call hands over a pageable column-major host matrix (julia/RankCompV3HIP.jl at src/RankCompV3.jl:652); the transform
+// is per sample and the pair kernel's items are per side (= per group), so nothing has to wait for the whole matrix:
+//   * the columns travel in chunks on an upload stream; as soon as a chunk has arrived its samples are ranked (the same
+//     t_sample / t_sample_wide launches as run_transform, on a list of that chunk's columns);
+//   * when the last sample of a group has been ranked the group's blocks are sliced into bit planes, and -- two groups, one
+//     GPU, thresholds set -- the pair kernel's items of THAT side are launched (launch_k1 with a side mask) while the other
+//     group's columns are still on their way;
+//   * the call returns when the whole matrix has been read (the ownership rule of reo_hip.h: no host pointer is kept), with the
+//     second side's pair kernel possibly still running (like reo_build_pairs on one GPU); reo_build_pairs then has nothing to do.
+// Anything the in-LDS ranking cannot take (a flagged sample: another form is needed) falls back to run_transform on the
+// resident copy at reo_build_pairs -- same results, no overlap.
+template <class T>
+int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
+{
+    const int G = static_cast<int>(c->G), S = static_cast<int>(c->S), Gp = c->Gp;
+    hipStream_t st = c->stream;
+    int32_t rc;
+    // sample layout: as transform_impl, but the samples are LISTED IN COLUMN ORDER (a chunk of columns = a run of the list)
+    c->goff.assign(c->ngroups + 1, 0);
+    for (int s = 0; s < S; ++s) c->goff[c->group_id[s] + 1]++;
+    for (int g = 0; g < c->ngroups; ++g) c->goff[g + 1] += c->goff[g];
+    c->goff32.assign(c->ngroups + 1, 0);
+    for (int g = 0; g < c->ngroups; ++g) c->goff32[g + 1] = c->goff32[g] + (c->goff[g + 1] - c->goff[g] + 31) / 32 * 32;
+    const int S32 = c->goff32[c->ngroups], nblk = S32 / 32;
+    std::vector<int32_t> lists(static_cast<size_t>(S) + S32), goff_blocks(c->ngroups + 1), seen(c->ngroups, 0);
+    int32_t *cols = lists.data(), *slots = lists.data() + S;   // [S] columns (identity), then [S samples + padding] slots
+    for (int s = 0; s < S; ++s) {
+        const int g = c->group_id[s];
+        cols[s] = s;
+        slots[s] = c->goff32[g] + seen[g]++;   // the order inside a group = column order, like the stable sort of transform_impl
+    }
+    int npad = 0;
+    for (int g = 0; g < c->ngroups; ++g)
+        for (int sl = c->goff32[g] + (c->goff[g + 1] - c->goff[g]); sl < c->goff32[g + 1]; ++sl) slots[S + npad++] = sl;
+    for (int g = 0; g <= c->ngroups; ++g) goff_blocks[g] = c->goff32[g] / 32;
+    DevBuf<int32_t> &d_flags = c->t_flags;
+    if ((rc = c->e_lists.ensure(lists.size())) || (rc = d_flags.ensure(32)) || (rc = c->goff_dev.ensure(c->ngroups + 1))) return rc;
+    REO_HIP_CHECK(hipMemcpyAsync(c->e_lists.p, lists.data(), sizeof(int32_t) * (static_cast<size_t>(S) + S + npad), hipMemcpyHostToDevice, st));
+    REO_HIP_CHECK(hipMemcpyAsync(c->goff_dev.p, goff_blocks.data(), sizeof(int32_t) * (c->ngroups + 1), hipMemcpyHostToDevice, st));
+    REO_HIP_CHECK(hipStreamSynchronize(st));  // the sources are locals
+    c->goff_blocks_host = goff_blocks; c->t_meta_ptr[2] = c->goff_dev.p;
+    const int32_t *d_cols = c->e_lists.p, *d_slots = c->e_lists.p + S;
+    REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
+    const size_t n = static_cast<size_t>(S32) * Gp, nq = static_cast<size_t>(nblk) * Gp * 4;
+    if ((rc = c->t_pos16.ensure(n)) || (rc = c->t_lo16.ensure(n)) || (rc = c->t_hi16.ensure(n)) ||
+        (rc = c->pos.ensure(nq)) || (rc = c->lo.ensure(nq)) || (rc = c->hi.ensure(nq)))
+        return rc;
+    if (!c->host_flags) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t)));
+    if (!c->up) {
+        REO_HIP_CHECK(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking));
+        for (auto &e : c->ev_up) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    T *dX = reinterpret_cast<T *>(c->dX_owned.p);
+    const bool wide = !kCountingPath<T>;
+    c->transform_in_lds = 0;
+    c->table_prezeroed = false;
+    if (with_k1) {   // the class table is cleared once, in front of everything; the side launches keep what is there
+        REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * 4 * c->Wp * sizeof(uint32_t), st));
+    }
+    tic(c, 0);
+    if (npad) {   // rows of zeros for the padding slots of every group (no data needed)
+        if ((rc = launch_lds_ranking<T>(c, dX, SampleList{d_cols, d_slots + S, 0, npad}, d_flags.p, wide))) return rc;
+    }
+    toc(c);
+    // Chunks: a ranking launch is one workgroup per sample and takes a sample's time (30 us for counts, 180 us for Float64) however few
+    // samples it has, so a chunk wants enough samples to fill the 256 CUs (measured at 20 000 x 1 000, tools/from_host_breakdown.py:
+    // chunks of 52 columns made the Float64 ranking 4.4 ms in all instead of 1.0); and it ends where the group label changes, so
+    // that a group's last chunk -- the one that releases its side of the pair kernel -- is not held up by columns of the next group.
+    int CH = static_cast<int>(std::max<int64_t>(256, (int64_t(8) << 20) / (static_cast<int64_t>(G) * 8)));
+    if (c->eager_chunk > 0) CH = c->eager_chunk;   // REO_EAGER_CHUNK (experiments)
+    std::vector<int> left(c->ngroups);
+    for (int g = 0; g < c->ngroups; ++g) left[g] = c->goff[g + 1] - c->goff[g];
+    int sides_done = 0, ranked = 0, ranked_at_read = -1;
+    bool fallback = false, bad_values = false;
+    int32_t *fl = c->host_flags;
+    auto read_flags = [&]() -> int32_t {   // the flags so far (waits for the rankings queued so far)
+        REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        REO_HIP_CHECK(hipStreamSynchronize(st));
+        ranked_at_read = ranked;
+        if (fl[0]) bad_values = true;
+        if (fl[4] || fl[5]) fallback = true;
+        return REO_OK;
+    };
+    int nchunk = 0;
+    for (int c0 = 0; c0 < S; ++nchunk) {
+        int nc = std::min(CH, S - c0);
+        for (int s = c0 + 1; s < c0 + nc; ++s)   // cut at the first change of label that leaves a chunk worth launching
+            if (c->group_id[s] != c->group_id[s - 1] && s - c0 >= std::min(CH, 64)) { nc = s - c0; break; }
+        // the copy: pageable source, so the call returns when the runtime has staged the chunk; the upload stream never waits for
+        // a kernel (a ring of events hands each chunk to the compute stream)
+        if (hld == c->G) REO_HIP_CHECK(hipMemcpyAsync(dX + static_cast<size_t>(c0) * G, hX + static_cast<size_t>(c0) * hld, static_cast<size_t>(nc) * G * sizeof(T), hipMemcpyHostToDevice, c->up));
+        else REO_HIP_CHECK(hipMemcpy2DAsync(dX + static_cast<size_t>(c0) * G, G * sizeof(T), hX + static_cast<size_t>(c0) * hld, hld * sizeof(T), G * sizeof(T), nc, hipMemcpyHostToDevice, c->up));
+        hipEvent_t ev = c->ev_up[nchunk % 8];
+        REO_HIP_CHECK(hipEventRecord(ev, c->up));
+        REO_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
+        const int cbeg = c0;
+        c0 += nc;
+        if (fallback || bad_values) continue;   // (the rest of the matrix still has to arrive)
+        tic(c, 0);
+        if ((rc = launch_lds_ranking<T>(c, dX, SampleList{d_cols + cbeg, d_slots + cbeg, nc, nc}, d_flags.p, wide))) return rc;
+        ranked = c0;
+        int ready = 0;   // groups whose last sample is in this chunk: their blocks are complete and can be sliced into bit planes
+        for (int s = cbeg; s < cbeg + nc; ++s) {
+            const int g = c->group_id[s];
+            if (--left[g] != 0) continue;
+            ready |= 1 << std::min(g, 30);
+            const int b0 = c->goff32[g] / 32, nb = (c->goff32[g + 1] - c->goff32[g]) / 32;
+            t_slice<<<dim3(Gp / 512, nb), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p, b0);
+            REO_HIP_CHECK(hipGetLastError());
+        }
+        toc(c);
+        if (with_k1 && ready) {   // two groups: side 0 counts group 0's samples, side 1 group 1's (k = 0)
+            if ((rc = read_flags())) return rc;
+            if (fallback || bad_values) continue;
+            const int mask = ready & 3;
+            c->has_ties = fl[1];   // ties seen SO FAR: covers every sample of this side (the tie-free loop is exact on a side without ties)
+            if ((rc = launch_k1(c, 0, mask, true))) return rc;
+            sides_done |= mask;
+        }
+    }
+    REO_HIP_CHECK(hipStreamSynchronize(c->up));   // the whole matrix has been read: the caller may have its array back
+    // the flags are final if they were read behind the last ranking (the boundary of the last group: the usual case) -- reading
+    // them again would wait for the second side's pair kernel, which the host has no need to wait for here
+    if (ranked_at_read != S && !bad_values && !fallback && (rc = read_flags())) return rc;
+    c->transformed = false;
+    if (bad_values) {
+        set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
+                  "src/RankCompV3.jl:601)");
+        return REO_EINVAL;
+    }
+    if (fallback) return REO_OK;   // some sample wants another form of the ranking: run_transform on the resident copy (reo_build_pairs)
+    c->has_ties = fl[1];
+    c->transform_in_lds = wide ? 2 : 1;
+    c->transformed = true;
+    if (with_k1 && sides_done == 3) c->eager_k1 = true;   // reo_build_pairs(0) finds its table made (or being made, on this stream)
+    return REO_OK;
+}
+
 }  // namespace
+
+int32_t eager_upload(reo_ctx *c, const void *hX, int64_t hld, bool with_k1)
+{
+    return c->dtype == 1 ? eager_upload_impl<double>(c, static_cast<const double *>(hX), hld, with_k1)
+                         : eager_upload_impl<int64_t>(c, static_cast<const int64_t *>(hX), hld, with_k1);
+}
 
 int32_t run_transform(reo_ctx *c)
 {

@@ -92,7 +92,8 @@ def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref
     comps = []
     with _ffi.Context(device=device, seed=seed) as ctx:
         ctx.set_profiling(profile)
-        ctx.set_matrix(data)
+        # groups, thresholds and sharding BEFORE the matrix: reo_set_matrix then ranks the samples as their columns arrive and, on
+        # one GPU with two groups, starts the pair kernel's first side while the second group is still crossing PCIe
         ctx.set_groups(gid, len(levels))
         thr = ctx.compute_thresholds(pval_reo)
         if shard[1] > 1:
@@ -101,6 +102,7 @@ def run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref
                 ctx.set_allgather(allgather)   # all-gather of the shards' own table words (what the in-library RCCL path does)
             else:
                 ctx.set_allreduce(allreduce)   # in-place sum of the whole table
+        ctx.set_matrix(data)
         for k in range(ncomp):  # `for k=1:gnum ... if gnum==2 break` (:396,431-434)
             ctx.build_pairs(k)
             result, iters, trace = ctx.identify_degs(np.asarray(ref_gene, dtype=bool), pval_deg, padj_deg, n_iter, n_conv)

@@ -51,9 +51,9 @@ int main(int argc, char **argv)
             CHECK(reo_comm_init_rank(ctx, id, 0, 1));
         }
     }
-    CHECK(reo_set_matrix_i64(ctx, X, G, S, G));                 /* Matrix(df_expr), :652 */
     CHECK(reo_set_groups(ctx, gid, S, (int32_t)ngroups));       /* unique(group), :353-357 */
     CHECK(reo_compute_thresholds(ctx, pval_reo));               /* :362 */
+    CHECK(reo_set_matrix_i64(ctx, X, G, S, G));                 /* Matrix(df_expr), :652 -- after the groups: the upload is pipelined with the ranking and the pair kernel */
     CHECK(reo_build_pairs(ctx, 0));                             /* :363-392 */
     int32_t passes = 0;
     CHECK(reo_identify_degs(ctx, ref, pval_deg, padj_deg, (int32_t)n_iter, (int32_t)n_conv, result, &passes, trace));  /* :396-425 */

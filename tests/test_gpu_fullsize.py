@@ -42,6 +42,15 @@ def test_config3_whole_table_and_loop_against_oracle(pkg, oracle, family, n_iter
         if n_conv == 0:
             assert iters == 128
         _check_result(res, exp)
+    # the drop-in order of calls (groups and thresholds first, then the matrix from pageable host memory: the upload is pipelined with
+    # the ranking and the pair kernel's sides, transform.hip eager_upload) against the same oracle table and loop
+    from test_gpu_parity import _eager_ctx
+    with _eager_ctx(pkg, np.asfortranarray(X), group, seed) as ctx2:
+        ctx2.build_pairs(0)  # (returns at once: reo_set_matrix has launched the pair kernel of both sides)
+        res2, it2, tr2 = ctx2.identify_degs(ref0, 1.0, 0.05, n_iter, n_conv)
+        assert it2 == eit and tr2 == etr
+        _check_result(res2, exp)
+        assert np.array_equal(ctx2.get_codes(0, G, 0, G), code), "class table of the pipelined upload differs from the oracle"
 
 
 def _two_shard_run(pkg, X, gid, seed, pval_reo, ref0, n_iter, n_conv):

@@ -560,6 +560,85 @@ def _shard_raw(pkg, ctx, ref0, G):
     return sharding_mirror.raw_counters(code, ref0)
 
 
+def _eager_ctx(pkg, X, group, seed, pval_reo=0.01):
+    """groups and thresholds BEFORE the matrix: reo_set_matrix_* pipelines the upload with the ranking and the pair kernel's sides"""
+    gid, lev = pkg.encode_groups(group)
+    ctx = pkg.Context(device=0, seed=seed)
+    ctx.set_groups(gid, len(lev))
+    ctx.compute_thresholds(pval_reo)
+    ctx.set_matrix(X)
+    return ctx
+
+
+@pytest.mark.parametrize("kind", ["ranks", "counts", "float", "big_int", "three_groups", "interleaved", "unequal", "view_ld", "small"])
+def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
+    """reo_set_matrix_i64 / _f64 from host memory with the groups already set (round 5): the columns travel in chunks, samples are
+    ranked as they arrive, a group's blocks are sliced when its last sample is in, and (two groups, one GPU, thresholds set) the
+    pair kernel's side of that group starts while the other group is still on its way.  Everything must be BIT-EQUAL to the
+    matrix-first order of rounds 1-4: whole class table, tallies, trace, every statistic -- for contiguous and interleaved labels,
+    unequal groups (padding slots), three groups (ranking only), a view with a leading dimension, data that the first choice of
+    ranking kernel flags (falls back to the resident copy), and with the pipelining switched down (REO_EAGER_UPLOAD=1, 0)."""
+    seed = 0x5EED0051
+    rng = np.random.default_rng(11)
+    G, S = 9000, 300
+    group = pkg.synth.groups(S)
+    if kind == "ranks": X = pkg.synth.t0_ranks(G, S, seed)
+    elif kind == "counts": X = pkg.synth.t1_counts(G, S, seed)
+    elif kind == "float": X = pkg.synth.float_expr(G, S, seed)
+    elif kind == "big_int": X = rng.integers(0, 2 ** 31, size=(G, S))            # more varying key bits than the histogram form takes
+    elif kind == "three_groups": X = pkg.synth.t1_counts(G, S, seed); group = ["a"] * 90 + ["b"] * 110 + ["c"] * 100
+    elif kind == "interleaved": X = pkg.synth.t1_counts(G, S, seed); group = [("u", "v")[int(b)] for b in rng.integers(0, 2, S)]
+    elif kind == "unequal": X = pkg.synth.t0_ranks(G, S, seed); group = ["u"] * 37 + ["v"] * (S - 37)
+    elif kind == "view_ld":
+        big = np.asfortranarray(np.full((G + 24, S), -7, dtype=np.int64)); big[8:8 + G, :] = pkg.synth.t1_counts(G, S, seed); X = big[8:8 + G, :]
+    else: G, S = 700, 41; X = pkg.synth.t1_counts(G, S, seed); group = pkg.synth.groups(S)
+    ref0 = pkg.synth.ref_mask(G, G // 5, seed)
+    ng = len(set(group))
+
+    def outputs(ctx):
+        with ctx:
+            out = []
+            for k in range(1 if ng == 2 else ng):
+                ctx.build_pairs(k)
+                codes = ctx.get_codes(0, G, 0, G)
+                out.append((codes, ctx.tally(ref0), ctx.identify_degs(ref0, 1.0, 0.05, 6, 0), ctx.info()["has_ties"]))
+            return out
+
+    want = outputs(_setup(pkg, X, group, seed)[0])
+    for mode in ("2", "1", "0"):
+        monkeypatch.setenv("REO_EAGER_UPLOAD", mode)
+        got = outputs(_eager_ctx(pkg, X, group, seed))
+        for (c0, t0, (r0, i0, tr0), h0), (c1, t1, (r1, i1, tr1), h1) in zip(want, got):
+            assert np.array_equal(c0, c1), (kind, mode, "class table")
+            assert np.array_equal(t0, t1) and i0 == i1 and tr0 == tr1 and h0 == h1, (kind, mode)
+            assert np.array_equal(r0, r1, equal_nan=True), (kind, mode, "statistics")
+    monkeypatch.delenv("REO_EAGER_UPLOAD")
+    # rebuilds on the same context, a second matrix, new thresholds
+    if ng == 2:
+        with _eager_ctx(pkg, X, group, seed) as ctx:
+            ctx.build_pairs(0)
+            r = ctx.identify_degs(ref0, 1.0, 0.05, 6, 0)
+            assert np.array_equal(r[0], want[0][2][0], equal_nan=True) and r[2] == want[0][2][2]
+            ctx.build_pairs(0); ctx.build_pairs(0)                                # (the second and third really rebuild)
+            assert np.array_equal(ctx.get_codes(0, G, 0, G), want[0][0])
+            ctx.set_matrix(X)                                                     # a second matrix on the same context, pipelined again
+            ctx.build_pairs(0)
+            assert np.array_equal(ctx.get_codes(0, G, 0, G), want[0][0])
+            ctx.compute_thresholds(0.2)                                           # new thresholds drop the table that reo_set_matrix made
+            with pytest.raises(pkg.DimensionMismatch):
+                ctx.get_codes(0, 4, 0, 4)
+    # a non-finite value is reported by the call that reads the matrix
+    if kind == "float":
+        Xn = X.copy(); Xn[G // 2, S - 3] = np.inf
+        gid, lev = pkg.encode_groups(group)
+        with pkg.Context(device=0, seed=seed) as ctx:
+            ctx.set_groups(gid, len(lev)); ctx.compute_thresholds(0.01)
+            with pytest.raises(pkg.DimensionMismatch, match="NaN or Inf"):
+                ctx.set_matrix(Xn)
+            ctx.set_matrix(X); ctx.build_pairs(0)                                 # the context works again
+            assert np.array_equal(ctx.get_codes(0, 64, 0, G), want[0][0][:64])
+
+
 def test_host_matrix_view_with_leading_dimension(pkg, oracle):
     """A column-major host view with ld > G (rows of a taller matrix, like a Julia view) must arrive
     intact: counts of blocks at both ends and in the middle of a 20 000-gene matrix."""
