@@ -63,6 +63,12 @@ const char *reo_last_error(void);
 int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed);
 void reo_destroy(reo_ctx *ctx);
 
+/* Memory of destroyed contexts is kept for the next one: a caller that makes a context per identify_degs call (the Julia shim
+ * does) would otherwise spend as long in hipMalloc / hipFree as in the computation (6 of 14 ms at 20 000 x 1 000).  Released
+ * device and pinned-host blocks wait in a process-wide cache, at most REO_DEVICE_CACHE_MB megabytes of them (environment,
+ * default 16384; 0 = no cache, every release is a hipFree); reo_trim_memory() returns all of them to the driver now. */
+int32_t reo_trim_memory(void);
+
 /* ---- several GPUs ---------------------------------------------------------------------------------------
  * The reference is one process with shared-memory threads (src/RankCompV3.jl:368,402) and has no multi-device
  * path; this is the build's own.  The pair tiles of the G x G triangle are dealt to `world` shards; every shard
@@ -255,7 +261,9 @@ int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);
  * inside one workgroup, 15 the iteration passes keep their rank histogram per XCD (the self-test of reo_create passed;
  * REO_XCC_LOCAL=0 switches it off), 16-18 the last reo_identify_degs: the period p of the cycle its iteration was found in
  * (0: none found), the pass in front of which the reference set equalled that of p passes earlier, and the passes that
- * were then skipped instead of executed (see reo_identify_degs; REO_CYCLE=0 switches the watch off). */
+ * were then skipped instead of executed (see reo_identify_degs; REO_CYCLE=0 switches the watch off), 19 the bytes that the last
+ * pipelined reo_set_matrix_i64 put on the PCIe link (Int64 numbers that fit travel as 16- or 32-bit numbers, converted by
+ * REO_UPLOAD_THREADS host threads, default 12, and widened on the device: exact; 0 threads = the caller's array as it is). */
 int32_t reo_get_info(reo_ctx *ctx, int64_t *info, int32_t n);
 
 #ifdef __cplusplus

@@ -20,7 +20,7 @@ NTIMINGS = 12
 
 # every symbol include/reo_hip.h declares
 SYMBOLS = [
-    "reo_version", "reo_last_error", "reo_create", "reo_destroy", "reo_set_shard", "reo_set_allreduce", "reo_set_allgather",
+    "reo_version", "reo_last_error", "reo_create", "reo_destroy", "reo_trim_memory", "reo_set_shard", "reo_set_allreduce", "reo_set_allgather",
     "reo_create_multi", "reo_comm_unique_id", "reo_comm_init_rank",
     "reo_set_matrix_f64", "reo_set_matrix_i64", "reo_set_matrix_dev_f64", "reo_set_matrix_dev_i64",
     "reo_set_groups", "reo_compute_thresholds", "reo_set_thresholds", "reo_get_thresholds", "reo_threshold",
@@ -81,6 +81,7 @@ def lib() -> ctypes.CDLL:
         "reo_last_error": (ctypes.c_char_p, []),
         "reo_create": (i32, [ctypes.POINTER(vp), i32, u64]),
         "reo_destroy": (None, [vp]),
+        "reo_trim_memory": (i32, []),
         "reo_set_shard": (i32, [vp, i32, i32]),
         "reo_create_multi": (i32, [ctypes.POINTER(vp), i32, u64]),
         "reo_comm_unique_id": (i32, [vp]),
@@ -128,6 +129,11 @@ def check(status: int) -> None:
     if status == REO_EINVAL:
         raise DimensionMismatch(status, msg)
     raise ReoError(status, msg)
+
+
+def trim_memory() -> None:
+    """reo_trim_memory: give the cached device and pinned blocks of destroyed contexts back to the driver."""
+    check(lib().reo_trim_memory())
 
 
 def threshold(sample_size: int, pval_reo: float = 0.01) -> int:
@@ -358,10 +364,10 @@ class Context:
                 "k2_full_launches": int(ms[9]), "k2_delta_ms": ms[10], "set_matrix_host_wall_ms": ms[11]}
 
     def info(self) -> dict:
-        v = np.zeros(19, dtype=np.int64)
-        check(self._L.reo_get_info(self._h, _ptr(v), 19))
+        v = np.zeros(20, dtype=np.int64)
+        check(self._L.reo_get_info(self._h, _ptr(v), 20))
         return {"G": int(v[0]), "S": int(v[1]), "Gp": int(v[2]), "table_bytes": int(v[3]), "has_ties": int(v[4]),
                 "tiles_owned": int(v[5]), "tiles_total": int(v[6]), "tile_i": int(v[7]), "chunk_j": int(v[8]),
                 "chunks_per_panel": int(v[9]), "unit_h": int(v[10]), "sample_slots": int(v[11]),
                 "shared_group_counts": int(v[12]), "group_count_bytes": int(v[13]), "transform_in_lds": int(v[14]), "xcc_local_histograms": int(v[15]),
-                "cycle_period": int(v[16]), "cycle_found_at_pass": int(v[17]), "cycle_passes_skipped": int(v[18])}
+                "cycle_period": int(v[16]), "cycle_found_at_pass": int(v[17]), "cycle_passes_skipped": int(v[18]), "upload_link_bytes": int(v[19])}

@@ -15,9 +15,90 @@
 
 #include "reo_internal.h"
 
+#include <mutex>
+
 namespace reo {
 
 static thread_local std::string g_err;
+thread_local bool tl_release_synced = false;
+
+// ---- the block cache (reo_internal.h) -------------------------------------------------------------------------------------------
+namespace {
+struct Block { void *p; size_t bytes; int device; bool pinned; };
+struct Pool {
+    std::mutex mu;
+    std::vector<Block> free_blocks;   // oldest first
+    size_t cached = 0, cap = size_t(16384) << 20;
+    bool read_env = false;
+};
+Pool &pool() { static Pool *p = new Pool(); return *p; }   // (never destroyed: the HIP runtime may be gone when statics are)
+size_t pool_round(size_t bytes) { return bytes <= 4096 ? 4096 : (bytes + 255) & ~size_t(255); }
+hipError_t raw_alloc(void **p, size_t bytes, bool pinned) { return pinned ? hipHostMalloc(p, bytes) : hipMalloc(p, bytes); }
+void raw_free(void *p, bool pinned) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
+}  // namespace
+
+hipError_t pool_alloc(void **out, size_t bytes, bool pinned)
+{
+    Pool &P = pool();
+    bytes = pool_round(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (!P.read_env) {
+            P.read_env = true;
+            if (const char *e = getenv("REO_DEVICE_CACHE_MB")) P.cap = static_cast<size_t>(std::max(0L, atol(e))) << 20;
+        }
+        // best fit among blocks that waste at most a quarter (contexts of one problem size ask for the same sizes again: exact hits)
+        int best = -1;
+        for (int i = 0; i < static_cast<int>(P.free_blocks.size()); ++i) {
+            const Block &b = P.free_blocks[i];
+            if (b.pinned != pinned || (!pinned && b.device != dev) || b.bytes < bytes || b.bytes > bytes + bytes / 4 + 4096) continue;
+            if (best < 0 || b.bytes < P.free_blocks[best].bytes) best = i;
+        }
+        if (best >= 0) {
+            *out = P.free_blocks[best].p;
+            P.cached -= P.free_blocks[best].bytes;
+            P.free_blocks.erase(P.free_blocks.begin() + best);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = raw_alloc(out, bytes, pinned);
+    if (e == hipErrorOutOfMemory) {   // give the cache back and try once more
+        (void)hipGetLastError();
+        (void)reo_trim_memory();
+        e = raw_alloc(out, bytes, pinned);
+    }
+    return e;
+}
+
+void pool_free(void *p, size_t bytes, bool pinned)
+{
+    if (!p) return;
+    Pool &P = pool();
+    bytes = pool_round(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::vector<Block> evict;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (bytes > P.cap) { evict.push_back({p, bytes, dev, pinned}); }
+        else {
+            P.free_blocks.push_back({p, bytes, dev, pinned});
+            P.cached += bytes;
+            while (P.cached > P.cap && !P.free_blocks.empty()) {   // the oldest go first
+                evict.push_back(P.free_blocks.front());
+                P.cached -= P.free_blocks.front().bytes;
+                P.free_blocks.erase(P.free_blocks.begin());
+            }
+        }
+    }
+    for (const Block &b : evict) {
+        if (!b.pinned && b.device != dev) (void)hipSetDevice(b.device);
+        raw_free(b.p, b.pinned);
+        if (!b.pinned && b.device != dev) (void)hipSetDevice(dev);
+    }
+}
 
 void set_error(const char *fmt, ...)
 {
@@ -225,7 +306,7 @@ static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64
             const double w0 = wall_us();
             struct DrainUp {   // no exit leaves a copy from the caller's array in flight (the upload stream; c->stream has its own guard below)
                 reo_ctx *c;
-                ~DrainUp() { if (c->up) (void)hipStreamSynchronize(c->up); }
+                ~DrainUp() { if (c->up) (void)hipStreamSynchronize(c->up); if (c->rk) (void)hipStreamSynchronize(c->rk); }
             } drain_up{c};
             DrainOnExit drain(c);
             rc = eager_upload(c, X, ld, k1);
@@ -281,7 +362,7 @@ static int32_t ensure_iter_buffers(reo_ctx *c)
         (rc = c->chunk_i.ensure(((G + kSortChunk - 1) / kSortChunk) * kSortChunk)) || (rc = c->part.ensure(3 * (std::max<size_t>(65536, (G + kSortChunk - 1) / kSortChunk * kSortChunk) / 16 + 8))) ||
         (rc = c->cand.ensure(2 * 1024)) || (rc = c->gridbar.ensure(4)) || (rc = c->hist.ensure(3 * kHistParts * ((G + 32767) / 32768 * 32768))) || (rc = c->olist.ensure(2 * kOneStride)) || (rc = c->mrank.ensure(c->Gp)) || (rc = c->lstate.ensure(1)) || (rc = c->clist.ensure(2 * kListStride)) || (rc = c->scal.ensure(64)))
         return rc;
-    if (!c->host_state) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState)));
+    if (!c->host_state) REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->host_state), sizeof(IterState), true));
     return REO_OK;
 }
 
@@ -388,6 +469,25 @@ extern "C" {
 
 int32_t reo_version(void) { return 100; }
 
+int32_t reo_trim_memory(void)
+{
+    std::vector<Block> all;
+    {
+        Pool &P = pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        all.swap(P.free_blocks);
+        P.cached = 0;
+    }
+    int dev = 0;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess;
+    for (const Block &b : all) {
+        if (!b.pinned) (void)hipSetDevice(b.device);
+        raw_free(b.p, b.pinned);
+    }
+    if (have_dev) (void)hipSetDevice(dev);
+    return REO_OK;
+}
+
 const char *reo_last_error(void) { return g_err.c_str(); }
 
 int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
@@ -434,6 +534,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (const char *e = getenv("REO_EXCHANGE_WAVES")) c->x_waves = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("REO_EAGER_UPLOAD")) c->eager_mode = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("REO_EAGER_CHUNK")) c->eager_chunk = std::max(1, atoi(e));
+    if (const char *e = getenv("REO_UPLOAD_THREADS")) c->upload_threads = std::max(0, std::min(64, atoi(e)));
     c->debug_passes = getenv("REO_DEBUG_PASSES") != nullptr;
     c->debug_stamps = getenv("REO_DEBUG_STAMPS") != nullptr;
     c->k1_stamps = getenv("REO_K1_STAMPS") != nullptr;
@@ -467,9 +568,11 @@ void reo_destroy(reo_ctx *c)
     for (int q = 0; q < 2; ++q) if (c->k1s[q]) (void)hipStreamSynchronize(c->k1s[q]);
     if (c->xs) (void)hipStreamSynchronize(c->xs);
     if (c->up) (void)hipStreamSynchronize(c->up);
+    if (c->rk) (void)hipStreamSynchronize(c->rk);
     (void)hipStreamSynchronize(c->stream);
     comm_release(c);
     collect_timings(c);
+    tl_release_synced = true;   // every stream of this context has been waited for: its blocks go back to the cache without further waits
     for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
     c->table.release();
@@ -479,8 +582,16 @@ void reo_destroy(reo_ctx *c)
     for (int q = 0; q < 2; ++q) { if (c->k1s[q]) (void)hipStreamDestroy(c->k1s[q]); if (c->ev_k1_join[q]) (void)hipEventDestroy(c->ev_k1_join[q]); }
     if (c->xs) (void)hipStreamDestroy(c->xs);
     if (c->up) (void)hipStreamDestroy(c->up);
+    if (c->rk) (void)hipStreamDestroy(c->rk);
+    for (auto &e : c->ev_rk) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_up) if (e) (void)hipEventDestroy(e);
     c->e_lists.release();
+    for (int q = 0; q < 3; ++q) {
+        if (c->stage_h[q]) pool_free(c->stage_h[q], c->stage_cap, true);
+        c->stage_d[q].release();
+        if (c->ev_stage[q]) (void)hipEventDestroy(c->ev_stage[q]);
+        if (c->ev_widen[q]) (void)hipEventDestroy(c->ev_widen[q]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_x) (void)hipEventDestroy(c->ev_x);
     for (auto &e : c->ev_k1) if (e) (void)hipEventDestroy(e);
@@ -490,12 +601,13 @@ void reo_destroy(reo_ctx *c)
     c->raw.release(); c->delta_list.release(); c->cont.release(); c->result.release(); c->sorted_d.release(); c->sorted_p.release();
     c->rank_s.release(); c->rank_a.release(); c->scal.release(); c->blockmin.release();
     c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->olist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->check_flag.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
-    if (c->host_state) (void)hipHostFree(c->host_state);
-    if (c->host_flags) (void)hipHostFree(c->host_flags);
+    if (c->host_state) pool_free(c->host_state, sizeof(IterState), true);
+    if (c->host_flags) pool_free(c->host_flags, 8 * sizeof(int32_t), true);
     if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
-    if (c->host_ref) (void)hipHostFree(c->host_ref);
+    if (c->host_ref) pool_free(c->host_ref, c->host_ref_cap, true);
     (void)hipStreamDestroy(c->stream);
-    delete c;
+    delete c;   // (its remaining DevBuf members are empty by now)
+    tl_release_synced = false;
 }
 
 int32_t reo_set_shard(reo_ctx *c, int32_t rank, int32_t world)
@@ -788,9 +900,9 @@ int32_t reo_identify_degs(reo_ctx *c, const uint8_t *ref0, double pval_deg, doub
     // mask and initial loop state through pinned host memory, and zeros(r,15) (:398), the K2 mode log and the histograms
     // cleared, all in one launch (kernels.hip, k_iter_init)
     if (c->host_ref_cap < static_cast<size_t>(G)) {
-        if (c->host_ref) (void)hipHostFree(c->host_ref);
+        if (c->host_ref) pool_free(c->host_ref, c->host_ref_cap, true);   // (the last call that read it has been waited for)
         c->host_ref = nullptr; c->host_ref_cap = 0;
-        REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_ref), static_cast<size_t>(c->Gp)));
+        REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->host_ref), static_cast<size_t>(c->Gp), true));
         c->host_ref_cap = static_cast<size_t>(c->Gp);
     }
     int32_t nref = 0;
@@ -1004,12 +1116,12 @@ int32_t reo_get_timings(reo_ctx *c, double *ms, int32_t n)
 int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
 {
     if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
-    const int64_t v[19] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
+    const int64_t v[20] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
                            c->tiles_owned, c->tiles_total, kTileI, c->k1_cj, c->k1_q, kUnitH,
                            c->goff32.empty() ? 0 : c->goff32.back(), c->last_k1_shared,
                            static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t)), c->transform_in_lds, c->xcc_local,
-                           c->it_cycle_period, c->it_cycle_at, c->it_cycle_skipped};
-    for (int i = 0; i < n && i < 19; ++i) info[i] = v[i];
+                           c->it_cycle_period, c->it_cycle_at, c->it_cycle_skipped, c->narrowed_bytes};
+    for (int i = 0; i < n && i < 20; ++i) info[i] = v[i];
     return REO_OK;
 }
 

@@ -119,6 +119,16 @@ void set_error(const char *fmt, ...);
         }                                                                                \
     } while (0)
 
+// Process-wide cache of device (and pinned host) blocks (api.hip).  The drop-in call makes a context, runs and destroys it
+// (julia/RankCompV3HIP.jl): about forty hipMalloc / hipFree pairs per call cost 6 ms at config 3 -- as much as the whole step.  A
+// released block goes to a free list instead (up to REO_DEVICE_CACHE_MB, default 16384; 0 switches the cache off) and the next
+// request of that size on that device takes it from there; reo_trim_memory() gives everything back.  hipFree waits for the device
+// before it unmaps; a cached block must be just as idle before someone else gets it, so release() waits for the device unless the
+// caller says it has waited already (reo_destroy: after its streams, once for all of its buffers).
+hipError_t pool_alloc(void **p, size_t bytes, bool pinned);
+void pool_free(void *p, size_t bytes, bool pinned);
+extern thread_local bool tl_release_synced;   // the releasing thread has waited for everything that used the blocks it releases
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -131,13 +141,16 @@ struct DevBuf {
     {
         if (count <= n && p) return REO_OK;
         release();
-        REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&p), count * sizeof(T), false));
         n = count;
         return REO_OK;
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (!tl_release_synced) (void)hipDeviceSynchronize();   // (what hipFree did implicitly)
+            pool_free(p, n * sizeof(T), false);
+        }
         p = nullptr;
         n = 0;
     }
@@ -199,9 +212,17 @@ struct reo_ctx {
     // pipelined upload of a host matrix (transform.hip, eager_upload): chunks on an upload stream, ranked as they arrive
     int eager_mode = 2;                  // REO_EAGER_UPLOAD: 0 off, 1 transform only, 2 (default) the pair kernel's sides as well
     int eager_chunk = 0;                 // REO_EAGER_CHUNK: columns per chunk (0: about 8 MB)
-    hipStream_t up = nullptr;            // the upload stream
+    hipStream_t up = nullptr, rk = nullptr;   // the upload stream; the stream that widens, ranks and slices the chunks (high priority)
     hipEvent_t ev_up[8] = {nullptr};     // chunk k has arrived (ring)
+    hipEvent_t ev_rk[2] = {nullptr, nullptr};   // fork from / join into the context's stream
     reo::DevBuf<int32_t> e_lists;        // [S] columns, [S + padding] slots, in column order
+    // narrowed upload of Int64 matrices: host threads convert a chunk to 16- or 32-bit numbers in a pinned staging slot, a kernel widens it
+    int upload_threads = 12;             // REO_UPLOAD_THREADS (0: the caller's array goes over the link as it is)
+    unsigned char *stage_h[3] = {nullptr, nullptr, nullptr};   // pinned staging slots (from the block cache)
+    size_t stage_cap = 0;                // bytes of each
+    reo::DevBuf<unsigned char> stage_d[3];
+    hipEvent_t ev_stage[3] = {nullptr, nullptr, nullptr}, ev_widen[3] = {nullptr, nullptr, nullptr};
+    int64_t narrowed_bytes = 0;          // bytes the last pipelined upload put on the link (reo_get_info 19)
     bool eager_k1 = false;               // reo_set_matrix has already launched the pair kernel of comparison 0 on this data, groups and thresholds
     int has_ties = 0;
     int transform_in_lds = 0;  // the last transform sorted each sample inside one workgroup's LDS (transform.hip)

@@ -24,7 +24,12 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <numeric>
+#include <thread>
 #include <type_traits>
 
 #include "reo_internal.h"
@@ -1050,7 +1055,7 @@ int32_t transform_impl(reo_ctx *c)
     // (up to 65 535 genes: positions are 16-bit numbers.  Above 32 768 genes the histogram forms use 16-bit bins / keep their low-bit
     //  rows in L2, and the bucket form keeps its gene row in L2.)
     if (G <= 65535 && !(env && env[0] == 's')) {
-        if (!c->host_flags) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t)));
+        if (!c->host_flags) REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t), true));
         if (!c->ev_flags) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming));
         int32_t *fl = c->host_flags;
         bool wide = !kCountingPath<T> || (env && env[0] == 'w');
@@ -1157,6 +1162,95 @@ int32_t transform_impl(reo_ctx *c)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Narrowed upload of Int64 matrices (round 5).  PCIe is the floor of the drop-in call's upload (57 GB/s measured from pageable memory:
+// 2.8 ms for the 160 MB of config 3), and Matrix(df_expr) of count data or ranks is Int64 numbers that fit 16 or 32 bits.  A few host
+// threads convert each chunk into a pinned staging buffer as 16-bit (then 32-bit) numbers -- 140 GB/s of source with 8 threads,
+// tools/microbench_narrow.cpp -- the link carries a quarter (half) of the bytes, and a kernel widens them into the Int64 matrix in
+// HBM that every other kernel reads.  Exact: a chunk with a value that does not fit is converted again one width up (the widths only
+// grow: 2 -> 4 -> 8 bytes = the caller's array itself), so what arrives is the caller's matrix, bit for bit.
+class HostPool {   // process-wide worker threads (started on first use, asleep otherwise, never joined: the process ends with them)
+public:
+    static HostPool &get(int want)
+    {
+        static HostPool *inst = new HostPool();
+        HostPool *p = inst;
+        std::lock_guard<std::mutex> lk(p->mu_);
+        while (static_cast<int>(p->th_.size()) < want - 1) {   // (the caller is a worker too)
+            p->th_.emplace_back([p] { p->worker(); });
+            p->th_.back().detach();
+        }
+        return *p;
+    }
+    // fn(task) for task = 0 .. ntasks - 1, on the workers and the calling thread; returns when every task is done
+    void run(int ntasks, const std::function<void(int)> &fn)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &fn; total_.store(ntasks); next_.store(0); pending_ = ntasks; ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    void work()
+    {
+        for (;;) {
+            const int t = next_.fetch_add(1);
+            if (t >= total_.load()) return;
+            (*job_)(t);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void worker()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (!job_) continue;
+            }
+            work();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(int)> *job_ = nullptr;
+    std::atomic<int> next_{0}, total_{0};
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+};
+
+template <class N>
+static bool narrow_columns(const int64_t *src, int64_t ld, int64_t G, int col0, int col1, N *dst)   // false: some value does not fit N
+{
+    int64_t bad = 0;
+    for (int cidx = col0; cidx < col1; ++cidx) {
+        const int64_t *s = src + static_cast<int64_t>(cidx) * ld;
+        N *d = dst + static_cast<int64_t>(cidx) * G;
+        for (int64_t i = 0; i < G; ++i) { const int64_t v = s[i]; const N w = static_cast<N>(v); d[i] = w; bad |= v ^ static_cast<int64_t>(w); }
+    }
+    return bad == 0;
+}
+
+template <class N>
+__global__ __launch_bounds__(256) void t_widen(const N *__restrict__ src, long long *__restrict__ dst, size_t n)
+{
+    const size_t base = static_cast<size_t>(blockIdx.x) * 2048 + threadIdx.x;   // consecutive lanes, consecutive numbers: no alignment to care about
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t i = base + static_cast<size_t>(k) * 256;
+        if (i < n) dst[i] = static_cast<long long>(src[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Pipelined upload (round 5): reo_set_matrix_i64 / _f64 from HOST memory when groups (and thresholds) are already known.
 // The drop-in call hands over a pageable column-major host matrix (julia/RankCompV3HIP.jl at src/RankCompV3.jl:652); the transform
 // is per sample and the pair kernel's items are per side (= per group), so nothing has to wait for the whole matrix:
@@ -1205,23 +1299,41 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     if ((rc = c->t_pos16.ensure(n)) || (rc = c->t_lo16.ensure(n)) || (rc = c->t_hi16.ensure(n)) ||
         (rc = c->pos.ensure(nq)) || (rc = c->lo.ensure(nq)) || (rc = c->hi.ensure(nq)))
         return rc;
-    if (!c->host_flags) REO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t)));
+    if (!c->host_flags) REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t), true));
+    // Three streams.  `up` carries the copies and never waits for a kernel of the other two.  `rk` (high priority) widens, ranks and
+    // slices the chunks as they arrive.  The context's own stream `st` runs the pair kernel's sides, each behind the slicing of
+    // its group (an event), so that side 0 counts while group 1's chunks are still being copied, widened and ranked beside it --
+    // on one stream the ranking of group 1 (and, with it, the staging ring of the narrowed upload) queued up behind side 0.
     if (!c->up) {
+        int lo_pri = 0, hi_pri = 0;
+        REO_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
         REO_HIP_CHECK(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking));
+        REO_HIP_CHECK(hipStreamCreateWithPriority(&c->rk, hipStreamNonBlocking, hi_pri));
         for (auto &e : c->ev_up) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_rk) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    hipStream_t rk = c->rk;
+    struct OnStream {   // the transform's launchers enqueue on the context's stream: it is `rk` while one of these lives
+        reo_ctx *c; hipStream_t saved;
+        OnStream(reo_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
+        ~OnStream() { c->stream = saved; }
+    };
     T *dX = reinterpret_cast<T *>(c->dX_owned.p);
     const bool wide = !kCountingPath<T>;
     c->transform_in_lds = 0;
     c->table_prezeroed = false;
+    REO_HIP_CHECK(hipEventRecord(c->ev_rk[0], st));            // (the cleared flags, the lists)
+    REO_HIP_CHECK(hipStreamWaitEvent(rk, c->ev_rk[0], 0));
     if (with_k1) {   // the class table is cleared once, in front of everything; the side launches keep what is there
         REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * 4 * c->Wp * sizeof(uint32_t), st));
     }
-    tic(c, 0);
     if (npad) {   // rows of zeros for the padding slots of every group (no data needed)
-        if ((rc = launch_lds_ranking<T>(c, dX, SampleList{d_cols, d_slots + S, 0, npad}, d_flags.p, wide))) return rc;
+        OnStream on(c, rk);
+        tic(c, 0);
+        rc = launch_lds_ranking<T>(c, dX, SampleList{d_cols, d_slots + S, 0, npad}, d_flags.p, wide);
+        toc(c);
+        if (rc) return rc;
     }
-    toc(c);
     // Chunks: a ranking launch is one workgroup per sample and takes a sample's time (30 us for counts, 180 us for Float64) however few
     // samples it has, so a chunk wants enough samples to fill the 256 CUs (measured at 20 000 x 1 000, tools/from_host_breakdown.py:
     // chunks of 52 columns made the Float64 ranking 4.4 ms in all instead of 1.0); and it ends where the group label changes, so
@@ -1233,47 +1345,114 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     int sides_done = 0, ranked = 0, ranked_at_read = -1;
     bool fallback = false, bad_values = false;
     int32_t *fl = c->host_flags;
-    auto read_flags = [&]() -> int32_t {   // the flags so far (waits for the rankings queued so far)
-        REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        REO_HIP_CHECK(hipStreamSynchronize(st));
+    auto read_flags = [&]() -> int32_t {   // the flags so far (waits for the rankings queued so far, not for the pair kernel)
+        REO_HIP_CHECK(hipMemcpyAsync(fl, d_flags.p, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, rk));
+        REO_HIP_CHECK(hipStreamSynchronize(rk));
         ranked_at_read = ranked;
         if (fl[0]) bad_values = true;
         if (fl[4] || fl[5]) fallback = true;
         return REO_OK;
     };
     int nchunk = 0;
+    // narrowed upload (Int64 only): staging ring, worker threads
+    constexpr int kStage = 3;
+    int width = 8, nslot = 0, nthreads = 1;
+    HostPool *pool = nullptr;
+    c->narrowed_bytes = 0;
+    if (std::is_same<T, int64_t>::value && c->upload_threads > 0) {
+        const size_t slot_bytes = static_cast<size_t>(std::min(CH, S)) * G * 4;
+        for (int q = 0; q < kStage; ++q) {
+            if (c->stage_cap < slot_bytes) {
+                if (c->stage_h[q]) { pool_free(c->stage_h[q], c->stage_cap, true); c->stage_h[q] = nullptr; }
+                REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->stage_h[q]), slot_bytes, true));
+            }
+            if ((rc = c->stage_d[q].ensure(slot_bytes))) return rc;
+            if (!c->ev_stage[q]) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_stage[q], hipEventDisableTiming));
+            if (!c->ev_widen[q]) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_widen[q], hipEventDisableTiming));
+        }
+        c->stage_cap = std::max(c->stage_cap, slot_bytes);
+        nthreads = std::max(1, std::min<int>(c->upload_threads, static_cast<int>(std::thread::hardware_concurrency())));
+        pool = &HostPool::get(nthreads);
+        width = 2;
+    }
     for (int c0 = 0; c0 < S; ++nchunk) {
         int nc = std::min(CH, S - c0);
         for (int s = c0 + 1; s < c0 + nc; ++s)   // cut at the first change of label that leaves a chunk worth launching
             if (c->group_id[s] != c->group_id[s - 1] && s - c0 >= std::min(CH, 64)) { nc = s - c0; break; }
-        // the copy: pageable source, so the call returns when the runtime has staged the chunk; the upload stream never waits for
-        // a kernel (a ring of events hands each chunk to the compute stream)
-        if (hld == c->G) REO_HIP_CHECK(hipMemcpyAsync(dX + static_cast<size_t>(c0) * G, hX + static_cast<size_t>(c0) * hld, static_cast<size_t>(nc) * G * sizeof(T), hipMemcpyHostToDevice, c->up));
-        else REO_HIP_CHECK(hipMemcpy2DAsync(dX + static_cast<size_t>(c0) * G, G * sizeof(T), hX + static_cast<size_t>(c0) * hld, hld * sizeof(T), G * sizeof(T), nc, hipMemcpyHostToDevice, c->up));
         hipEvent_t ev = c->ev_up[nchunk % 8];
-        REO_HIP_CHECK(hipEventRecord(ev, c->up));
-        REO_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
+        bool sent = false;
+        if constexpr (std::is_same<T, int64_t>::value) {
+            // narrowed: host threads convert the chunk into pinned staging slot `sl` (16-bit, then 32-bit numbers), the link carries
+            // that, t_widen writes the Int64 columns.  The slot's pinned half is free when the copy that read it is done (ev_stage);
+            // its device half when the widening is (the next copy into it follows on the same stream).
+            while (width < 8 && !sent) {
+                const int sl = nslot % kStage;
+                if (nslot >= kStage) REO_HIP_CHECK(hipEventSynchronize(c->ev_stage[sl]));
+                unsigned char *hs = c->stage_h[sl];
+                std::atomic<int> fits{1};
+                const int per = (nc + nthreads - 1) / nthreads;
+                pool->run(nthreads, [&](int t) {
+                    const int a = std::min(nc, t * per), b = std::min(nc, a + per);
+                    if (a >= b) return;
+                    const int64_t *src = reinterpret_cast<const int64_t *>(hX) + static_cast<int64_t>(c0) * hld;
+                    const bool ok = width == 2 ? narrow_columns<int16_t>(src, hld, G, a, b, reinterpret_cast<int16_t *>(hs))
+                                               : narrow_columns<int32_t>(src, hld, G, a, b, reinterpret_cast<int32_t *>(hs));
+                    if (!ok) fits.store(0);
+                });
+                if (!fits.load()) { width *= 2; continue; }   // (this chunk again, one width up; the widths only grow)
+                const size_t nel = static_cast<size_t>(nc) * G;
+                // copy and widening both on the upload stream: the slot's device half is free again when its widening is done, whatever
+                // the ranking stream is waiting for (its workgroups want a whole CU each and find none while a side of the pair kernel
+                // runs: with the widening on that stream the staging ring -- and so the upload -- stood still behind them)
+                REO_HIP_CHECK(hipMemcpyAsync(c->stage_d[sl].p, hs, nel * width, hipMemcpyHostToDevice, c->up));
+                REO_HIP_CHECK(hipEventRecord(c->ev_stage[sl], c->up));
+                long long *dst = reinterpret_cast<long long *>(dX) + static_cast<size_t>(c0) * G;
+                const unsigned grid = static_cast<unsigned>((nel + 2047) / 2048);
+                if (width == 2) t_widen<int16_t><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int16_t *>(c->stage_d[sl].p), dst, nel);
+                else t_widen<int32_t><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int32_t *>(c->stage_d[sl].p), dst, nel);
+                REO_HIP_CHECK(hipGetLastError());
+                REO_HIP_CHECK(hipEventRecord(c->ev_widen[sl], c->up));
+                REO_HIP_CHECK(hipStreamWaitEvent(rk, c->ev_widen[sl], 0));
+                ++nslot;
+                sent = true;
+                c->narrowed_bytes += static_cast<int64_t>(nel) * width;
+            }
+        }
+        if (!sent) {
+            // the copy: pageable source, so the call returns when the runtime has staged the chunk; the upload stream never waits for
+            // a kernel (a ring of events hands each chunk to the ranking stream)
+            if (hld == c->G) REO_HIP_CHECK(hipMemcpyAsync(dX + static_cast<size_t>(c0) * G, hX + static_cast<size_t>(c0) * hld, static_cast<size_t>(nc) * G * sizeof(T), hipMemcpyHostToDevice, c->up));
+            else REO_HIP_CHECK(hipMemcpy2DAsync(dX + static_cast<size_t>(c0) * G, G * sizeof(T), hX + static_cast<size_t>(c0) * hld, hld * sizeof(T), G * sizeof(T), nc, hipMemcpyHostToDevice, c->up));
+            REO_HIP_CHECK(hipEventRecord(ev, c->up));
+            REO_HIP_CHECK(hipStreamWaitEvent(rk, ev, 0));
+            c->narrowed_bytes += static_cast<int64_t>(nc) * G * 8;
+        }
         const int cbeg = c0;
         c0 += nc;
         if (fallback || bad_values) continue;   // (the rest of the matrix still has to arrive)
-        tic(c, 0);
-        if ((rc = launch_lds_ranking<T>(c, dX, SampleList{d_cols + cbeg, d_slots + cbeg, nc, nc}, d_flags.p, wide))) return rc;
-        ranked = c0;
         int ready = 0;   // groups whose last sample is in this chunk: their blocks are complete and can be sliced into bit planes
-        for (int s = cbeg; s < cbeg + nc; ++s) {
-            const int g = c->group_id[s];
-            if (--left[g] != 0) continue;
-            ready |= 1 << std::min(g, 30);
-            const int b0 = c->goff32[g] / 32, nb = (c->goff32[g + 1] - c->goff32[g]) / 32;
-            t_slice<<<dim3(Gp / 512, nb), 256, 0, st>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p, b0);
-            REO_HIP_CHECK(hipGetLastError());
+        {
+            OnStream on(c, rk);
+            tic(c, 0);
+            rc = launch_lds_ranking<T>(c, dX, SampleList{d_cols + cbeg, d_slots + cbeg, nc, nc}, d_flags.p, wide);
+            ranked = c0;
+            for (int s = cbeg; s < cbeg + nc && !rc; ++s) {
+                const int g = c->group_id[s];
+                if (--left[g] != 0) continue;
+                ready |= 1 << std::min(g, 30);
+                const int b0 = c->goff32[g] / 32, nb = (c->goff32[g + 1] - c->goff32[g]) / 32;
+                t_slice<<<dim3(Gp / 512, nb), 256, 0, rk>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p, b0);
+                if (hipGetLastError() != hipSuccess) { set_error("t_slice launch failed"); rc = REO_EHIP; }
+            }
+            toc(c);
+            if (rc) return rc;
         }
-        toc(c);
         if (with_k1 && ready) {   // two groups: side 0 counts group 0's samples, side 1 group 1's (k = 0)
             if ((rc = read_flags())) return rc;
             if (fallback || bad_values) continue;
             const int mask = ready & 3;
             c->has_ties = fl[1];   // ties seen SO FAR: covers every sample of this side (the tie-free loop is exact on a side without ties)
+            // (the planes of this side are in place: the host has just waited for the ranking stream)
             if ((rc = launch_k1(c, 0, mask, true))) return rc;
             sides_done |= mask;
         }
@@ -1282,6 +1461,9 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     // the flags are final if they were read behind the last ranking (the boundary of the last group: the usual case) -- reading
     // them again would wait for the second side's pair kernel, which the host has no need to wait for here
     if (ranked_at_read != S && !bad_values && !fallback && (rc = read_flags())) return rc;
+    // whatever follows on the context's stream (reo_build_pairs, the fall-back transform) is ordered behind the ranking stream
+    REO_HIP_CHECK(hipEventRecord(c->ev_rk[1], rk));
+    REO_HIP_CHECK(hipStreamWaitEvent(st, c->ev_rk[1], 0));
     c->transformed = false;
     if (bad_values) {
         set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "

@@ -570,7 +570,8 @@ def _eager_ctx(pkg, X, group, seed, pval_reo=0.01):
     return ctx
 
 
-@pytest.mark.parametrize("kind", ["ranks", "counts", "float", "big_int", "three_groups", "interleaved", "unequal", "view_ld", "small"])
+@pytest.mark.parametrize("kind", ["ranks", "counts", "float", "big_int", "three_groups", "interleaved", "unequal", "view_ld", "small",
+                                  "negative", "huge_int", "growing"])
 def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
     """reo_set_matrix_i64 / _f64 from host memory with the groups already set (round 5): the columns travel in chunks, samples are
     ranked as they arrive, a group's blocks are sliced when its last sample is in, and (two groups, one GPU, thresholds set) the
@@ -591,6 +592,10 @@ def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
     elif kind == "unequal": X = pkg.synth.t0_ranks(G, S, seed); group = ["u"] * 37 + ["v"] * (S - 37)
     elif kind == "view_ld":
         big = np.asfortranarray(np.full((G + 24, S), -7, dtype=np.int64)); big[8:8 + G, :] = pkg.synth.t1_counts(G, S, seed); X = big[8:8 + G, :]
+    elif kind == "negative": X = rng.integers(-30000, 30000, size=(G, S)); X[5, 7] = -32768; X[6, 299] = 32767     # the 16-bit limits exactly
+    elif kind == "huge_int": X = rng.integers(-2 ** 40, 2 ** 40, size=(G, S))                                      # no narrow width fits: the caller's array itself
+    elif kind == "growing":                                                                                        # widths grow on the way: 16 bits, then 32, then 64
+        X = rng.integers(0, 30000, size=(G, S)); X[:, 130:] += 40000; X[17, 135] = 2 ** 31 - 1; X[G - 1, 280] = -2 ** 31 - 1
     else: G, S = 700, 41; X = pkg.synth.t1_counts(G, S, seed); group = pkg.synth.groups(S)
     ref0 = pkg.synth.ref_mask(G, G // 5, seed)
     ng = len(set(group))
@@ -605,14 +610,30 @@ def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
             return out
 
     want = outputs(_setup(pkg, X, group, seed)[0])
-    for mode in ("2", "1", "0"):
+    # (REO_UPLOAD_THREADS: Int64 chunks cross the link as 16- or 32-bit numbers when they fit, converted by that many host threads and
+    #  widened on the device; 0 = the caller's array as it is.  REO_EAGER_CHUNK=37: many small chunks, the staging ring goes round.)
+    for mode, threads, chunk in (("2", None, None), ("1", None, None), ("0", None, None), ("2", "0", None), ("2", "3", "37")):
         monkeypatch.setenv("REO_EAGER_UPLOAD", mode)
-        got = outputs(_eager_ctx(pkg, X, group, seed))
+        for name, val in (("REO_UPLOAD_THREADS", threads), ("REO_EAGER_CHUNK", chunk)):
+            if val is None: monkeypatch.delenv(name, raising=False)
+            else: monkeypatch.setenv(name, val)
+        ctxe = _eager_ctx(pkg, X, group, seed)
+        link = ctxe.info()["upload_link_bytes"]
+        if mode != "0" and threads != "0" and kind in ("ranks", "negative", "big_int"):
+            assert link == X.size * (2 if kind in ("ranks", "negative") else 4), (kind, link)     # what the link carried
+        elif mode != "0" and threads != "0" and kind in ("counts", "growing"):
+            assert X.size * 2 < link < X.size * 8, (kind, link)                                   # chunk by chunk: the narrowest width that fits
+        elif mode != "0" and (kind in ("float", "huge_int") or threads == "0"):
+            assert link == X.size * 8, (kind, link)
+        elif mode != "0":
+            assert X.size * 2 <= link <= X.size * 8, (kind, link)
+        got = outputs(ctxe)
         for (c0, t0, (r0, i0, tr0), h0), (c1, t1, (r1, i1, tr1), h1) in zip(want, got):
             assert np.array_equal(c0, c1), (kind, mode, "class table")
             assert np.array_equal(t0, t1) and i0 == i1 and tr0 == tr1 and h0 == h1, (kind, mode)
             assert np.array_equal(r0, r1, equal_nan=True), (kind, mode, "statistics")
-    monkeypatch.delenv("REO_EAGER_UPLOAD")
+    for name in ("REO_EAGER_UPLOAD", "REO_UPLOAD_THREADS", "REO_EAGER_CHUNK"):
+        monkeypatch.delenv(name, raising=False)
     # rebuilds on the same context, a second matrix, new thresholds
     if ng == 2:
         with _eager_ctx(pkg, X, group, seed) as ctx:

@@ -24,5 +24,6 @@ $CLANG -shared -fPIC -fsanitize=address -shared-libasan -o $B/libreo_hip_asan_mo
     $B/api.o $B/kernels.o $B/transform.o $B/pseudobulk.o $B/comm.o -L$B -lmockhip -Wl,-rpath,$B
 RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.asan-x86_64.so" | head -1)
 export LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1 REO_LIB_PATH=$B/libreo_hip_asan_mock.so REO_MOCK_LIB=$B/libmockhip.so
-python3 tools/asan_host_mock_calls.py "$@"
+REO_DEVICE_CACHE_MB=0 python3 tools/asan_host_mock_calls.py "$@"     # every release is a free: ASan sees use-after-release at once
+python3 tools/asan_host_mock_calls.py "$@"                           # the block cache on (the default): blocks travel between contexts
 echo "asan_host_mock: clean"

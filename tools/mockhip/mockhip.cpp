@@ -23,17 +23,24 @@ namespace {
 struct Call { dim3 g, b; size_t shmem; hipStream_t st; };
 thread_local std::vector<Call> g_calls;
 std::mutex g_mu;
-void *g_iterstate = nullptr;      // last pinned allocation of IterState's size
-size_t g_iterstate_bytes = 0;
+std::map<void *, size_t> g_pinned;   // live pinned allocations
 long g_launches = 0, g_copies = 0;
 int tok;                          // address used for opaque handles
 void advance_state()
 {
+    // IterState lives in a small pinned block; since the library takes its pinned blocks from a cache (4 KB classes) the mock cannot
+    // tell it from the two other small pinned blocks of a context (the transform's flags, the reference mask on its way to the
+    // device), so every small pinned block gets the two words.  In the flags block that reads as "the data has ties" -- harmless.
     const char *e = getenv("MOCKHIP_N_ITER");
-    if (!e || !g_iterstate) return;
-    int32_t *w = static_cast<int32_t *>(g_iterstate);
+    if (!e) return;
     const int n = atoi(e);
-    if (n > 0) { w[1] = n; w[11] = 1; }   // IterState.passes, .last_full (reo_internal.h)
+    if (n <= 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_pinned) {
+        if (kv.second < 64 || kv.second > 16384) continue;   // (a 4 KB request may be served by a cached block a little larger)
+        int32_t *w = static_cast<int32_t *>(kv.first);
+        w[1] = n; w[11] = 1;   // IterState.passes, .last_full (reo_internal.h)
+    }
 }
 }  // namespace
 
@@ -87,12 +94,12 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned)
 {
     *p = calloc(1, n ? n : 1);
     std::lock_guard<std::mutex> lk(g_mu);
-    if (n >= 64 && n <= 256) { g_iterstate = *p; g_iterstate_bytes = n; }
+    if (*p) g_pinned[*p] = n;
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 hipError_t hipHostFree(void *p)
 {
-    { std::lock_guard<std::mutex> lk(g_mu); if (p == g_iterstate) g_iterstate = nullptr; }
+    { std::lock_guard<std::mutex> lk(g_mu); g_pinned.erase(p); }
     free(p);
     return hipSuccess;
 }
@@ -108,8 +115,11 @@ hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { advance_state(); return hipSuccess; }
+hipError_t hipDeviceSynchronize() { advance_state(); return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t) { advance_state(); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = reinterpret_cast<hipEvent_t>(malloc(8)); return hipSuccess; }
