@@ -36,6 +36,7 @@
 //
 // Wave = 64 lanes everywhere; no warp-32 idiom is used.
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -3701,6 +3702,21 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table)
                                      static_cast<uint64_t>(wave ? std::max(a.ce - a.cb, a.te - a.tb) : c->goff32[c->ngroups] / 32),
                                  static_cast<uint64_t>(sides) << 48 | static_cast<uint64_t>(part) << 32 | static_cast<uint32_t>(nparts)};
         if (!cache.buf.p || std::memcmp(key, cache.key, sizeof key) != 0) {
+            // The list is a function of the geometry alone: a process-wide store keeps the last few as host vectors, so that a NEW context
+            // on the same problem shape (the drop-in call makes one per identify_degs) does not build and sort it again (0.9 ms per
+            // side at config 3, on the critical path of the pipelined upload).
+            struct Stored { uint64_t key[7]; std::vector<uint32_t> units, items; };
+            static std::mutex store_mu;
+            static std::vector<Stored> *store = new std::vector<Stored>();
+            const uint64_t skey[7] = {key[0], key[1], key[2], key[3], key[4], static_cast<uint64_t>(c->n_cus), static_cast<uint64_t>(big ? 1 : 0) << 1 | static_cast<uint64_t>(wide ? 1 : 0)};
+            std::vector<uint32_t> items;
+            bool have = false;
+            {
+                std::lock_guard<std::mutex> lk(store_mu);
+                for (const Stored &st : *store)
+                    if (std::memcmp(st.key, skey, sizeof skey) == 0 && st.units == units) { items = st.items; have = true; break; }
+            }
+            if (!have) {
             // Workgroup b runs on XCD b & 7.  An item goes to the list of XCD (wave chunk & 7), and an XCD walks its list
             // group by group of its chunks (as many pos chunks of one side as fit about 2.5 MB of its 4 MiB L2), inside a
             // group side-major, then i-tile-major, chunks fastest: the group's pos planes stay in that L2 while each tile
@@ -3726,22 +3742,28 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table)
                             ++total_items;
                         }
                 }
-            for (auto &l : lists)
-                std::sort(l.begin(), l.end(), [per_group](uint32_t x, uint32_t y) {
-                    const uint32_t cx = (x >> 16) & 0x7FFFu, cy = (y >> 16) & 0x7FFFu;
-                    const uint32_t gx = (cx >> 3) / static_cast<uint32_t>(per_group), gy = (cy >> 3) / static_cast<uint32_t>(per_group);
-                    if (gx != gy) return gx < gy;
-                    if ((x >> 31) != (y >> 31)) return (x >> 31) < (y >> 31);
-                    if ((x & 0xFFFFu) != (y & 0xFFFFu)) return (x & 0xFFFFu) < (y & 0xFFFFu);
-                    return cx < cy;
-                });
+            // order inside an XCD's list: chunk group, side, i-tile, chunk -- sorted as one 64-bit key per item (the comparator form,
+            // with its two divisions per comparison, took 0.9 ms per side at config 3)
+            std::vector<uint64_t> keys;
+            for (auto &l : lists) {
+                keys.resize(l.size());
+                for (size_t q = 0; q < l.size(); ++q) {
+                    const uint32_t x = l[q], cx = (x >> 16) & 0x7FFFu;
+                    keys[q] = static_cast<uint64_t>((cx >> 3) / static_cast<uint32_t>(per_group)) << 32 | static_cast<uint64_t>(x >> 31) << 31 |
+                              static_cast<uint64_t>(x & 0xFFFFu) << 15 | cx;
+                }
+                std::sort(keys.begin(), keys.end());
+                for (size_t q = 0; q < l.size(); ++q) {
+                    const uint64_t k = keys[q];
+                    l[q] = static_cast<uint32_t>((k >> 31) & 1u) << 31 | static_cast<uint32_t>(k & 0x7FFFu) << 16 | static_cast<uint32_t>((k >> 15) & 0xFFFFu);
+                }
+            }
             const size_t per = (total_items + 7) / 8;
             std::vector<uint32_t> surplus;
             for (auto &l : lists)
                 while (l.size() > per) { surplus.push_back(l.back()); l.pop_back(); }
             for (auto &l : lists)
                 while (l.size() < per && !surplus.empty()) { l.push_back(surplus.back()); surplus.pop_back(); }
-            std::vector<uint32_t> items;
             items.reserve(total_items);
             for (size_t k = 0; k < per; ++k)
                 for (auto &l : lists)
@@ -3762,6 +3784,13 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table)
                         for (uint32_t x : tail) items.push_back(x | 0x8000u | (half ? 0x4000u : 0u));
                 }
             }
+                std::lock_guard<std::mutex> lk(store_mu);
+                if (store->size() >= 16) store->erase(store->begin());
+                Stored st;
+                std::memcpy(st.key, skey, sizeof skey);
+                st.units = units; st.items = items;
+                store->push_back(std::move(st));
+            }   // (!have)
             int32_t rc2;
             if ((rc2 = cache.buf.ensure(std::max<size_t>(items.size(), 1)))) return rc2;
             if (!items.empty()) {
@@ -3871,7 +3900,9 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table)
     }
     if (wave || (wcounts && !c->gc_valid) || wmulti) {
         reo_ctx::ItemList &il = c->k1_wave_items[sides == 3 ? 0 : sides];   // (a side's list keeps its own slot: the two sides of a pipelined upload alternate)
+        const auto w0 = std::chrono::steady_clock::now();
         if ((rc = item_list(units, il, 0, 1))) return rc;
+        if (c->debug_passes) fprintf(stderr, "  launch_k1 sides %d: item list (%zu items) ready after %.0f us\n", sides, il.n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count());
         a.items = il.buf.p; c->k1_items_n = il.n;
         if (c->k1_stamps) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), (std::max<size_t>(c->k1_items_n, 1) * 4 + 2) * sizeof(unsigned long long)));
     }

@@ -24,6 +24,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -1266,6 +1267,10 @@ __global__ __launch_bounds__(256) void t_widen(const N *__restrict__ src, long l
 template <class T>
 int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
 {
+    const auto w_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {   // REO_DEBUG_PASSES: where the host is, microseconds since the call began
+        if (c->debug_passes) fprintf(stderr, "  eager_upload: %s at %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w_begin).count());
+    };
     const int G = static_cast<int>(c->G), S = static_cast<int>(c->S), Gp = c->Gp;
     hipStream_t st = c->stream;
     int32_t rc;
@@ -1375,6 +1380,7 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
         pool = &HostPool::get(nthreads);
         width = 2;
     }
+    stamp("buffers, streams, lists ready");
     for (int c0 = 0; c0 < S; ++nchunk) {
         int nc = std::min(CH, S - c0);
         for (int s = c0 + 1; s < c0 + nc; ++s)   // cut at the first change of label that leaves a chunk worth launching
@@ -1448,16 +1454,20 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
             if (rc) return rc;
         }
         if (with_k1 && ready) {   // two groups: side 0 counts group 0's samples, side 1 group 1's (k = 0)
+            stamp("a group's last chunk enqueued");
             if ((rc = read_flags())) return rc;
+            stamp("its flags read");
             if (fallback || bad_values) continue;
             const int mask = ready & 3;
             c->has_ties = fl[1];   // ties seen SO FAR: covers every sample of this side (the tie-free loop is exact on a side without ties)
             // (the planes of this side are in place: the host has just waited for the ranking stream)
             if ((rc = launch_k1(c, 0, mask, true))) return rc;
+            stamp("its side of the pair kernel launched");
             sides_done |= mask;
         }
     }
     REO_HIP_CHECK(hipStreamSynchronize(c->up));   // the whole matrix has been read: the caller may have its array back
+    stamp("upload stream idle");
     // the flags are final if they were read behind the last ranking (the boundary of the last group: the usual case) -- reading
     // them again would wait for the second side's pair kernel, which the host has no need to wait for here
     if (ranked_at_read != S && !bad_values && !fallback && (rc = read_flags())) return rc;
