@@ -21,7 +21,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#ifdef REO_WITH_ROCPRIM   // tools only (A/B against the library's segmented sort): the shipped library has no library call on this path
 #include <rocprim/rocprim.hpp>
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -67,6 +69,7 @@ struct Codec<int64_t> {
     __device__ static bool finite(int64_t) { return true; }
 };
 
+#ifdef REO_WITH_ROCPRIM   // the segmented-sort form of the transform (rounds 1-4): built for A/B runs only (make ROCPRIM=1)
 template <class T, class IdxT>
 __global__ __launch_bounds__(256) void t_keys(const T *__restrict__ X, int64_t ld,
                                               const int32_t *__restrict__ colmap, int G, int cb0,
@@ -134,6 +137,8 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
     lo[o] = static_cast<IdxT>(l);
     hi[o] = static_cast<IdxT>(h + 1);
 }
+
+#endif  // REO_WITH_ROCPRIM
 
 // One workgroup per sample, everything in LDS: when the varying key bits fit 31 bits and the genes fit
 // 1024 x IPT items, the sample's column is read once, sorted with a block radix sort (rocprim block
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
             l = s0 + smaller; h = l + equal; p = l + before;
         }
         if constexpr (std::is_same<T, double>::value) {  // the band is wider than the equal values: two more rank queries
-l = rank_of(band_edge_code<false>(x, k), false);
+            l = rank_of(band_edge_code<false>(x, k), false);
             h = rank_of(band_edge_code<true>(x, k), true);
         }
         tied |= h - l > 1u;
@@ -788,6 +793,196 @@ l = rank_of(band_edge_code<false>(x, k), false);
     }
     if (tied && *anytie == 0) atomicOr(anytie, 1);
     TSTAMP(6);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// t_sample_big (round 5): the bucket ranking of t_sample_wide for MORE THAN 65 535 GENES (up to kMaxGenes = 262 143), every input type.
+// A sample's per-gene rows no longer fit the LDS (2 bytes per gene would be 512 KB), so only the splitters and the 32-bit bins stay
+// there (80 KB) and the by-slot row moves to a scratch row in L2 -- ONE 64-bit record per slot: gene | bucket word << 32 | the 16 offset
+// bits << 48, so a scan reads one word per member.  Positions are 18-bit numbers: 32-bit output rows (t_slice_big makes the planes).
+// Same algorithm otherwise: 1 024 sample splitters, 16 sub-buckets + an equality bucket each, rank queries = prefix sum + scan of
+// one bucket, Float64 band edges in code space with the reference's own predicate (src/RankCompV3.jl:72).  This replaces
+// rocprim::segmented_radix_sort_pairs, the last library call on the product path.
+template <class T>
+__global__ __launch_bounds__(1024) void t_sample_big(const T *__restrict__ X, int64_t ld, const int32_t *__restrict__ colmap,
+                                                     const int32_t *__restrict__ slots, int G, int Gp,
+                                                     uint32_t *__restrict__ pos, uint32_t *__restrict__ lo, uint32_t *__restrict__ hi,
+                                                     int32_t *__restrict__ flags, uint64_t *__restrict__ recs)   // [samples of the launch][Gp]
+{
+    constexpr int LOGSUB = 4, SUB = 1 << LOGSUB, PER = SUB + 1, NB = kSplit1 * PER;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *spl = reinterpret_cast<unsigned long long *>(smem);   // [1024] sorted splitters; [1024..1039] wave maxima
+    uint32_t *hist = reinterpret_cast<uint32_t *>(spl + kSplit1 + 16);         // [NB + 1] bins, skewed by one word in 32
+    constexpr int HW = NB + 1;
+    uint32_t *wtot = hist + HW + (HW >> 5) + 1;                               // 16 wave totals
+    auto at = [](uint32_t b) { return b + (b >> 5); };
+    auto HB = [&](uint32_t b) -> uint32_t { return hist[at(b)]; };
+    const int t = threadIdx.x, c = blockIdx.x;
+    const T *col = X + static_cast<int64_t>(colmap[c]) * ld;
+    const size_t orow = static_cast<size_t>(slots[c]) * Gp;
+    uint32_t *prow = pos + orow, *lrow = lo + orow, *hrow = hi + orow;
+    uint64_t *rec = recs + static_cast<size_t>(c) * Gp;
+    int32_t *anytie = flags + 1;
+    // ---- 1. the column's maximum, non-finite values; the sample, sorted
+    uint64_t kmax = 0;
+    bool bad = false;
+#pragma unroll 8
+    for (int i = t; i < G; i += 1024) {
+        const T x = col[i];
+        bad |= !Codec<T>::finite(x);
+        const uint64_t k = Codec<T>::enc(x);
+        kmax = k > kmax ? k : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint64_t b = __shfl_xor(kmax, o, 64); kmax = b > kmax ? b : kmax; }
+    if ((t & 63) == 0) spl[kSplit1 + (t >> 6)] = kmax;
+    if (__ballot(bad) != 0 && (t & 63) == 0) atomicOr(flags, 1);
+    for (int b = t; b < HW + (HW >> 5) + 1; b += 1024) hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint64_t b = spl[kSplit1 + w]; kmax = b > kmax ? b : kmax; }
+    {
+        uint64_t v = t == kSplit1 - 1 ? kmax : Codec<T>::enc(col[static_cast<int>((static_cast<int64_t>(t) * G) >> 10)]);
+        for (int k = 2; k <= kSplit1; k <<= 1) {   // bitonic sort, one key per thread
+            const bool up = (t & k) == 0;
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                uint64_t pv;
+                if (j >= 64) {
+                    __syncthreads();
+                    spl[t] = v;
+                    __syncthreads();
+                    pv = spl[t ^ j];
+                } else {
+                    pv = __shfl_xor(v, j, 64);
+                }
+                const bool keep_min = ((t & j) == 0) == up;
+                const bool take = keep_min ? pv < v : pv > v;
+                v = take ? pv : v;
+            }
+        }
+        __syncthreads();
+        spl[t] = v;
+    }
+    __syncthreads();
+    auto locate = [&](uint64_t k, uint32_t &bucket, uint32_t &r16, bool &exact) {   // as in t_sample_wide
+        int lb = 0;
+#pragma unroll
+        for (int s = kSplit1 / 2; s > 0; s >>= 1) lb += spl[lb + s - 1] < k ? s : 0;
+        const uint64_t to = spl[lb];
+        if (to == k) { bucket = lb * PER + SUB; r16 = 0; exact = true; return; }
+        const uint64_t from = lb ? spl[lb - 1] : 0ULL, width = to - from, o = k - from;
+        const int bits = 64 - __builtin_clzll(width);
+        const int sh = bits > LOGSUB ? bits - LOGSUB : 0;
+        bucket = lb * PER + static_cast<uint32_t>(o >> sh);
+        const int rs = sh > 16 ? sh - 16 : 0;
+        r16 = static_cast<uint32_t>((o & ((1ULL << sh) - 1ULL)) >> rs);
+        exact = sh <= 16;
+    };
+    // ---- 2. histogram; the arrival slot is parked in the pos row, bucket word and offset bits in the lo row (32-bit rows)
+#pragma unroll 2
+    for (int i = t; i < G; i += 1024) {
+        const uint64_t k = Codec<T>::enc(col[i]);
+        uint32_t b, r; bool ex;
+        locate(k, b, r, ex);
+        prow[i] = atomicAdd(&hist[at(b)], 1u);
+        lrow[i] = b | (ex ? 0x8000u : 0u) | (r << 16);
+    }
+    __syncthreads();
+    {   // exclusive prefix sums of the bins, in place: thread t owns the PER bins of splitter t
+        uint32_t cnt[PER], tot = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { cnt[u] = HB(t * PER + u); tot += cnt[u]; }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += up; }
+        if ((t & 63) == 63) wtot[t >> 6] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot;
+        for (int w = 0; w < (t >> 6); ++w) run += wtot[w];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { hist[at(t * PER + u)] = run; run += cnt[u]; }
+        if (t == kSplit1 - 1) hist[at(NB)] = static_cast<uint32_t>(G);
+    }
+    __syncthreads();
+    // ---- 3. members into bucket order: one record per slot
+#pragma unroll 4
+    for (int i = t; i < G; i += 1024) {
+        const uint32_t w = lrow[i], sl = HB(w & 0x7FFFu) + prow[i];
+        rec[sl] = static_cast<uint64_t>(static_cast<uint32_t>(i)) | (static_cast<uint64_t>(w) << 32);   // gene | bucket word << 32 | offset bits << 48
+    }
+    __syncthreads();   // (workgroup barrier: the records written above are visible to every thread of this workgroup)
+    auto rank_of = [&](uint64_t cq, bool le) -> uint32_t {   // number of genes whose code is below cq (le: below or equal)
+        if (cq > kmax) return static_cast<uint32_t>(G);
+        uint32_t b, cr; bool exact;
+        locate(cq, b, cr, exact);
+        const uint32_t s0 = HB(b), s1 = HB(b + 1);
+        if (b % PER == SUB) return le ? s1 : s0;
+        uint32_t n = 0;
+        for (uint32_t q0 = s0; q0 < s1; q0 += 4) {   // four records per round trip
+            uint64_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = q0 + u < s1 ? rec[q0 + u] : ~0ULL;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q0 + u >= s1) break;
+                const uint32_t r = static_cast<uint32_t>(w[u] >> 48);
+                if (r < cr) ++n;
+                else if (r == cr) {
+                    if (exact) n += le ? 1u : 0u;
+                    else { const uint64_t k = Codec<T>::enc(col[static_cast<uint32_t>(w[u])]); n += (k < cq || (le && k == cq)) ? 1u : 0u; }
+                }
+            }
+        }
+        return s0 + n;
+    };
+    // ---- 4. pos, lo, hi, slot by slot (the lanes of a wave take consecutive slots: members of the same or of neighbouring buckets)
+    bool tied = false;
+#pragma unroll 1
+    for (int sl = t; sl < G; sl += 1024) {
+        const uint64_t w = rec[sl];
+        const uint32_t gene = static_cast<uint32_t>(w), bw = static_cast<uint32_t>(w >> 32) & 0xFFFFu, mr = static_cast<uint32_t>(w >> 48), me = static_cast<uint32_t>(sl);
+        const uint32_t b = bw & 0x7FFFu;
+        const bool exact = (bw & 0x8000u) != 0;
+        // The gene's own value is a scattered 8-byte read of a column that no cache holds at this size (256 workgroups x 0.5-2 MB): only
+        // Float64 (band edges) and a bucket wider than 2^16 codes need it -- an Int64 key in an exact bucket IS (bucket, offset bits).
+        const bool need_x = std::is_same<T, double>::value || !exact;
+        T x = T(0);
+        uint64_t k = 0;
+        if (need_x) { x = col[gene]; k = Codec<T>::enc(x); }
+        const uint32_t s0 = HB(b), s1 = HB(b + 1);
+        uint32_t l, h, p;
+        if (b % PER == SUB) {  // one value: slot order
+            l = s0; h = s1; p = me;
+        } else {
+            uint32_t smaller = 0, equal = 1, before = 0;
+            for (uint32_t q0 = s0; q0 < s1; q0 += 4) {   // four records per round trip
+                uint64_t wq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wq[u] = q0 + u < s1 ? rec[q0 + u] : ~0ULL;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t q = q0 + u;
+                    if (q >= s1) break;
+                    const uint32_t r = static_cast<uint32_t>(wq[u] >> 48);
+                    smaller += r < mr ? 1u : 0u;
+                    if (r == mr && q != me) {
+                        if (exact) { ++equal; before += q < me ? 1u : 0u; }
+                        else { const uint64_t kq = Codec<T>::enc(col[static_cast<uint32_t>(wq[u])]); smaller += kq < k ? 1u : 0u; equal += kq == k ? 1u : 0u; before += (kq == k && q < me) ? 1u : 0u; }
+                    }
+                }
+            }
+            l = s0 + smaller; h = l + equal; p = l + before;
+        }
+        if constexpr (std::is_same<T, double>::value) {  // the band is wider than the equal values: two more rank queries
+            l = rank_of(band_edge_code<false>(x, k), false);
+            h = rank_of(band_edge_code<true>(x, k), true);
+        }
+        tied |= h - l > 1u;
+        // (the pos / lo rows still hold the parked words of OTHER genes that later slots of this loop do not read any more: phase 3 was
+        //  the last reader of a parked word, and it is behind a barrier)
+        prow[gene] = p; lrow[gene] = l; hrow[gene] = h;
+    }
+    if (tied && *anytie == 0) atomicOr(anytie, 1);
 }
 
 // 16-bit rows -> bit planes over 32-sample blocks.  One thread per (pair of genes, block): reads the genes' 32 numbers
@@ -963,10 +1158,12 @@ int32_t launch_lds_ranking(reo_ctx *c, const T *X, const SampleList &d_order, in
     return launch_sample_wide<T, 3, false>(c, X, d_order, d_flags);
 }
 
+#ifdef REO_WITH_ROCPRIM
 struct SegOff {
     unsigned G;
     __host__ __device__ unsigned operator()(unsigned i) const { return i * G; }
 };
+#endif
 
 template <class T>
 int32_t transform_impl(reo_ctx *c)
@@ -1099,10 +1296,36 @@ int32_t transform_impl(reo_ctx *c)
                 return finish(fl[1], true);
             }
             REO_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, 6 * sizeof(int32_t), st));
-            if (wide || fl[4]) break;  // a crowded bucket of different values: the segmented sort
+            if (wide) { set_error("the bucket form of the ranking flagged a sample: internal error"); return REO_EHIP; }   // (it takes every input: never seen)
             wide = true;               // some sample needs the bucket form: all of them take it
         }
     }
+    if (big && !(env && env[0] == 's')) {
+        // more than 65 535 genes: the bucket ranking with its by-slot records in L2 (t_sample_big); rows of padding slots and padded
+        // genes keep the zeros of the memsets above.  Launched in batches when the records of all samples would not fit 4 GiB.
+        const size_t lds = 8 * (kSplit1 + 16) + 4 * (static_cast<size_t>(kSplit1) * 17 + 1 + ((static_cast<size_t>(kSplit1) * 17 + 1) >> 5) + 1 + 17) + 16;
+        REO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(t_sample_big<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const int batch = static_cast<int>(std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(S), (size_t(4) << 30) / (static_cast<size_t>(Gp) * 8))));
+        if ((rc = c->t_kin.ensure(static_cast<size_t>(batch) * Gp))) return rc;
+        for (int s0 = 0; s0 < S; s0 += batch) {
+            const int ns = std::min(batch, S - s0);
+            t_sample_big<T><<<static_cast<unsigned>(ns), 1024, lds, st>>>(X, c->ld, d_order.p + s0, c->t_slots.p + s0, G, Gp, c->t_pos32.p, c->t_lo32.p, c->t_hi32.p,
+                                                                      d_flags.p, c->t_kin.p);
+            REO_HIP_CHECK(hipGetLastError());
+        }
+        if ((rc = slice())) return rc;
+        int32_t flags[2] = {0, 0};
+        REO_HIP_CHECK(hipMemcpyAsync(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost, st));
+        REO_HIP_CHECK(hipStreamSynchronize(st));
+        if (flags[0]) {
+            set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
+                      "src/RankCompV3.jl:601)");
+            return REO_EINVAL;
+        }
+        c->transform_in_lds = 3;   // (ranked inside one workgroup per sample; rows in L2)
+        return finish(flags[1], true);
+    }
+#ifdef REO_WITH_ROCPRIM
     if (!big) {  // the segmented path writes the genes of the samples only: padding slots and padded genes read as zero
         REO_HIP_CHECK(hipMemsetAsync(c->t_pos16.p, 0, n * sizeof(uint16_t), st));
         REO_HIP_CHECK(hipMemsetAsync(c->t_lo16.p, 0, n * sizeof(uint16_t), st));
@@ -1160,6 +1383,12 @@ int32_t transform_impl(reo_ctx *c)
         return REO_EINVAL;
     }
     return finish(flags[1], false);
+#else
+    (void)finish; (void)d_varbits;
+    set_error("REO_TRANSFORM=segmented: this build of libreo_hip carries no segmented sort (the library's rocprim call left the product path in "
+              "round 5; `make ROCPRIM=1` in csrc builds the A/B variant)");
+    return REO_EINVAL;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -689,11 +689,22 @@ def test_host_matrix_view_with_leading_dimension(pkg, oracle):
 
 
 def _counts_blocks(pkg, X, gid, ngroups, blocks, seed=3):
-    with pkg.Context(device=0, seed=seed) as ctx:
-        ctx.set_matrix(X)
-        ctx.set_groups(gid, ngroups)
-        out = [ctx.pair_counts(*b) for b in blocks]
-        return out, ctx.info()
+    """Counts of pair blocks as the library ranks the data.  With REO_TRANSFORM=segmented in the environment the caller asks for the
+    SECOND implementation of the transform (rocprim's segmented sort, rounds 1-4).  Since round 5 the shipped library carries no
+    rocprim (`make ROCPRIM=1` builds the A/B variant): then the second opinion is the oracle's literal comparator itself."""
+    try:
+        with pkg.Context(device=0, seed=seed) as ctx:
+            ctx.set_matrix(X)
+            ctx.set_groups(gid, ngroups)
+            out = [ctx.pair_counts(*b) for b in blocks]
+            return out, ctx.info()
+    except pkg.DimensionMismatch as e:
+        if os.environ.get("REO_TRANSFORM") != "segmented" or "no segmented sort" not in str(e):
+            raise
+        import __graft_entry__ as ge
+        orc = ge.load_oracle()
+        Xf = np.asarray(X, dtype=np.float64)
+        return [orc.pair_counts(Xf, np.asarray(gid, dtype=np.int32), ngroups, *b) for b in blocks], {"transform_in_lds": 0, "has_ties": None}
 
 
 def _varying_key_bits(X):
@@ -1224,15 +1235,17 @@ def test_full_identify_degs_at_65535_genes(pkg, oracle):
     _check_result(run.result, exp)
 
 
-@pytest.mark.parametrize("G,S,family,n_iter", [(70000, 24, "t1", 8), (140000, 16, "t0", 6)])
-def test_more_than_65535_genes(pkg, oracle, G, S, family, n_iter):
-    """Above 65 535 genes positions take 17 or 18 bit planes (round 3): 32-bit transform rows on the segmented path, the
-    big plane layout, the generated count loop for NB = 17 / 18 at two waves per SIMD, the sorting passes with their
-    splitter tables in dynamic LDS (the light passes are not used there).  Sampled blocks of the class table against the
-    oracle's counts -- first / last columns, the diagonal, across the 65 536 boundary, the padded tail -- and the whole
-    run (trace, tallies, statistics) against the oracle."""
+@pytest.mark.parametrize("G,S,family,n_iter", [(70000, 24, "t1", 8), (140000, 16, "t0", 6), (70000, 24, "float", 4), (66000, 24, "big_int", 4)])
+def test_more_than_65535_genes(pkg, oracle, G, S, family, n_iter, monkeypatch):
+    """Above 65 535 genes positions take 17 or 18 bit planes (round 3): 32-bit transform rows, the big plane layout, the
+    generated count loop for NB = 17 / 18 at two waves per SIMD, the sorting passes with their splitter tables in dynamic LDS.
+    Round 5: every sample is ranked by ONE workgroup here too (t_sample_big: the bucket ranking with its by-slot records in L2;
+    Int64 of any width and Float64 with the 0.1 band) -- rocprim's segmented sort is no longer on the path (REO_TRANSFORM=segmented
+    still runs it: compared below).  Sampled blocks of the class table against the oracle's counts -- first / last columns, the
+    diagonal, across the 65 536 boundary, the padded tail -- and the whole run (trace, tallies, statistics) against the oracle."""
     seed = 0x5EED0065
-    X = (pkg.synth.t1_counts if family == "t1" else pkg.synth.t0_ranks)(G, S, seed)
+    X = {"t1": pkg.synth.t1_counts, "t0": pkg.synth.t0_ranks, "float": pkg.synth.float_expr,
+         "big_int": lambda G_, S_, seed_: np.random.default_rng(seed_).integers(-2 ** 40, 2 ** 40, size=(G_, S_))}[family](G, S, seed)
     group = np.array(["a", "b"] * (S // 2), dtype=object)      # interleaved groups: the transform re-orders the samples
     gid, lev = pkg.encode_groups(group)
     ref0 = pkg.synth.ref_mask(G, 3000, seed)
@@ -1242,7 +1255,7 @@ def test_more_than_65535_genes(pkg, oracle, G, S, family, n_iter):
         thr = ctx.compute_thresholds(0.05)
         ctx.build_pairs(0)
         info = ctx.info()
-        assert info["has_ties"] == (1 if family == "t1" else 0) and info["transform_in_lds"] == 0
+        assert info["has_ties"] == (1 if family in ("t1", "float") else 0) and info["transform_in_lds"] == 3
         for (i0, j0, n) in [(0, G - 40, 40), (0, 0, 40), (65520, 65520, 48), (65500, 100, 40), (100, 65530, 40), (G - 48, G - 48, 48),
                             (G - 33, 17, 32), (40000, G - 300, 32)]:
             exp = _expected_block_codes(oracle, Xf, gid, thr, seed, i0, i0 + n, j0, j0 + n)
@@ -1257,6 +1270,16 @@ def test_more_than_65535_genes(pkg, oracle, G, S, family, n_iter):
     exp, eit, etr = oracle.identify_degs(Xf, gid, 2, 0.05, 1.0, 0.05, ref0, n_iter, 3, seed)
     assert iters == eit and trace == etr, (iters, eit, trace, etr)
     _check_result(res, exp)
+    # the library's segmented sort (rounds 3-4) gives the same counts, everywhere sampled
+    blocks = [(0, 64, G - 64, G), (65500, 65564, 0, 64), (G - 64, G, 30000, 30064), (12345, 12409, 54321, 54385)]
+    with pkg.Context(device=0, seed=seed) as ctx:
+        ctx.set_matrix(X); ctx.set_groups(gid, 2)
+        mine = [ctx.pair_counts(*b) for b in blocks]
+    monkeypatch.setenv("REO_TRANSFORM", "segmented")
+    other, info_o = _counts_blocks(pkg, X, gid, 2, blocks, seed=seed)   # (the A/B build's segmented sort, or the oracle)
+    for b, (gt, eq), (sgt, seq) in zip(blocks, mine, other):
+        assert np.array_equal(gt, sgt) and np.array_equal(eq, seq), b
+    assert info_o["transform_in_lds"] == 0
 
 
 def test_gene_count_limits(pkg, oracle, monkeypatch):
@@ -1266,6 +1289,17 @@ def test_gene_count_limits(pkg, oracle, monkeypatch):
     with pkg.Context(device=0, seed=1) as ctx:
         with pytest.raises(pkg.ReoError):
             ctx.set_matrix(np.zeros((262144, 2), dtype=np.int64))
+    # the largest gene count, ranked by t_sample_big (counts with many repeated values, then Float64): sampled counts against the oracle
+    Gm, Sm = 262143, 4
+    for Xm in (rng.integers(0, 3000, size=(Gm, Sm)), np.round(rng.normal(8, 2, size=(Gm, Sm)), 3)):
+        with pkg.Context(device=0, seed=1) as ctx:
+            ctx.set_matrix(Xm); ctx.set_groups([0, 1, 0, 1], 2)
+            for (i0, i1, j0, j1) in ((0, 32, Gm - 64, Gm), (Gm - 32, Gm, 0, 64), (131000, 131032, 200000, 200064)):
+                gt, eq = ctx.pair_counts(i0, i1, j0, j1)
+                egt, eeq = oracle.pair_counts(Xm.astype(np.float64), np.array([0, 1, 0, 1], dtype=np.int32), 2, i0, i1, j0, j1)
+                assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), (Xm.dtype, i0, j0)
+            assert ctx.info()["transform_in_lds"] == 3
+    pkg._ffi.trim_memory()   # (a 34 GB class table went back to the block cache: return it to the driver)
     G, S, seed = 66000, 9, 0x5EED0067
     X = rng.integers(0, 1000, size=(G, S))
     gid = np.array([0, 1, 2, 0, 1, 2, 0, 1, 2], dtype=np.int32)

@@ -107,7 +107,7 @@ os.environ["REO_SHARE_GROUP_COUNTS"] = "0"; one(3000, 70, ngroups=7); del os.env
 # (REO_LIGHT=2 and REO_STATE_MIRROR=0 copy the DEVICE copy of the loop state back, which no kernel has written here: only with the block
 #  cache off, when the mock's fresh "device" blocks are zeros)
 unmirrored = (("REO_LIGHT", "2"), ("REO_STATE_MIRROR", "0")) if os.environ.get("REO_DEVICE_CACHE_MB") == "0" else ()
-for e, v in (("REO_LIGHT", "0"), ("REO_LIGHT", "3"), ("REO_K1_WAVE", "0"), ("REO_TRANSFORM", "segmented"), ("REO_TRANSFORM", "wide"),
+for e, v in (("REO_LIGHT", "0"), ("REO_LIGHT", "3"), ("REO_K1_WAVE", "0"), ("REO_TRANSFORM", "wide"),
              ("REO_EAGER_UPLOAD", "0"), ("REO_EAGER_UPLOAD", "1"), ("REO_EAGER_CHUNK", "7")) + unmirrored:
     os.environ[e] = v; one(9000, 40, n_iter=12); one(9000, 41, n_iter=3, ints=False); del os.environ[e]
 L.reo_trim_memory()

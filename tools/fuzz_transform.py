@@ -1,4 +1,5 @@
-"""Randomized parity run of the rank/band transform at LARGE gene counts (not part of the test suite): random G up to 65 535,
+"""Randomized parity run of the rank/band transform at LARGE gene counts (not part of the test suite): random G up to 65 535 (with a
+third argument `big`: 65 536 ... 262 143, the records-in-L2 form t_sample_big, form 3),
 few samples, every kind of data (ranks, small counts, long-tailed counts, wide and negative integers, log-expression floats,
 floats on a 0.1 grid), random pair blocks compared with the oracle's literal comparator; which form of the transform ran is
 tallied (1 histogram forms, 2 bucket form, 0 segmented sort).  python tools/fuzz_transform.py [N] [seed]"""
@@ -11,9 +12,12 @@ pkg = ge.load_pkg(); oracle = ge.load_oracle()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31337)
 
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+
 def case():
     G = int(rng.choice([rng.integers(1000, 20481), rng.integers(20481, 32769), rng.integers(32769, 41473), rng.integers(41473, 58369), rng.integers(58369, 65536), 65535]))
-    S = int(rng.integers(6, 15))
+    if BIG: G = int(rng.choice([65536, rng.integers(65536, 90000), rng.integers(90000, 180000), rng.integers(180000, 262144), 262143]))
+    S = int(rng.integers(6, 15)) if not BIG else int(rng.integers(2, 7))
     kind = str(rng.choice(["ranks", "small_int", "tail", "wide_int", "big_int", "float_expr", "float_band", "float_cont", "float_zeros"]))
     if kind == "ranks": X = np.argsort(np.argsort(rng.random((G, S)), axis=0), axis=0)
     elif kind == "small_int": X = rng.integers(0, int(rng.integers(2, 40)), size=(G, S))

@@ -1,0 +1,5 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5g
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "more_than_65535_genes or gene_count_limits" > $O/big_tests.log 2>&1
