@@ -107,7 +107,7 @@ __device__ uint32_t tie_wins(uint64_t seed, uint32_t i, uint32_t j, uint32_t g, 
 //     lt <- majority(~p_k, u_k, lt)                       one v_bitop3_b32 (truth table 0x8e) per bit plane
 //     n_gt += popcount(lt)                                one v_bcnt_u32_b32 per 32 samples
 // i.e. (NB + 1) / 32 instructions per comparison instead of the two packed float ops of round 1.  Measured on
-// MI355X (tools/microbench_bitop.hip, tools/k1b_proto.hip): v_bitop3_b32 with three VGPR sources issues at full
+// MI355X (tools/microbench_bitop.hip, tools/history/k1b_proto.hip): v_bitop3_b32 with three VGPR sources issues at full
 // rate (1.0-1.2 ns per wave-instruction per SIMD), at half rate with an SGPR source or when its three sources share
 // a VGPR bank, and v_bcnt / v_lshl_add at half rate; v_bfi_b32 + v_xor_b32 (two ops per bit) is no faster than
 // the float form.  Lane = gene j (RJ genes per lane, 64 apart), the 32 genes i of the tile are wave-uniform and
