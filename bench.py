@@ -9,9 +9,16 @@ makes the convergence test of src/RankCompV3.jl:419 never true, i.e. exactly 128
 the run with the reference's default n_conv = 5 is reported beside it as `converged`, and the tie-rich family (count
 data: two comparisons per pair and sample) as `tie_rich`.
 
-Two more blocks ride on the same line: `float64` (the same shape as Float64 input: the reference's other eltype, ranked
-through the 0.1 tie band) and `config4` (BASELINE config 4, 30 000 x 4 000 -- the shape BASELINE.json names for the
-1/2/4/8-GPU scaling -- forced and converging run, K1 roofline, per-rank stage times when N > 1).
+More blocks ride on the same line: `float64` (the same shape as Float64 input: the reference's other eltype, ranked
+through the 0.1 tie band), `config4` (BASELINE config 4, 30 000 x 4 000 -- the shape BASELINE.json names for the
+1/2/4/8-GPU scaling -- forced and converging run, K1 roofline, per-rank stage times when N > 1), `cycle_watch` (the
+library's default: whole periods of a loop that repeats itself are skipped) and, since round 5, `from_host`: the DROP-IN
+call, whose matrix starts in pageable host memory as the Julia shim hands it over (upload alone, the pipelined call
+sequence, the sequence of rounds 1-4, a context per call) for config 3 as Int64 and Float64 and for config 4.  `value`
+never includes an upload.  `cpu_baseline` times the reference-faithful C restatement on the WHOLE config-3 workload
+(about 40 s on the GPU box's 128 threads) and checks its trace against the GPU's.
+With N > 1 nothing is timed before every rank's sharded build of a small problem has reproduced rank 0's unsharded
+class table, trace and tallies (`sharded_equals_unsharded`; exit status 3 otherwise).
 
 `dtype` is "u16": the pair kernel compares 16-bit sorted positions, bit-sliced over 32-sample blocks (v_bitop3_b32
 borrow chains + v_bcnt_u32_b32); the tallies are integer popcounts and the per-gene statistics fp64.
@@ -155,16 +162,6 @@ def main() -> None:
                     ctx.comm_init_rank(box[0], rank, world)
         return ctx
 
-    def table_and_trace_hash(ctx_, G_, ref_, n_iter_=8):
-        """64-bit hash of the whole class table (every ordered pair's class, reo_get_codes) and of the iteration's trace + tallies"""
-        import hashlib
-        h = hashlib.blake2b(digest_size=8)
-        for i0 in range(0, G_, 1024):
-            h.update(ctx_.get_codes(i0, min(G_, i0 + 1024), 0, G_).tobytes())
-        res_, it_, tr_ = ctx_.identify_degs(ref_, 1.0, 0.05, n_iter_, 0)
-        h.update(np.asarray(tr_, dtype=np.int64).tobytes()); h.update(np.ascontiguousarray(res_[:, 2:11]).tobytes())
-        return h.hexdigest()
-
     sharded_ok = None
     if world > 1 or force_comm:
         # The first run with more than one rank must not produce a number from a wrong table: before anything is timed every rank
@@ -176,7 +173,7 @@ def main() -> None:
         refs_ = pkg.synth.ref_mask(Gs_, 2000, seeds_)
         def small(ctx_):
             ctx_.set_matrix(Xs_); ctx_.set_groups(gids_, len(levs_)); ctx_.compute_thresholds(0.01); ctx_.build_pairs(0)
-            return table_and_trace_hash(ctx_, Gs_, refs_)
+            return pkg.dist.table_trace_digest(ctx_, Gs_, refs_)   # 64-bit digest of every pair's class + 8-pass trace + tallies
         ctxs_ = make_ctx()
         mine_ = small(ctxs_)
         ctxs_.close()

@@ -1414,6 +1414,7 @@ public:
     // fn(task) for task = 0 .. ntasks - 1, on the workers and the calling thread; returns when every task is done
     void run(int ntasks, const std::function<void(int)> &fn)
     {
+        std::lock_guard<std::mutex> one_job(run_mu_);   // contexts of different threads share the pool: their jobs take turns
         {
             std::lock_guard<std::mutex> lk(mu_);
             job_ = &fn; total_.store(ntasks); next_.store(0); pending_ = ntasks; ++gen_;
@@ -1448,7 +1449,7 @@ private:
             work();
         }
     }
-    std::mutex mu_;
+    std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_;
     std::vector<std::thread> th_;
     const std::function<void(int)> *job_ = nullptr;

@@ -111,3 +111,19 @@ def run_identify_degs_sharded(data, group, gene_names, pval_reo, pval_deg, padj_
     hook = allgather_hook(torch.device("cuda", device_index)) if world > 1 else None  # the gather form: a quarter of the sum's bytes
     return run_identify_degs(data, group, gene_names, pval_reo, pval_deg, padj_deg, ref_gene, n_iter, n_conv,
                              seed=seed, device=device_index, shard=(rank, world), allgather=hook, profile=profile)
+
+
+def table_trace_digest(ctx, G: int, ref0, n_iter: int = 8, rows_per_call: int = 1024) -> str:
+    """64-bit digest (hex) of everything a sharded build must reproduce: the class of EVERY ordered gene pair (reo_get_codes over the
+    whole G x G table, row blocks), then the iteration's trace and the nine tallies of every gene after `n_iter` forced passes.
+    bench.py compares it across ranks and with an unsharded build before it times anything with more than one rank."""
+    import hashlib
+    import numpy as np
+    h = hashlib.blake2b(digest_size=8)
+    for i0 in range(0, G, rows_per_call):
+        h.update(np.ascontiguousarray(ctx.get_codes(i0, min(G, i0 + rows_per_call), 0, G)).tobytes())
+    res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, n_iter, 0)
+    h.update(np.asarray([iters], dtype=np.int64).tobytes())
+    h.update(np.asarray(trace, dtype=np.int64).tobytes())
+    h.update(np.ascontiguousarray(res[:, 2:11]).tobytes())
+    return h.hexdigest()

@@ -1145,7 +1145,8 @@ def test_one_context_through_many_problems(pkg, oracle):
 
 def test_contexts_in_concurrent_host_threads(pkg, oracle):
     """Three callers, each with its own context on the same device, running at the same time (ctypes drops the GIL during a
-    call): contexts share nothing but the device and the per-device self-test verdict; reo_last_error is per thread."""
+    call): contexts share the device, the per-device self-test verdict and -- since round 5 -- the process-wide block cache, the
+    host thread pool of the narrowed upload and the store of pair-kernel work lists; reo_last_error is per thread."""
     import threading
     seed = 77
     jobs = []
@@ -1156,11 +1157,14 @@ def test_contexts_in_concurrent_host_threads(pkg, oracle):
 
     def work(job):
         try:
-            for rep in range(3):
+            for rep in range(4):
                 with pkg.Context(device=0, seed=seed) as ctx:
-                    ctx.set_matrix(job["X"])
+                    if rep % 2 == 0:   # the matrix first (one copy), or groups and thresholds first: the pipelined, narrowed upload, whose
+                        ctx.set_matrix(job["X"])          # host thread pool, staging blocks and work-list store the contexts of all threads share
                     ctx.set_groups(job["gid"], job["ng"])
                     ctx.compute_thresholds(0.01)
+                    if rep % 2 == 1:
+                        ctx.set_matrix(job["X"])
                     ctx.build_pairs(0)
                     job["out"].append(ctx.identify_degs(job["ref0"], 1.0, 0.05, 24, 0))
         except Exception as e:  # noqa: BLE001 -- reported by the main thread

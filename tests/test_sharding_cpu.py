@@ -224,3 +224,30 @@ def test_generated_count_loops_are_current(pkg):
     csrc = os.path.join(ROOT, "rankcompv3.jl_amd", "csrc")
     out = subprocess.run([sys.executable, os.path.join(csrc, "gen_k1_loop.py")], capture_output=True, text=True, check=True).stdout
     assert out == open(os.path.join(csrc, "k1_loop_gen.inc")).read()
+
+
+def test_digest_of_table_and_trace_sees_every_difference(pkg):
+    """bench.py --gpus N refuses to time a sharded run whose class table, trace or tallies differ from the unsharded build's: the
+    64-bit digest it compares (dist.table_trace_digest) must change when ONE pair's class, one trace entry or one tally changes, must
+    not depend on how the table is read in row blocks, and must be the same for equal inputs.  (A stand-in context: no GPU.)"""
+    rng = np.random.default_rng(5)
+    G = 300
+    codes = rng.integers(0, 9, size=(G, G)).astype(np.uint8)
+    res = np.zeros((G, 15)); res[:, 2:11] = rng.integers(0, 50, size=(G, 9))
+    trace = [(int(a), G - int(a)) for a in rng.integers(0, 40, size=8)]
+
+    class Ctx:
+        def __init__(self, codes, res, trace): self.codes, self.res, self.trace = codes, res, trace
+        def get_codes(self, i0, i1, j0, j1): return self.codes[i0:i1, j0:j1]
+        def identify_degs(self, ref0, pval_deg, padj_deg, n_iter, n_conv): return self.res, len(self.trace), self.trace
+
+    ref0 = np.ones(G, dtype=bool)
+    base = pkg.dist.table_trace_digest(Ctx(codes, res, trace), G, ref0)
+    assert base == pkg.dist.table_trace_digest(Ctx(codes.copy(), res.copy(), list(trace)), G, ref0) and len(base) == 16
+    assert base == pkg.dist.table_trace_digest(Ctx(codes, res, trace), G, ref0, rows_per_call=37)       # block size of the read: irrelevant
+    c2 = codes.copy(); c2[G - 1, 0] ^= 1
+    r2 = res.copy(); r2[G // 2, 10] += 1
+    t2 = list(trace); t2[-1] = (t2[-1][0] + 1, t2[-1][1] - 1)
+    others = {pkg.dist.table_trace_digest(Ctx(c2, res, trace), G, ref0), pkg.dist.table_trace_digest(Ctx(codes, r2, trace), G, ref0),
+              pkg.dist.table_trace_digest(Ctx(codes, res, t2), G, ref0), pkg.dist.table_trace_digest(Ctx(codes, res, trace[:-1]), G, ref0)}
+    assert base not in others and len(others) == 4
