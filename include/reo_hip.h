@@ -144,6 +144,8 @@ int32_t reo_set_allgather(reo_ctx *ctx, reo_allgather_fn fn, void *user);
  * kernel may be running then, exactly as after reo_build_pairs on one GPU, and the reo_build_pairs(ctx, 0) that follows has nothing
  * left to do (it is still the call that makes the class table current: keep it).  Results are bit-identical in every order.  A
  * non-finite value is reported (REO_EINVAL) by whichever call reads the matrix: this one in the pipelined case.
+ * A context that is used for several matrices should keep to that order each time: a matrix handed over while the groups of the LAST
+ * problem are still set is ranked and paired with those, and all of it is done again when the new groups arrive (correct, but wasted).
  * REO_EAGER_UPLOAD=0 in the environment switches the pipelining off, =1 keeps it to the ranking. */
 int32_t reo_set_matrix_f64(reo_ctx *ctx, const double *X, int64_t G, int64_t S, int64_t ld);
 int32_t reo_set_matrix_i64(reo_ctx *ctx, const int64_t *X, int64_t G, int64_t S, int64_t ld);
