@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -324,6 +325,9 @@ namespace reo {
 // transform.hip
 int32_t run_transform(reo_ctx *c);
 int32_t eager_upload(reo_ctx *c, const void *hX, int64_t hld, bool with_k1);  // host matrix -> HBM in chunks, ranked (and paired) as they arrive
+int32_t ensure_upload_streams(reo_ctx *c);                                      // c->up, c->rk and their events (created on first use)
+int32_t ensure_staging(reo_ctx *c, size_t slot_bytes);                          // three pinned + device staging slots of at least that size, their events
+void host_parallel(int nthreads, int ntasks, const std::function<void(int)> &fn);   // fn(0 .. ntasks - 1) on the process-wide pool of host threads (and the caller)
 
 // kernels.hip
 int32_t launch_k1(reo_ctx *c, int k, int sides = 3, bool keep_table = false);  // sides: bit 0 = the comparison's own group, bit 1 = the rest (wave form; eager_upload)

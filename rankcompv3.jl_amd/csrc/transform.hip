@@ -1539,14 +1539,7 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     // slices the chunks as they arrive.  The context's own stream `st` runs the pair kernel's sides, each behind the slicing of
     // its group (an event), so that side 0 counts while group 1's chunks are still being copied, widened and ranked beside it --
     // on one stream the ranking of group 1 (and, with it, the staging ring of the narrowed upload) queued up behind side 0.
-    if (!c->up) {
-        int lo_pri = 0, hi_pri = 0;
-        REO_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
-        REO_HIP_CHECK(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking));
-        REO_HIP_CHECK(hipStreamCreateWithPriority(&c->rk, hipStreamNonBlocking, hi_pri));
-        for (auto &e : c->ev_up) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto &e : c->ev_rk) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    if ((rc = ensure_upload_streams(c))) return rc;
     hipStream_t rk = c->rk;
     struct OnStream {   // the transform's launchers enqueue on the context's stream: it is `rk` while one of these lives
         reo_ctx *c; hipStream_t saved;
@@ -1595,17 +1588,7 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     HostPool *pool = nullptr;
     c->narrowed_bytes = 0;
     if (std::is_same<T, int64_t>::value && c->upload_threads > 0) {
-        const size_t slot_bytes = static_cast<size_t>(std::min(CH, S)) * G * 4;
-        for (int q = 0; q < kStage; ++q) {
-            if (c->stage_cap < slot_bytes) {
-                if (c->stage_h[q]) { pool_free(c->stage_h[q], c->stage_cap, true); c->stage_h[q] = nullptr; }
-                REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->stage_h[q]), slot_bytes, true));
-            }
-            if ((rc = c->stage_d[q].ensure(slot_bytes))) return rc;
-            if (!c->ev_stage[q]) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_stage[q], hipEventDisableTiming));
-            if (!c->ev_widen[q]) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_widen[q], hipEventDisableTiming));
-        }
-        c->stage_cap = std::max(c->stage_cap, slot_bytes);
+        if ((rc = ensure_staging(c, static_cast<size_t>(std::min(CH, S)) * G * 4))) return rc;
         nthreads = std::max(1, std::min<int>(c->upload_threads, static_cast<int>(std::thread::hardware_concurrency())));
         pool = &HostPool::get(nthreads);
         width = 2;
@@ -1719,6 +1702,36 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
 }
 
 }  // namespace
+
+void host_parallel(int nthreads, int ntasks, const std::function<void(int)> &fn) { HostPool::get(nthreads).run(ntasks, fn); }
+
+int32_t ensure_upload_streams(reo_ctx *c)
+{
+    if (c->up) return REO_OK;
+    int lo_pri = 0, hi_pri = 0;
+    REO_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+    REO_HIP_CHECK(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking));
+    REO_HIP_CHECK(hipStreamCreateWithPriority(&c->rk, hipStreamNonBlocking, hi_pri));
+    for (auto &e : c->ev_up) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : c->ev_rk) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return REO_OK;
+}
+
+int32_t ensure_staging(reo_ctx *c, size_t slot_bytes)
+{
+    int32_t rc;
+    for (int q = 0; q < 3; ++q) {
+        if (c->stage_cap < slot_bytes) {
+            if (c->stage_h[q]) { pool_free(c->stage_h[q], c->stage_cap, true); c->stage_h[q] = nullptr; }
+            REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->stage_h[q]), slot_bytes, true));
+        }
+        if ((rc = c->stage_d[q].ensure(slot_bytes))) return rc;
+        if (!c->ev_stage[q]) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_stage[q], hipEventDisableTiming));
+        if (!c->ev_widen[q]) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_widen[q], hipEventDisableTiming));
+    }
+    c->stage_cap = std::max(c->stage_cap, slot_bytes);
+    return REO_OK;
+}
 
 int32_t eager_upload(reo_ctx *c, const void *hX, int64_t hld, bool with_k1)
 {

@@ -1006,6 +1006,49 @@ def test_pseudobulk_kernels_dense_and_csc(pkg, rn):
             ctx.pseudobulk(X2, np.array([5, 300], dtype=np.int32), np.array([0, 2], dtype=np.int32))
 
 
+@pytest.mark.parametrize("kind", ["small_counts", "wide_counts", "huge_value", "float", "many_genes"])
+def test_pseudobulk_csc_chunked_narrowed_upload(pkg, kind, monkeypatch):
+    """CSC input from host memory (round 5): the entries travel in chunks of 4 M, a pool of host threads checks the row indices and
+    narrows them (16 bits when G <= 65 536) and the Int64 values (16, else 32 bits, else the caller's array itself; the widths only
+    grow) into pinned staging, kernels widen them on the device.  Exact sums for every width, for Float64 values (not narrowed),
+    above 65 536 genes (32-bit row indices), with the narrowing switched off; a row index outside the matrix is refused."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    G, C, dens = (30000, 3200, 0.06) if kind != "many_genes" else (70000, 1100, 0.06)     # 5.8 M / 4.6 M entries: two chunks
+    nnz_per = rng.binomial(G, dens, size=C)
+    indptr = np.concatenate([[0], np.cumsum(nnz_per)]).astype(np.int64)
+    rows = np.concatenate([np.sort(rng.choice(G, n, replace=False)) for n in nnz_per]).astype(np.int32)
+    nnz = int(indptr[-1])
+    assert nnz > (4 << 20)
+    if kind == "float": vals = np.round(rng.lognormal(1.0, 1.0, nnz), 3)
+    else:
+        vals = rng.integers(1, 300, size=nnz).astype(np.int64)
+        if kind == "wide_counts": vals[rng.integers(0, nnz, 50)] = 100000           # 32 bits from the first chunk on
+        if kind == "huge_value": vals[nnz - 7] = 2 ** 40; vals[5] = -40000           # 32 bits in chunk one, the raw array in chunk two
+    X = sp.csc_matrix((vals, rows, indptr), shape=(G, C))
+    order = rng.permutation(C).astype(np.int32)
+    ptr = np.array([0, 700, 700, 1500, C], dtype=np.int32) if C > 1500 else np.array([0, 400, 400, 900, C], dtype=np.int32)
+    exp = np.stack([np.asarray(X[:, order[ptr[o]:ptr[o + 1]]].sum(axis=1)).ravel() for o in range(len(ptr) - 1)], axis=1)
+    if kind == "float":   # the reference's left-to-right order of the row sums (:63)
+        from oracle import reo_numpy as rn
+        exp = None
+    for threads in (None, "0", "3"):
+        if threads is None: monkeypatch.delenv("REO_UPLOAD_THREADS", raising=False)
+        else: monkeypatch.setenv("REO_UPLOAD_THREADS", threads)
+        with pkg.Context(device=0) as ctx:
+            got = ctx.pseudobulk(X, order, ptr)
+            if exp is None:
+                exp = got                        # Float64: bit-equal across the settings; against numpy within rounding below
+                dense = np.stack([np.asarray(X[:, order[ptr[o]:ptr[o + 1]]].sum(axis=1)).ravel() for o in range(len(ptr) - 1)], axis=1)
+                assert np.allclose(got, dense, rtol=1e-12, atol=0)
+            assert np.array_equal(got, exp), (kind, threads)
+            bad = X.copy(); bad.indices = bad.indices.copy(); bad.indices[nnz - 3] = G        # one row index outside the matrix
+            bad.has_sorted_indices = True
+            with pytest.raises(pkg.DimensionMismatch, match="row index"):
+                ctx.pseudobulk(bad, order, ptr)
+            assert np.array_equal(ctx.pseudobulk(X, order, ptr), exp)                        # the context works again
+
+
 def test_reoa_pseudobulk_mode(pkg, oracle, tmp_path):
     """reoa(n_pseudo=...) (src/RankCompV3.jl:608-612): cells -> pseudo-bulk profiles -> identify_degs."""
     import importlib
