@@ -316,11 +316,15 @@ static int32_t set_matrix(reo_ctx *c, const void *X, int64_t G, int64_t S, int64
             if (c->eager_k1) { c->built_k = 0; c->table_complete = true; }
             return REO_OK;
         }
+        // groups not known yet (or the pipelining switched off): the upload alone, chunked, Int64 narrowed
+        struct DrainUp2 {
+            reo_ctx *c;
+            ~DrainUp2() { if (c->up) (void)hipStreamSynchronize(c->up); }
+        } drain_up{c};
         DrainOnExit drain(c);
         const double w0 = wall_us();
-        REO_HIP_CHECK(hipMemcpy2DAsync(c->dX_owned.p, G * 8, X, ld * 8, G * 8, S, hipMemcpyHostToDevice, c->stream));
-        REO_HIP_CHECK(hipStreamSynchronize(c->stream));
-        drain.dismiss();
+        if ((rc = upload_columns(c, X, ld, G, S, c->dX_owned.p, dtype))) { invalidate(c); return rc; }
+        drain.dismiss();   // (upload_columns has waited for the upload stream: the caller's array has been read)
         c->t_ms[11] += (wall_us() - w0) * 1e-3;
     }
     return REO_OK;

@@ -114,7 +114,13 @@ int32_t run_dense(reo_ctx *c, const T *X, int64_t G, int64_t C, int64_t ld, cons
     if ((rc = dX.ensure(static_cast<size_t>(G) * C)) || (rc = dOut.ensure(static_cast<size_t>(G) * n_out)) ||
         (rc = dOrd.ensure(std::max<int64_t>(n_order, 1))) || (rc = dPtr.ensure(n_out + 1)))
         return rc;
-    hipError_t e = hipMemcpy2DAsync(dX.p, G * sizeof(T), X, ld * sizeof(T), G * sizeof(T), C, hipMemcpyHostToDevice, c->stream);
+    struct Drain {   // no exit leaves a copy from or into the caller's arrays in flight
+        reo_ctx *c;
+        ~Drain() { if (c->up) (void)hipStreamSynchronize(c->up); (void)hipStreamSynchronize(c->stream); }
+    } drain{c};
+    // the cell matrix in chunks of columns, Int64 narrowed on the way (transform.hip, upload_columns)
+    if ((rc = upload_columns(c, X, ld, G, C, dX.p, std::is_same<T, double>::value ? 1 : 2))) return rc;
+    hipError_t e = hipSuccess;
     if (e == hipSuccess && n_order) e = hipMemcpyAsync(dOrd.p, order, n_order * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dPtr.p, chunk_ptr, (n_out + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {

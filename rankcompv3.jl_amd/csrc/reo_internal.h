@@ -325,6 +325,7 @@ namespace reo {
 // transform.hip
 int32_t run_transform(reo_ctx *c);
 int32_t eager_upload(reo_ctx *c, const void *hX, int64_t hld, bool with_k1);  // host matrix -> HBM in chunks, ranked (and paired) as they arrive
+int32_t upload_columns(reo_ctx *c, const void *hX, int64_t hld, int64_t G, int64_t ncols, void *dX, int dtype);  // a host matrix into a device matrix (ld = G), chunked, Int64 narrowed
 int32_t ensure_upload_streams(reo_ctx *c);                                      // c->up, c->rk and their events (created on first use)
 int32_t ensure_staging(reo_ctx *c, size_t slot_bytes);                          // three pinned + device staging slots of at least that size, their events
 void host_parallel(int nthreads, int ntasks, const std::function<void(int)> &fn);   // fn(0 .. ntasks - 1) on the process-wide pool of host threads (and the caller)

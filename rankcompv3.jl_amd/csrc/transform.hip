@@ -1481,6 +1481,81 @@ __global__ __launch_bounds__(256) void t_widen(const N *__restrict__ src, long l
     }
 }
 
+// One chunk of columns of a host matrix into its place in the device matrix, on the context's upload stream: Int64 chunks narrowed
+// (host thread pool -> pinned staging slot -> link -> t_widen), everything else -- Float64, REO_UPLOAD_THREADS=0, a chunk with a value
+// beyond 32 bits and every chunk after it -- straight from the caller's array.  send() returns the event behind which the chunk is
+// in place.  Used by the pipelined reo_set_matrix (eager_upload), by the plain one and by the dense pseudo-bulk call (upload_columns).
+template <class T>
+struct ChunkUploader {
+    static constexpr int kStage = 3;
+    reo_ctx *c;
+    const T *hX;
+    int64_t hld, G;
+    T *dX;
+    int width = 8, nslot = 0, nthreads = 1, nraw = 0;
+
+    int32_t init(reo_ctx *ctx, const T *host, int64_t ld, int64_t genes, T *dev, int max_cols)
+    {
+        c = ctx; hX = host; hld = ld; G = genes; dX = dev;
+        int32_t rc;
+        if ((rc = ensure_upload_streams(c))) return rc;
+        c->narrowed_bytes = 0;
+        if (std::is_same<T, int64_t>::value && c->upload_threads > 0) {
+            if ((rc = ensure_staging(c, static_cast<size_t>(max_cols) * G * 4))) return rc;
+            nthreads = std::max(1, std::min<int>(c->upload_threads, static_cast<int>(std::thread::hardware_concurrency())));
+            width = 2;
+        }
+        return REO_OK;
+    }
+
+    int32_t send(int c0, int nc, hipEvent_t *ready)
+    {
+        if constexpr (std::is_same<T, int64_t>::value) {
+            // the slot's pinned half is free when the copy that read it is done (ev_stage); its device half when the widening is (the
+            // next copy into it follows on the same stream)
+            while (width < 8) {
+                const int sl = nslot % kStage;
+                if (nslot >= kStage) REO_HIP_CHECK(hipEventSynchronize(c->ev_stage[sl]));
+                unsigned char *hs = c->stage_h[sl];
+                std::atomic<int> fits{1};
+                const int per = (nc + nthreads - 1) / nthreads;
+                const int w = width;
+                HostPool::get(nthreads).run(nthreads, [&](int t) {
+                    const int a = std::min(nc, t * per), b = std::min(nc, a + per);
+                    if (a >= b) return;
+                    const int64_t *src = reinterpret_cast<const int64_t *>(hX) + static_cast<int64_t>(c0) * hld;
+                    const bool ok = w == 2 ? narrow_columns<int16_t>(src, hld, G, a, b, reinterpret_cast<int16_t *>(hs))
+                                           : narrow_columns<int32_t>(src, hld, G, a, b, reinterpret_cast<int32_t *>(hs));
+                    if (!ok) fits.store(0);
+                });
+                if (!fits.load()) { width *= 2; continue; }   // (this chunk again, one width up; the widths only grow)
+                const size_t nel = static_cast<size_t>(nc) * G;
+                // copy and widening both on the upload stream: the staging ring turns whatever the other streams are waiting for
+                REO_HIP_CHECK(hipMemcpyAsync(c->stage_d[sl].p, hs, nel * width, hipMemcpyHostToDevice, c->up));
+                REO_HIP_CHECK(hipEventRecord(c->ev_stage[sl], c->up));
+                long long *dst = reinterpret_cast<long long *>(dX) + static_cast<size_t>(c0) * G;
+                const unsigned grid = static_cast<unsigned>((nel + 2047) / 2048);
+                if (width == 2) t_widen<int16_t><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int16_t *>(c->stage_d[sl].p), dst, nel);
+                else t_widen<int32_t><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int32_t *>(c->stage_d[sl].p), dst, nel);
+                REO_HIP_CHECK(hipGetLastError());
+                REO_HIP_CHECK(hipEventRecord(c->ev_widen[sl], c->up));
+                *ready = c->ev_widen[sl];
+                ++nslot;
+                c->narrowed_bytes += static_cast<int64_t>(nel) * width;
+                return REO_OK;
+            }
+        }
+        // the caller's array as it is: pageable source, so the call returns when the runtime has staged the chunk
+        if (hld == G) REO_HIP_CHECK(hipMemcpyAsync(dX + static_cast<size_t>(c0) * G, hX + static_cast<size_t>(c0) * hld, static_cast<size_t>(nc) * G * sizeof(T), hipMemcpyHostToDevice, c->up));
+        else REO_HIP_CHECK(hipMemcpy2DAsync(dX + static_cast<size_t>(c0) * G, G * sizeof(T), hX + static_cast<size_t>(c0) * hld, hld * sizeof(T), G * sizeof(T), nc, hipMemcpyHostToDevice, c->up));
+        hipEvent_t ev = c->ev_up[nraw++ % 8];
+        REO_HIP_CHECK(hipEventRecord(ev, c->up));
+        *ready = ev;
+        c->narrowed_bytes += static_cast<int64_t>(nc) * G * 8;
+        return REO_OK;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Pipelined upload (round 5): reo_set_matrix_i64 / _f64 from HOST memory when groups (and thresholds) are already known.
 // The drop-in call hands over a pageable column-major host matrix (julia/RankCompV3HIP.jl at src/RankCompV3.jl:652); the transform
@@ -1581,71 +1656,16 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
         if (fl[4] || fl[5]) fallback = true;
         return REO_OK;
     };
-    int nchunk = 0;
-    // narrowed upload (Int64 only): staging ring, worker threads
-    constexpr int kStage = 3;
-    int width = 8, nslot = 0, nthreads = 1;
-    HostPool *pool = nullptr;
-    c->narrowed_bytes = 0;
-    if (std::is_same<T, int64_t>::value && c->upload_threads > 0) {
-        if ((rc = ensure_staging(c, static_cast<size_t>(std::min(CH, S)) * G * 4))) return rc;
-        nthreads = std::max(1, std::min<int>(c->upload_threads, static_cast<int>(std::thread::hardware_concurrency())));
-        pool = &HostPool::get(nthreads);
-        width = 2;
-    }
+    ChunkUploader<T> upl;
+    if ((rc = upl.init(c, hX, hld, G, dX, std::min(CH, S)))) return rc;
     stamp("buffers, streams, lists ready");
-    for (int c0 = 0; c0 < S; ++nchunk) {
+    for (int c0 = 0; c0 < S;) {
         int nc = std::min(CH, S - c0);
         for (int s = c0 + 1; s < c0 + nc; ++s)   // cut at the first change of label that leaves a chunk worth launching
             if (c->group_id[s] != c->group_id[s - 1] && s - c0 >= std::min(CH, 64)) { nc = s - c0; break; }
-        hipEvent_t ev = c->ev_up[nchunk % 8];
-        bool sent = false;
-        if constexpr (std::is_same<T, int64_t>::value) {
-            // narrowed: host threads convert the chunk into pinned staging slot `sl` (16-bit, then 32-bit numbers), the link carries
-            // that, t_widen writes the Int64 columns.  The slot's pinned half is free when the copy that read it is done (ev_stage);
-            // its device half when the widening is (the next copy into it follows on the same stream).
-            while (width < 8 && !sent) {
-                const int sl = nslot % kStage;
-                if (nslot >= kStage) REO_HIP_CHECK(hipEventSynchronize(c->ev_stage[sl]));
-                unsigned char *hs = c->stage_h[sl];
-                std::atomic<int> fits{1};
-                const int per = (nc + nthreads - 1) / nthreads;
-                pool->run(nthreads, [&](int t) {
-                    const int a = std::min(nc, t * per), b = std::min(nc, a + per);
-                    if (a >= b) return;
-                    const int64_t *src = reinterpret_cast<const int64_t *>(hX) + static_cast<int64_t>(c0) * hld;
-                    const bool ok = width == 2 ? narrow_columns<int16_t>(src, hld, G, a, b, reinterpret_cast<int16_t *>(hs))
-                                               : narrow_columns<int32_t>(src, hld, G, a, b, reinterpret_cast<int32_t *>(hs));
-                    if (!ok) fits.store(0);
-                });
-                if (!fits.load()) { width *= 2; continue; }   // (this chunk again, one width up; the widths only grow)
-                const size_t nel = static_cast<size_t>(nc) * G;
-                // copy and widening both on the upload stream: the slot's device half is free again when its widening is done, whatever
-                // the ranking stream is waiting for (its workgroups want a whole CU each and find none while a side of the pair kernel
-                // runs: with the widening on that stream the staging ring -- and so the upload -- stood still behind them)
-                REO_HIP_CHECK(hipMemcpyAsync(c->stage_d[sl].p, hs, nel * width, hipMemcpyHostToDevice, c->up));
-                REO_HIP_CHECK(hipEventRecord(c->ev_stage[sl], c->up));
-                long long *dst = reinterpret_cast<long long *>(dX) + static_cast<size_t>(c0) * G;
-                const unsigned grid = static_cast<unsigned>((nel + 2047) / 2048);
-                if (width == 2) t_widen<int16_t><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int16_t *>(c->stage_d[sl].p), dst, nel);
-                else t_widen<int32_t><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int32_t *>(c->stage_d[sl].p), dst, nel);
-                REO_HIP_CHECK(hipGetLastError());
-                REO_HIP_CHECK(hipEventRecord(c->ev_widen[sl], c->up));
-                REO_HIP_CHECK(hipStreamWaitEvent(rk, c->ev_widen[sl], 0));
-                ++nslot;
-                sent = true;
-                c->narrowed_bytes += static_cast<int64_t>(nel) * width;
-            }
-        }
-        if (!sent) {
-            // the copy: pageable source, so the call returns when the runtime has staged the chunk; the upload stream never waits for
-            // a kernel (a ring of events hands each chunk to the ranking stream)
-            if (hld == c->G) REO_HIP_CHECK(hipMemcpyAsync(dX + static_cast<size_t>(c0) * G, hX + static_cast<size_t>(c0) * hld, static_cast<size_t>(nc) * G * sizeof(T), hipMemcpyHostToDevice, c->up));
-            else REO_HIP_CHECK(hipMemcpy2DAsync(dX + static_cast<size_t>(c0) * G, G * sizeof(T), hX + static_cast<size_t>(c0) * hld, hld * sizeof(T), G * sizeof(T), nc, hipMemcpyHostToDevice, c->up));
-            REO_HIP_CHECK(hipEventRecord(ev, c->up));
-            REO_HIP_CHECK(hipStreamWaitEvent(rk, ev, 0));
-            c->narrowed_bytes += static_cast<int64_t>(nc) * G * 8;
-        }
+        hipEvent_t arrived = nullptr;
+        if ((rc = upl.send(c0, nc, &arrived))) return rc;
+        REO_HIP_CHECK(hipStreamWaitEvent(rk, arrived, 0));   // the upload stream never waits for a kernel of the other two
         const int cbeg = c0;
         c0 += nc;
         if (fallback || bad_values) continue;   // (the rest of the matrix still has to arrive)
@@ -1731,6 +1751,27 @@ int32_t ensure_staging(reo_ctx *c, size_t slot_bytes)
     }
     c->stage_cap = std::max(c->stage_cap, slot_bytes);
     return REO_OK;
+}
+
+// A whole host matrix (G x ncols, leading dimension hld) into a device matrix of leading dimension G, in chunks on the upload stream
+// (Int64 narrowed: ChunkUploader); the context's stream is ordered behind the last chunk, and the call returns when the host array has
+// been read.  dtype: 1 Float64, 2 Int64.
+int32_t upload_columns(reo_ctx *c, const void *hX, int64_t hld, int64_t G, int64_t ncols, void *dX, int dtype)
+{
+    auto go = [&](auto *host, auto *dev) -> int32_t {
+        using T = std::remove_pointer_t<decltype(dev)>;
+        const int CH = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(ncols, std::max<int64_t>(16, (int64_t(32) << 20) / (G * 8)))));   // about 32 MB of source per chunk
+        ChunkUploader<T> upl;
+        int32_t rc = upl.init(c, host, hld, G, dev, CH);
+        if (rc) return rc;
+        hipEvent_t last = nullptr;
+        for (int64_t c0 = 0; c0 < ncols; c0 += CH)
+            if ((rc = upl.send(static_cast<int>(c0), static_cast<int>(std::min<int64_t>(CH, ncols - c0)), &last))) return rc;
+        if (last) REO_HIP_CHECK(hipStreamWaitEvent(c->stream, last, 0));
+        REO_HIP_CHECK(hipStreamSynchronize(c->up));
+        return REO_OK;
+    };
+    return dtype == 1 ? go(static_cast<const double *>(hX), static_cast<double *>(dX)) : go(static_cast<const int64_t *>(hX), static_cast<int64_t *>(dX));
 }
 
 int32_t eager_upload(reo_ctx *c, const void *hX, int64_t hld, bool with_k1)
