@@ -193,7 +193,7 @@ struct reo_ctx {
     reo::DevBuf<uint4> hi;      // [nblk][Gp][4]  the same for one past the last position of the tie band
     reo::DevBuf<uint16_t> t_pos16, t_lo16, t_hi16;  // [S32][Gp] the three numbers before slicing (scratch)
     reo::DevBuf<uint32_t> t_pos32, t_lo32, t_hi32;  // the same for more than 65 535 genes (32-bit positions; transform.hip, t_slice_big)
-    reo::DevBuf<uint32_t> t_vin32, t_vout32;        // gene indices of the segmented sort, 32-bit
+    reo::DevBuf<uint32_t> t_vin32, t_vout32;        // by-slot scratch of the bucket ranking (!GENL); gene indices of the A/B build's segmented sort, 32-bit
     reo::DevBuf<int32_t> goff_dev;  // group offsets in blocks
     // transform scratch (grow-only, freed with the context)
     reo::DevBuf<uint64_t> t_kin, t_kout;
