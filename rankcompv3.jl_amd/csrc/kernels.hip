@@ -498,7 +498,13 @@ __device__ __forceinline__ void k1w_item(const K1Args &a, uint4 *ring, int i0, i
     const int lane = threadIdx.x, jl = jw + lane, bi = i0 >> 6;
     const int bb = side ? a.tb : a.cb, be = side ? a.te : a.ce;
     Counts gt0, gt1, gt2, gt3;                    // n_gt of the lane's four genes: packed, rows 2h and 2h+1
-    uint32_t park[TIES ? RJ * (RI / 2) : 1];      // n_ge (tie-rich data): the first pass's counts wait in the private segment
+    // n_ge (tie-rich data), the first pass's counts, wait for the second pass: in the private segment (scratch) at three waves per
+    // SIMD -- or, above 16 planes, where the loop's own registers leave room for two waves only, in 64 more registers.  Measured A/B
+    // (profiles/r5_ties_park_ab.txt): registers everywhere cost NB = 15 its third wave, 5.1 -> 5.5 ms at config 3 and 36.9 -> 39.8 at
+    // config 4; at NB = 17 (70 000 x 1 000) registers win, 67.2 -> 65.9 ms.
+    constexpr bool PARK_REGS = NB > 16;
+    uint32_t park[(TIES && !PARK_REGS) ? RJ * (RI / 2) : 1];
+    Counts ge0 = 0, ge1 = 0, ge2 = 0, ge3 = 0;
     unsigned long long t_loop = 0, t_emit = 0;
     if (a.stamps) t_loop = __builtin_amdgcn_s_memrealtime();
     if (be > bb) {
@@ -512,17 +518,18 @@ __device__ __forceinline__ void k1w_item(const K1Args &a, uint4 *ring, int i0, i
             k1_loop<NB>(gt0, gt1, gt2, gt3, pb, static_cast<uint32_t>(a.Gp) * 16u, ab, static_cast<uint32_t>(a.Gp) * static_cast<uint32_t>(ROWB),
                         static_cast<uint32_t>(be - bb), static_cast<uint32_t>(jl) * 16u, static_cast<uint32_t>(lane) * 16u, lds);
             if (TIES && e == 0) {
+                if constexpr (PARK_REGS) { ge0 = gt0; ge1 = gt1; ge2 = gt2; ge3 = gt3; }
+                else {
+                    constexpr int W = (TIES && !PARK_REGS) ? RI / 2 : 0;
 #pragma unroll
-                for (int h = 0; h < RI / 2; ++h) {
-                    park[h] = gt0[h]; park[(TIES ? 1 : 0) * (RI / 2) + h] = gt1[h];
-                    park[(TIES ? 2 : 0) * (RI / 2) + h] = gt2[h]; park[(TIES ? 3 : 0) * (RI / 2) + h] = gt3[h];
+                    for (int h = 0; h < W; ++h) { park[h] = gt0[h]; park[W + h] = gt1[h]; park[2 * W + h] = gt2[h]; park[3 * W + h] = gt3[h]; }
                 }
             }
         }
     } else {
         gt0 = 0; gt1 = 0; gt2 = 0; gt3 = 0;
 #pragma unroll
-        for (int h = 0; h < (TIES ? RJ * (RI / 2) : 1); ++h) park[h] = 0;
+        for (int h = 0; h < ((TIES && !PARK_REGS) ? RJ * (RI / 2) : 1); ++h) park[h] = 0;
     }
     if (a.stamps) t_emit = __builtin_amdgcn_s_memrealtime();
     const int g = side ? a.gt : a.gc;
@@ -533,7 +540,8 @@ __device__ __forceinline__ void k1w_item(const K1Args &a, uint4 *ring, int i0, i
     for (int r = 0; r < RJ; ++r) {
         const Counts cur = gt0;
         Counts cge = 0;
-        if (TIES) {
+        if constexpr (TIES && PARK_REGS) cge = ge0;
+        else if constexpr (TIES) {
 #pragma unroll
             for (int h = 0; h < RI / 2; ++h) cge[h] = park[r * (RI / 2) + h];  // (dynamic r: the array stays in memory)
         }
@@ -552,6 +560,7 @@ __device__ __forceinline__ void k1w_item(const K1Args &a, uint4 *ring, int i0, i
             return nre;
         });
         gt0 = gt1; gt1 = gt2; gt2 = gt3;
+        if constexpr (TIES && PARK_REGS) { ge0 = ge1; ge1 = ge2; ge2 = ge3; }
     }
     if (a.stamps && lane == 0) {
         unsigned long long *st = a.stamps + static_cast<size_t>(blockIdx.x) * 4;
