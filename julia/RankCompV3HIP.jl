@@ -35,10 +35,10 @@ function identify_degs(data::AbstractMatrix, group::AbstractVector, gene_names::
         check(ccall((:reo_set_groups, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int64, Int32), ctx[], gid, c, length(glev)))
         check(ccall((:reo_compute_thresholds, LIB), Int32, (Ptr{Cvoid}, Float64), ctx[], pval_reo))           # :362
         if eltype(data) <: Integer
-            X = Matrix{Int64}(data)
+            X = convert(Matrix{Int64}, data)            # (no copy when `data` is a Matrix{Int64} already: Matrix(df_expr) of counts)
             check(ccall((:reo_set_matrix_i64, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Int64, Int64), ctx[], X, r, c, r))
         else
-            X = Matrix{Float64}(data)
+            X = convert(Matrix{Float64}, data)
             check(ccall((:reo_set_matrix_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64), ctx[], X, r, c, r))
         end
         res = Matrix{Any}(reshape(gene_names, r, 1))
