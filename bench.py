@@ -437,12 +437,12 @@ def main() -> None:
             plain.set_matrix(Xh)
             upn_w, _ = timed_walls(lambda: plain.set_matrix(Xh), max(3, steps_h))
             plain.close()
-            os.environ["REO_EAGER_UPLOAD"] = "0"                               # rounds 1-4: upload, THEN transform, pair kernel, passes
+            os.environ["REO_EAGER_UPLOAD"] = "0"; os.environ["REO_UPLOAD_THREADS"] = "0"   # rounds 1-4: ONE copy of the caller's array, THEN transform, pair kernel, passes
             ctxs = pkg.Context(device=local, seed=seedh)
             call(ctxs)
             seq_w, rseq = timed_walls(lambda: call(ctxs), steps_h)
             ctxs.close()
-            del os.environ["REO_EAGER_UPLOAD"]
+            del os.environ["REO_EAGER_UPLOAD"], os.environ["REO_UPLOAD_THREADS"]
             ctxh = pkg.Context(device=local, seed=seedh)
             call(ctxh)
             pip_w, rpip = timed_walls(lambda: call(ctxh), steps_h)
