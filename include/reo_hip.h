@@ -266,8 +266,9 @@ int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);
  * REO_XCC_LOCAL=0 switches it off), 16-18 the last reo_identify_degs: the period p of the cycle its iteration was found in
  * (0: none found), the pass in front of which the reference set equalled that of p passes earlier, and the passes that
  * were then skipped instead of executed (see reo_identify_degs; REO_CYCLE=0 switches the watch off), 19 the bytes that the last
- * pipelined reo_set_matrix_i64 put on the PCIe link (Int64 numbers that fit travel as 16- or 32-bit numbers, converted by
- * REO_UPLOAD_THREADS host threads, default 12, and widened on the device: exact; 0 threads = the caller's array as it is). */
+ * reo_set_matrix_i64 / _f64 put on the PCIe link (chunks whose values all fit travel as int16 / int32 -- Float64 chunks of
+ * integer-valued or single-precision numbers too, as int16 / int32 / float32 -- converted by REO_UPLOAD_THREADS host threads,
+ * default 12, and widened on the device: bit-exact; 0 threads = the caller's array as it is). */
 int32_t reo_get_info(reo_ctx *ctx, int64_t *info, int32_t n);
 
 #ifdef __cplusplus

@@ -17,6 +17,7 @@
 // PLANES over blocks of 32 samples (t_slice), because [pos_j < lo_i] for 32 samples at once is a borrow chain
 // of one v_bitop3_b32 per bit.  Every group is padded to whole 32-sample blocks; padding samples have
 // lo = hi = 0, which no position is below.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +31,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <limits>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -1462,7 +1464,7 @@ template <class N>
 static bool narrow_columns(const int64_t *src, int64_t ld, int64_t G, int col0, int col1, N *dst)   // false: some value does not fit N
 {
     int64_t bad = 0;
-    for (int cidx = col0; cidx < col1; ++cidx) {
+    for (int cidx = col0; cidx < col1 && !bad; ++cidx) {   // (a column that does not fit ends this thread's share: the chunk is redone wider)
         const int64_t *s = src + static_cast<int64_t>(cidx) * ld;
         N *d = dst + static_cast<int64_t>(cidx) * G;
         for (int64_t i = 0; i < G; ++i) { const int64_t v = s[i]; const N w = static_cast<N>(v); d[i] = w; bad |= v ^ static_cast<int64_t>(w); }
@@ -1470,29 +1472,57 @@ static bool narrow_columns(const int64_t *src, int64_t ld, int64_t G, int col0, 
     return bad == 0;
 }
 
-template <class N>
-__global__ __launch_bounds__(256) void t_widen(const N *__restrict__ src, long long *__restrict__ dst, size_t n)
+template <class N, class W>
+__global__ __launch_bounds__(256) void t_widen(const N *__restrict__ src, W *__restrict__ dst, size_t n)
 {
     const size_t base = static_cast<size_t>(blockIdx.x) * 2048 + threadIdx.x;   // consecutive lanes, consecutive numbers: no alignment to care about
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const size_t i = base + static_cast<size_t>(k) * 256;
-        if (i < n) dst[i] = static_cast<long long>(src[i]);
+        if (i < n) dst[i] = static_cast<W>(src[i]);   // (int16 / int32 -> Int64 or Float64, float -> Float64: all exact)
     }
 }
 
+// Float64 columns whose values are integers (counts read into a Float64 DataFrame) or float32 numbers (data that was stored in single
+// precision) cross the link as int16 / int32 / float32 too: the chunk is narrowed only if EVERY value converts back to the same
+// bits (so -0.0, NaN and anything with more mantissa than the narrow type keeps the chunk on the wider form).
+template <class N>
+static bool narrow_columns_f64(const double *src, int64_t ld, int64_t G, int col0, int col1, N *dst)
+{
+    bool ok = true;
+    for (int cidx = col0; cidx < col1 && ok; ++cidx) {
+        const double *s = src + static_cast<int64_t>(cidx) * ld;
+        N *d = dst + static_cast<int64_t>(cidx) * G;
+        if constexpr (std::is_same<N, float>::value) {
+            for (int64_t i = 0; i < G; ++i) { const double v = s[i]; const float q = static_cast<float>(v); d[i] = q; ok &= static_cast<double>(q) == v; }
+        } else {
+            constexpr double lo = static_cast<double>(std::numeric_limits<N>::min()), hi = static_cast<double>(std::numeric_limits<N>::max());
+            for (int64_t i = 0; i < G; ++i) {
+                const double v = s[i];
+                const bool in = v >= lo && v <= hi;            // (false for NaN; the conversion below is undefined outside the range)
+                const N q = in ? static_cast<N>(v) : N(0);
+                d[i] = q;
+                ok &= in && static_cast<double>(q) == v && !(v == 0.0 && std::signbit(v));
+            }
+        }
+    }
+    return ok;
+}
+
 // One chunk of columns of a host matrix into its place in the device matrix, on the context's upload stream: Int64 chunks narrowed
-// (host thread pool -> pinned staging slot -> link -> t_widen), everything else -- Float64, REO_UPLOAD_THREADS=0, a chunk with a value
-// beyond 32 bits and every chunk after it -- straight from the caller's array.  send() returns the event behind which the chunk is
+// (host thread pool -> pinned staging slot -> link -> t_widen), and so do Float64 chunks whose values are all integers or all float32
+// numbers; everything else -- other Float64 data, REO_UPLOAD_THREADS=0, a chunk with a value beyond 32 bits and every chunk after it --
+// goes straight from the caller's array.  send() returns the event behind which the chunk is
 // in place.  Used by the pipelined reo_set_matrix (eager_upload), by the plain one and by the dense pseudo-bulk call (upload_columns).
 template <class T>
 struct ChunkUploader {
     static constexpr int kStage = 3;
+    enum Form { I16 = 0, I32 = 1, F32 = 2, RAW = 3 };   // what a chunk is on the link; the form only moves up this ladder (F32: Float64 input only)
     reo_ctx *c;
     const T *hX;
     int64_t hld, G;
     T *dX;
-    int width = 8, nslot = 0, nthreads = 1, nraw = 0;
+    int form = RAW, nslot = 0, nthreads = 1, nraw = 0;
 
     int32_t init(reo_ctx *ctx, const T *host, int64_t ld, int64_t genes, T *dev, int max_cols)
     {
@@ -1500,50 +1530,76 @@ struct ChunkUploader {
         int32_t rc;
         if ((rc = ensure_upload_streams(c))) return rc;
         c->narrowed_bytes = 0;
-        if (std::is_same<T, int64_t>::value && c->upload_threads > 0) {
+        if (c->upload_threads > 0) {
             if ((rc = ensure_staging(c, static_cast<size_t>(max_cols) * G * 4))) return rc;
             nthreads = std::max(1, std::min<int>(c->upload_threads, static_cast<int>(std::thread::hardware_concurrency())));
-            width = 2;
+            form = I16;
         }
         return REO_OK;
     }
 
     int32_t send(int c0, int nc, hipEvent_t *ready)
     {
-        if constexpr (std::is_same<T, int64_t>::value) {
-            // the slot's pinned half is free when the copy that read it is done (ev_stage); its device half when the widening is (the
-            // next copy into it follows on the same stream)
-            while (width < 8) {
-                const int sl = nslot % kStage;
-                if (nslot >= kStage) REO_HIP_CHECK(hipEventSynchronize(c->ev_stage[sl]));
-                unsigned char *hs = c->stage_h[sl];
-                std::atomic<int> fits{1};
-                const int per = (nc + nthreads - 1) / nthreads;
-                const int w = width;
-                HostPool::get(nthreads).run(nthreads, [&](int t) {
-                    const int a = std::min(nc, t * per), b = std::min(nc, a + per);
-                    if (a >= b) return;
-                    const int64_t *src = reinterpret_cast<const int64_t *>(hX) + static_cast<int64_t>(c0) * hld;
-                    const bool ok = w == 2 ? narrow_columns<int16_t>(src, hld, G, a, b, reinterpret_cast<int16_t *>(hs))
-                                           : narrow_columns<int32_t>(src, hld, G, a, b, reinterpret_cast<int32_t *>(hs));
-                    if (!ok) fits.store(0);
-                });
-                if (!fits.load()) { width *= 2; continue; }   // (this chunk again, one width up; the widths only grow)
-                const size_t nel = static_cast<size_t>(nc) * G;
-                // copy and widening both on the upload stream: the staging ring turns whatever the other streams are waiting for
-                REO_HIP_CHECK(hipMemcpyAsync(c->stage_d[sl].p, hs, nel * width, hipMemcpyHostToDevice, c->up));
-                REO_HIP_CHECK(hipEventRecord(c->ev_stage[sl], c->up));
-                long long *dst = reinterpret_cast<long long *>(dX) + static_cast<size_t>(c0) * G;
-                const unsigned grid = static_cast<unsigned>((nel + 2047) / 2048);
-                if (width == 2) t_widen<int16_t><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int16_t *>(c->stage_d[sl].p), dst, nel);
-                else t_widen<int32_t><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int32_t *>(c->stage_d[sl].p), dst, nel);
-                REO_HIP_CHECK(hipGetLastError());
-                REO_HIP_CHECK(hipEventRecord(c->ev_widen[sl], c->up));
-                *ready = c->ev_widen[sl];
-                ++nslot;
-                c->narrowed_bytes += static_cast<int64_t>(nel) * width;
-                return REO_OK;
+        // the slot's pinned half is free when the copy that read it is done (ev_stage); its device half when the widening is (the next
+        // copy into it follows on the same stream)
+        while (form != RAW) {
+            if (form == F32 && !std::is_same<T, double>::value) { form = RAW; break; }
+            {   // a probe first: the head of the chunk's first column decides in microseconds what real Float64 data (or wide integers)
+                // would otherwise find out after a whole converted chunk per form
+                unsigned char probe[256 * 4];
+                const int64_t np_ = std::min<int64_t>(G, 256);
+                bool ok;
+                if constexpr (std::is_same<T, int64_t>::value) {
+                    const int64_t *src = hX + static_cast<int64_t>(c0) * hld;
+                    ok = form == I16 ? narrow_columns<int16_t>(src, hld, np_, 0, 1, reinterpret_cast<int16_t *>(probe))
+                                     : narrow_columns<int32_t>(src, hld, np_, 0, 1, reinterpret_cast<int32_t *>(probe));
+                } else {
+                    const double *src = hX + static_cast<int64_t>(c0) * hld;
+                    ok = form == I16 ? narrow_columns_f64<int16_t>(src, hld, np_, 0, 1, reinterpret_cast<int16_t *>(probe))
+                       : form == I32 ? narrow_columns_f64<int32_t>(src, hld, np_, 0, 1, reinterpret_cast<int32_t *>(probe))
+                                     : narrow_columns_f64<float>(src, hld, np_, 0, 1, reinterpret_cast<float *>(probe));
+                }
+                if (!ok) { ++form; continue; }
             }
+            const int sl = nslot % kStage;
+            if (nslot >= kStage) REO_HIP_CHECK(hipEventSynchronize(c->ev_stage[sl]));
+            unsigned char *hs = c->stage_h[sl];
+            std::atomic<int> fits{1};
+            const int per = (nc + nthreads - 1) / nthreads;
+            const int f = form;
+            HostPool::get(nthreads).run(nthreads, [&](int t) {
+                const int a = std::min(nc, t * per), b = std::min(nc, a + per);
+                if (a >= b) return;
+                bool ok;
+                if constexpr (std::is_same<T, int64_t>::value) {
+                    const int64_t *src = hX + static_cast<int64_t>(c0) * hld;
+                    ok = f == I16 ? narrow_columns<int16_t>(src, hld, G, a, b, reinterpret_cast<int16_t *>(hs))
+                                  : narrow_columns<int32_t>(src, hld, G, a, b, reinterpret_cast<int32_t *>(hs));
+                } else {
+                    const double *src = hX + static_cast<int64_t>(c0) * hld;
+                    ok = f == I16 ? narrow_columns_f64<int16_t>(src, hld, G, a, b, reinterpret_cast<int16_t *>(hs))
+                       : f == I32 ? narrow_columns_f64<int32_t>(src, hld, G, a, b, reinterpret_cast<int32_t *>(hs))
+                                  : narrow_columns_f64<float>(src, hld, G, a, b, reinterpret_cast<float *>(hs));
+                }
+                if (!ok) fits.store(0);
+            });
+            if (!fits.load()) { ++form; continue; }   // (this chunk again, one form up)
+            const size_t nel = static_cast<size_t>(nc) * G, width = form == I16 ? 2 : 4;
+            // copy and widening both on the upload stream: the staging ring turns whatever the other streams are waiting for
+            REO_HIP_CHECK(hipMemcpyAsync(c->stage_d[sl].p, hs, nel * width, hipMemcpyHostToDevice, c->up));
+            REO_HIP_CHECK(hipEventRecord(c->ev_stage[sl], c->up));
+            T *dst = dX + static_cast<size_t>(c0) * G;
+            const unsigned grid = static_cast<unsigned>((nel + 2047) / 2048);
+            const unsigned char *ds = c->stage_d[sl].p;
+            if (form == I16) t_widen<int16_t, T><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int16_t *>(ds), dst, nel);
+            else if (form == I32) t_widen<int32_t, T><<<grid, 256, 0, c->up>>>(reinterpret_cast<const int32_t *>(ds), dst, nel);
+            else t_widen<float, T><<<grid, 256, 0, c->up>>>(reinterpret_cast<const float *>(ds), dst, nel);
+            REO_HIP_CHECK(hipGetLastError());
+            REO_HIP_CHECK(hipEventRecord(c->ev_widen[sl], c->up));
+            *ready = c->ev_widen[sl];
+            ++nslot;
+            c->narrowed_bytes += static_cast<int64_t>(nel * width);
+            return REO_OK;
         }
         // the caller's array as it is: pageable source, so the call returns when the runtime has staged the chunk
         if (hld == G) REO_HIP_CHECK(hipMemcpyAsync(dX + static_cast<size_t>(c0) * G, hX + static_cast<size_t>(c0) * hld, static_cast<size_t>(nc) * G * sizeof(T), hipMemcpyHostToDevice, c->up));

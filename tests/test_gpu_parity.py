@@ -571,14 +571,15 @@ def _eager_ctx(pkg, X, group, seed, pval_reo=0.01):
 
 
 @pytest.mark.parametrize("kind", ["ranks", "counts", "float", "big_int", "three_groups", "interleaved", "unequal", "view_ld", "small",
-                                  "negative", "huge_int", "growing"])
+                                  "negative", "huge_int", "growing", "float_counts", "float_from_f32", "float_mixed"])
 def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
     """reo_set_matrix_i64 / _f64 from host memory with the groups already set (round 5): the columns travel in chunks, samples are
     ranked as they arrive, a group's blocks are sliced when its last sample is in, and (two groups, one GPU, thresholds set) the
     pair kernel's side of that group starts while the other group is still on its way.  Everything must be BIT-EQUAL to the
     matrix-first order of rounds 1-4: whole class table, tallies, trace, every statistic -- for contiguous and interleaved labels,
     unequal groups (padding slots), three groups (ranking only), a view with a leading dimension, data that the first choice of
-    ranking kernel flags (falls back to the resident copy), and with the pipelining switched down (REO_EAGER_UPLOAD=1, 0)."""
+    ranking kernel flags (falls back to the resident copy), every form a chunk can take on the link (int16 / int32 / float32 / the
+    caller's array, for Int64 and for Float64 input, changing on the way), and with the pipelining switched down (REO_EAGER_UPLOAD=1, 0)."""
     seed = 0x5EED0051
     rng = np.random.default_rng(11)
     G, S = 9000, 300
@@ -596,6 +597,11 @@ def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
     elif kind == "huge_int": X = rng.integers(-2 ** 40, 2 ** 40, size=(G, S))                                      # no narrow width fits: the caller's array itself
     elif kind == "growing":                                                                                        # widths grow on the way: 16 bits, then 32, then 64
         X = rng.integers(0, 30000, size=(G, S)); X[:, 130:] += 40000; X[17, 135] = 2 ** 31 - 1; X[G - 1, 280] = -2 ** 31 - 1
+    elif kind == "float_counts": X = rng.integers(0, 3000, size=(G, S)).astype(np.float64); X[3, 3] = -5.0                  # integers in a Float64 matrix: 16-bit on the link
+    elif kind == "float_from_f32": X = np.round(rng.lognormal(1, 1, size=(G, S)), 2).astype(np.float32).astype(np.float64)   # single-precision data: float32 on the link
+    elif kind == "float_mixed":                                                                                              # the form climbs: int16, int32, float32, the array itself
+        X = rng.integers(0, 900, size=(G, S)).astype(np.float64); X[:, 100:] += 70000.0; X[:, 180:] += np.float32(0.25); X[11, 190] = -0.0
+        X[:, 250:] = rng.normal(8, 2, size=(G, 50))
     else: G, S = 700, 41; X = pkg.synth.t1_counts(G, S, seed); group = pkg.synth.groups(S)
     ref0 = pkg.synth.ref_mask(G, G // 5, seed)
     ng = len(set(group))
@@ -619,10 +625,10 @@ def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
             else: monkeypatch.setenv(name, val)
         ctxe = _eager_ctx(pkg, X, group, seed)
         link = ctxe.info()["upload_link_bytes"]
-        if mode != "0" and threads != "0" and kind in ("ranks", "negative", "big_int"):
-            assert link == X.size * (2 if kind in ("ranks", "negative") else 4), (kind, link)     # what the link carried
-        elif mode != "0" and threads != "0" and kind in ("counts", "growing"):
-            assert X.size * 2 < link < X.size * 8, (kind, link)                                   # chunk by chunk: the narrowest width that fits
+        if mode != "0" and threads != "0" and kind in ("ranks", "negative", "big_int", "float_counts", "float_from_f32"):
+            assert link == X.size * (2 if kind in ("ranks", "negative", "float_counts") else 4), (kind, link)     # what the link carried
+        elif mode != "0" and threads != "0" and kind in ("counts", "growing", "float_mixed"):
+            assert X.size * 2 < link < X.size * 8, (kind, link)                                   # chunk by chunk: the narrowest form that fits
         elif mode != "0" and (kind in ("float", "huge_int") or threads == "0"):
             assert link == X.size * 8, (kind, link)
         elif mode != "0":

@@ -34,7 +34,7 @@ for n in range(N):
     elif layout == "interleaved": labels = rng.integers(0, ng, S); labels[:ng] = np.arange(ng)
     else:
         cut = np.sort(rng.choice(np.arange(2, S - 2), ng - 1, replace=False)); labels = np.searchsorted(cut, np.arange(S), side="right")
-    kind = str(rng.choice(["ranks", "counts16", "counts32", "huge", "growing", "negative", "float", "float_band"]))
+    kind = str(rng.choice(["ranks", "counts16", "counts32", "huge", "growing", "negative", "float", "float_band", "float_counts", "float_f32", "float_mixed"]))
     if kind == "ranks": X = np.argsort(np.argsort(rng.random((G, S)), axis=0), axis=0).astype(np.int64)
     elif kind == "counts16": X = rng.integers(0, int(rng.integers(3, 30000)), size=(G, S))
     elif kind == "counts32": X = np.floor(np.exp(rng.normal(4, 3, size=(G, S)))).astype(np.int64) % (2 ** 31)
@@ -42,6 +42,11 @@ for n in range(N):
     elif kind == "growing":
         X = rng.integers(0, 20000, size=(G, S)); c1, c2 = sorted(rng.integers(1, S, 2)); X[:, c1:] += 50000; X[rng.integers(0, G), c2:] = 2 ** 33
     elif kind == "negative": X = rng.integers(-32768, 32768, size=(G, S))
+    elif kind == "float_counts": X = rng.integers(-100, int(rng.integers(3, 100000)), size=(G, S)).astype(np.float64)
+    elif kind == "float_f32": X = rng.lognormal(1, 2, size=(G, S)).astype(np.float32).astype(np.float64)
+    elif kind == "float_mixed":
+        X = rng.integers(0, 500, size=(G, S)).astype(np.float64); c1, c2 = sorted(rng.integers(1, S, 2)); X[:, c1:] *= 0.5; X[:, c2:] += rng.normal(0, 1e-9, size=(G, S - c2))
+        X[rng.integers(0, G), rng.integers(0, S)] = -0.0
     elif kind == "float": X = np.log2(1.0 + np.floor(np.exp(rng.normal(2.0, 2.0, size=(G, S))))) + rng.uniform(0, 0.05, (G, S))
     else: X = np.round(rng.normal(5, 1.0, size=(G, S)), 1) + rng.choice([0.0, 0.04, 0.099, 0.1], size=(G, S))
     X = np.asfortranarray(X)
