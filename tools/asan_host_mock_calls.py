@@ -88,9 +88,11 @@ with pkg.Context(device=0, seed=1) as ctx:
 note("entry points on one context")
 
 # ---- 3. shapes that take the other kernels' host paths: light passes, more than 65 535 genes, more than 65 535 samples, many groups --
-def one(G, S, ngroups=2, n_iter=3, ints=True, seed=5, shard=(0, 1), allgather=None, allreduce=None):
+def one(G, S, ngroups=2, n_iter=3, ints=True, seed=5, shard=(0, 1), allgather=None, allreduce=None, kind=None):
     r = np.random.default_rng(seed)
     X = r.integers(0, 1000, size=(G, S)) if ints else r.normal(size=(G, S))
+    if kind == "float_counts": X = r.integers(0, 100000, size=(G, S)).astype(np.float64); X[:, S // 2:] += 0.5; X[:, 3 * S // 4:] += 1e-9   # int32, float32, raw on the way
+    if kind == "wide_ints": X = r.integers(0, 30000, size=(G, S)); X[:, S // 3:] += 2 ** 20; X[7, S - 2] = 2 ** 50                          # int16, int32, raw
     labels = np.repeat(np.arange(ngroups), -(-S // ngroups))[:S]
     os.environ["MOCKHIP_N_ITER"] = str(n_iter)
     return pkg.run_identify_degs(X, labels, list(range(G)), 0.05, 1.0, 0.05, pkg.synth.ref_mask(G, G // 4, seed), n_iter, 0, seed=seed, device=0,
@@ -98,6 +100,10 @@ def one(G, S, ngroups=2, n_iter=3, ints=True, seed=5, shard=(0, 1), allgather=No
 
 
 one(9000, 64, n_iter=40)                  # light passes (G >= 4096): batches, the replay
+for ch in ("7", "16", None):              # every form of a chunk on the link, climbing on the way, small and default chunks
+    if ch: os.environ["REO_EAGER_CHUNK"] = ch
+    one(5000, 64, kind="float_counts"); one(5000, 64, kind="wide_ints")
+    os.environ.pop("REO_EAGER_CHUNK", None)
 one(9000, 64, n_iter=40, ints=False)
 one(30000, 16)
 one(70000, 8)                             # 32-bit positions, the segmented sort's host side, k1w_pairs<17>
