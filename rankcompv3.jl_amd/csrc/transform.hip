@@ -1418,7 +1418,10 @@ public:
     {
         std::lock_guard<std::mutex> one_job(run_mu_);   // contexts of different threads share the pool: their jobs take turns
         {
-            std::lock_guard<std::mutex> lk(mu_);
+            // a worker of the LAST job may still be on its way out of work() (its final fetch of a task index): the counters are not
+            // touched before it has left, or that fetch could land between the two stores below and hand out a task twice
+            std::unique_lock<std::mutex> lk(mu_);
+            idle_.wait(lk, [&] { return active_ == 0; });
             job_ = &fn; total_.store(ntasks); next_.store(0); pending_ = ntasks; ++gen_;
         }
         cv_.notify_all();
@@ -1446,13 +1449,17 @@ private:
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
-                if (!job_) continue;
+                if (!job_) continue;   // (woken late: that job is over.  A job that IS set is completely set up: decided under the lock)
+                ++active_;
             }
             work();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--active_ == 0) idle_.notify_all();
         }
     }
     std::mutex mu_, run_mu_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_, done_, idle_;
+    int active_ = 0;               // workers inside work()
     std::vector<std::thread> th_;
     const std::function<void(int)> *job_ = nullptr;
     std::atomic<int> next_{0}, total_{0};
