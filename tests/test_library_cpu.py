@@ -78,3 +78,14 @@ def test_synthetic_generators(pkg):
     from oracle import reo_numpy as rn
     z = int(pkg.synth.u64(5, np.array([7]), np.array([3]))[0])
     assert z == rn.mix64(5 ^ rn.mix64((7 << 32) | 3))
+
+
+def test_host_thread_pool_of_the_narrowed_upload_under_thread_sanitizer():
+    """HostPool (csrc/transform.hip): the pool of host threads that narrows Int64 / Float64 chunks for the upload and checks CSC row
+    indices.  The class is cut out of the source verbatim and stressed on the CPU under ThreadSanitizer (tools/hostpool_tsan.py): four
+    caller threads, 80 000 short jobs with task counts around the worker count -- every task exactly once, no data race reported."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "hostpool_tsan.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "hostpool_tsan: clean" in out.stdout, out.stdout + out.stderr
