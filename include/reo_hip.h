@@ -66,7 +66,8 @@ void reo_destroy(reo_ctx *ctx);
 /* Memory of destroyed contexts is kept for the next one: a caller that makes a context per identify_degs call (the Julia shim
  * does) would otherwise spend as long in hipMalloc / hipFree as in the computation (6 of 14 ms at 20 000 x 1 000).  Released
  * device and pinned-host blocks wait in a process-wide cache, at most REO_DEVICE_CACHE_MB megabytes of them (environment,
- * default 16384; 0 = no cache, every release is a hipFree); reo_trim_memory() returns all of them to the driver now. */
+ * default 16384; 0 = no cache, every release is a hipFree), and so do the streams and events of destroyed contexts;
+ * reo_trim_memory() returns all of it to the driver now. */
 int32_t reo_trim_memory(void);
 
 /* ---- several GPUs ---------------------------------------------------------------------------------------

@@ -37,6 +37,73 @@ hipError_t raw_alloc(void **p, size_t bytes, bool pinned) { return pinned ? hipH
 void raw_free(void *p, bool pinned) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
 }  // namespace
 
+namespace {
+struct Handles {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> streams[2];   // (device, stream) by kind
+    std::vector<std::pair<int, hipEvent_t>> events[2];
+};
+Handles &handles() { static Handles *h = new Handles(); return *h; }
+}  // namespace
+
+hipError_t handle_stream(hipStream_t *s, int kind)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        Handles &H = handles();
+        std::lock_guard<std::mutex> lk(H.mu);
+        auto &v = H.streams[kind];
+        for (size_t i = v.size(); i-- > 0;)
+            if (v[i].first == dev) { *s = v[i].second; v.erase(v.begin() + static_cast<long>(i)); return hipSuccess; }
+    }
+    if (kind == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int lo_pri = 0, hi_pri = 0;
+    const hipError_t e = hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+    return e != hipSuccess ? e : hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi_pri);
+}
+
+hipError_t handle_event(hipEvent_t *ev, int kind)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        Handles &H = handles();
+        std::lock_guard<std::mutex> lk(H.mu);
+        auto &v = H.events[kind];
+        for (size_t i = v.size(); i-- > 0;)
+            if (v[i].first == dev) { *ev = v[i].second; v.erase(v.begin() + static_cast<long>(i)); return hipSuccess; }
+    }
+    return kind ? hipEventCreate(ev) : hipEventCreateWithFlags(ev, hipEventDisableTiming);
+}
+
+void release_stream(hipStream_t s, int kind)
+{
+    if (!s) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Handles &H = handles();
+    {
+        std::lock_guard<std::mutex> lk(H.mu);
+        // (kept only if idle and healthy: a stream that reports an error is destroyed, not handed to the next context)
+        if (H.streams[kind].size() < 64 && pool().cap > 0 && hipStreamQuery(s) == hipSuccess) { H.streams[kind].emplace_back(dev, s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
+void release_event(hipEvent_t ev, int kind)
+{
+    if (!ev) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Handles &H = handles();
+    {
+        std::lock_guard<std::mutex> lk(H.mu);
+        if (H.events[kind].size() < 1024 && pool().cap > 0) { H.events[kind].emplace_back(dev, ev); return; }
+    }
+    (void)hipEventDestroy(ev);
+}
+
 hipError_t pool_alloc(void **out, size_t bytes, bool pinned)
 {
     Pool &P = pool();
@@ -115,7 +182,7 @@ void tic(reo_ctx *c, int slot)
     if (!c->profiling) return;
     StageTimer t;
     if (!c->pool.empty()) { t = c->pool.back(); c->pool.pop_back(); }
-    else { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
+    else { (void)handle_event(&t.a, 1); (void)handle_event(&t.b, 1); }
     (void)hipEventRecord(t.a, c->stream);
     c->pending.emplace_back(slot, t);
     c->open.push_back(c->pending.size() - 1);
@@ -488,6 +555,15 @@ int32_t reo_trim_memory(void)
         if (!b.pinned) (void)hipSetDevice(b.device);
         raw_free(b.p, b.pinned);
     }
+    {
+        Handles &H = handles();
+        std::lock_guard<std::mutex> lk(H.mu);
+        for (int k = 0; k < 2; ++k) {
+            for (auto &st : H.streams[k]) { (void)hipSetDevice(st.first); (void)hipStreamDestroy(st.second); }
+            for (auto &ev : H.events[k]) { (void)hipSetDevice(ev.first); (void)hipEventDestroy(ev.second); }
+            H.streams[k].clear(); H.events[k].clear();
+        }
+    }
     if (have_dev) (void)hipSetDevice(dev);
     return REO_OK;
 }
@@ -542,7 +618,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->debug_passes = getenv("REO_DEBUG_PASSES") != nullptr;
     c->debug_stamps = getenv("REO_DEBUG_STAMPS") != nullptr;
     c->k1_stamps = getenv("REO_K1_STAMPS") != nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = handle_stream(&c->stream, 0);
     if (e != hipSuccess) { delete c; set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return REO_EHIP; }
     // The light passes keep their BH-rank histogram as one partial per XCD, updated by atomics that stay in that XCD's L2.
     // That rests on two properties of the part, checked here once (a 20 us kernel): the XCC id register tells workgroups
@@ -577,28 +653,28 @@ void reo_destroy(reo_ctx *c)
     comm_release(c);
     collect_timings(c);
     tl_release_synced = true;   // every stream of this context has been waited for: its blocks go back to the cache without further waits
-    for (auto &t : c->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto &t : c->pool) { release_event(t.a, 1); release_event(t.b, 1); }
     c->dX_owned.release(); c->pos.release(); c->lo.release(); c->hi.release(); c->goff_dev.release();
     c->table.release();
     c->t_kin.release(); c->t_kout.release(); c->t_vin.release(); c->t_vout.release(); c->t_temp.release();
     c->t_order.release(); c->t_flags.release(); c->t_slots.release(); c->unit_map.release();
     for (auto &il : c->k1_wave_items) il.buf.release();
-    for (int q = 0; q < 2; ++q) { if (c->k1s[q]) (void)hipStreamDestroy(c->k1s[q]); if (c->ev_k1_join[q]) (void)hipEventDestroy(c->ev_k1_join[q]); }
-    if (c->xs) (void)hipStreamDestroy(c->xs);
-    if (c->up) (void)hipStreamDestroy(c->up);
-    if (c->rk) (void)hipStreamDestroy(c->rk);
-    for (auto &e : c->ev_rk) if (e) (void)hipEventDestroy(e);
-    for (auto &e : c->ev_up) if (e) (void)hipEventDestroy(e);
+    for (int q = 0; q < 2; ++q) { release_stream(c->k1s[q], 0); release_event(c->ev_k1_join[q], 0); }
+    release_stream(c->xs, 0);
+    release_stream(c->up, 0);
+    release_stream(c->rk, 1);
+    for (auto &e : c->ev_rk) release_event(e, 0);
+    for (auto &e : c->ev_up) release_event(e, 0);
     c->e_lists.release();
     for (int q = 0; q < 3; ++q) {
         if (c->stage_h[q]) pool_free(c->stage_h[q], c->stage_cap, true);
         c->stage_d[q].release();
-        if (c->ev_stage[q]) (void)hipEventDestroy(c->ev_stage[q]);
-        if (c->ev_widen[q]) (void)hipEventDestroy(c->ev_widen[q]);
+        release_event(c->ev_stage[q], 0);
+        release_event(c->ev_widen[q], 0);
     }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_x) (void)hipEventDestroy(c->ev_x);
-    for (auto &e : c->ev_k1) if (e) (void)hipEventDestroy(e);
+    release_event(c->ev_fork, 0);
+    release_event(c->ev_x, 0);
+    for (auto &e : c->ev_k1) release_event(e, 0);
     c->t_pos16.release(); c->t_lo16.release(); c->t_hi16.release(); c->gcounts.release();
     c->t_pos32.release(); c->t_lo32.release(); c->t_hi32.release(); c->t_vin32.release(); c->t_vout32.release();
     for (int t = 0; t < 2; ++t) { c->refbits[t].release(); c->refbytes[t].release(); }
@@ -607,9 +683,9 @@ void reo_destroy(reo_ctx *c)
     c->state.release(); c->trace.release(); c->modes.release(); c->cand.release(); c->hist.release(); c->mrank.release(); c->lstate.release(); c->clist.release(); c->olist.release(); c->units_all.release(); c->xsend.release(); c->xrecv.release(); c->check_flag.release(); c->gridbar.release(); c->chunk_v.release(); c->chunk_i.release(); c->part.release();
     if (c->host_state) pool_free(c->host_state, sizeof(IterState), true);
     if (c->host_flags) pool_free(c->host_flags, 8 * sizeof(int32_t), true);
-    if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
+    release_event(c->ev_flags, 0);
     if (c->host_ref) pool_free(c->host_ref, c->host_ref_cap, true);
-    (void)hipStreamDestroy(c->stream);
+    release_stream(c->stream, 0);
     delete c;   // (its remaining DevBuf members are empty by now)
     tl_release_synced = false;
 }

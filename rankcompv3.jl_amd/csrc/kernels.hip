@@ -3834,12 +3834,12 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table)
         const size_t uw = static_cast<size_t>(kUnitRows) * kPlanes * (static_cast<size_t>(Q) * CJ / 32);
         if ((rc = c->xsend.ensure(uw * mw * nwaves)) || (rc = c->xrecv.ensure(uw * mw * nwaves * c->world))) return rc;
         if (!c->xs) {
-            for (int q = 0; q < 2; ++q) REO_HIP_CHECK(hipStreamCreateWithFlags(&c->k1s[q], hipStreamNonBlocking));
-            REO_HIP_CHECK(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
-            REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming));
-            for (int q = 0; q < 2; ++q) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_k1_join[q], hipEventDisableTiming));
-            for (int q = 0; q < 8; ++q) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_k1[q], hipEventDisableTiming));
+            for (int q = 0; q < 2; ++q) REO_HIP_CHECK(handle_stream(&c->k1s[q], 0));
+            REO_HIP_CHECK(handle_stream(&c->xs, 0));
+            REO_HIP_CHECK(handle_event(&c->ev_fork, 0));
+            REO_HIP_CHECK(handle_event(&c->ev_x, 0));
+            for (int q = 0; q < 2; ++q) REO_HIP_CHECK(handle_event(&c->ev_k1_join[q], 0));
+            for (int q = 0; q < 8; ++q) REO_HIP_CHECK(handle_event(&c->ev_k1[q], 0));
         }
         // the waves' item lists (uploads synchronise c->stream: before anything is forked)
         std::vector<std::vector<uint32_t>> wunits(nwaves);

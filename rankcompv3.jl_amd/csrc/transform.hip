@@ -1256,7 +1256,7 @@ int32_t transform_impl(reo_ctx *c)
     //  rows in L2, and the bucket form keeps its gene row in L2.)
     if (G <= 65535 && !(env && env[0] == 's')) {
         if (!c->host_flags) REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t), true));
-        if (!c->ev_flags) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming));
+        if (!c->ev_flags) REO_HIP_CHECK(handle_event(&c->ev_flags, 0));
         int32_t *fl = c->host_flags;
         bool wide = !kCountingPath<T> || (env && env[0] == 'w');
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1791,12 +1791,10 @@ void host_parallel(int nthreads, int ntasks, const std::function<void(int)> &fn)
 int32_t ensure_upload_streams(reo_ctx *c)
 {
     if (c->up) return REO_OK;
-    int lo_pri = 0, hi_pri = 0;
-    REO_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
-    REO_HIP_CHECK(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking));
-    REO_HIP_CHECK(hipStreamCreateWithPriority(&c->rk, hipStreamNonBlocking, hi_pri));
-    for (auto &e : c->ev_up) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : c->ev_rk) REO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    REO_HIP_CHECK(handle_stream(&c->up, 0));
+    REO_HIP_CHECK(handle_stream(&c->rk, 1));   // high priority
+    for (auto &e : c->ev_up) REO_HIP_CHECK(handle_event(&e, 0));
+    for (auto &e : c->ev_rk) REO_HIP_CHECK(handle_event(&e, 0));
     return REO_OK;
 }
 
@@ -1809,8 +1807,8 @@ int32_t ensure_staging(reo_ctx *c, size_t slot_bytes)
             REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->stage_h[q]), slot_bytes, true));
         }
         if ((rc = c->stage_d[q].ensure(slot_bytes))) return rc;
-        if (!c->ev_stage[q]) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_stage[q], hipEventDisableTiming));
-        if (!c->ev_widen[q]) REO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_widen[q], hipEventDisableTiming));
+        if (!c->ev_stage[q]) REO_HIP_CHECK(handle_event(&c->ev_stage[q], 0));
+        if (!c->ev_widen[q]) REO_HIP_CHECK(handle_event(&c->ev_widen[q], 0));
     }
     c->stage_cap = std::max(c->stage_cap, slot_bytes);
     return REO_OK;
