@@ -614,6 +614,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (const char *e = getenv("REO_EXCHANGE_WAVES")) c->x_waves = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("REO_EAGER_UPLOAD")) c->eager_mode = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("REO_EAGER_CHUNK")) c->eager_chunk = std::max(1, atoi(e));
+    if (const char *e = getenv("REO_EAGER_GATE")) c->eager_gate = atoi(e) != 0;
     if (const char *e = getenv("REO_UPLOAD_THREADS")) c->upload_threads = std::max(0, std::min(64, atoi(e)));
     c->debug_passes = getenv("REO_DEBUG_PASSES") != nullptr;
     c->debug_stamps = getenv("REO_DEBUG_STAMPS") != nullptr;

@@ -260,6 +260,9 @@ struct K1Args {
     int ngroups;
     const uint32_t *items;  // wave form: side << 31 | wave chunk << 16 | i-tile, one per workgroup
     unsigned long long *stamps;  // diagnostic (REO_K1_STAMPS=1): four s_memrealtime marks per item, else null
+    const int32_t *gate;         // pipelined upload: the transform's flags (0 non-finite input, 1 some tie so far, 4 / 5 another form of the
+                                 // ranking is needed), read by k1w_pairs_gated, which picks the tie form itself -- the host need not wait
+                                 // for the flags before it launches a side.  Else null.
 };
 
 // true when every gene j of the wave (64 RJ consecutive genes from jw) is padding (>= G) or lies in a 64-gene
@@ -575,11 +578,9 @@ __device__ __forceinline__ void k1w_item(const K1Args &a, uint4 *ring, int i0, i
 // More than 65 535 genes (NB = 17, 18): the big plane layout of transform.hip (five pos quads per gene and block, edge
 // rows of 8 uint4), 180 registers, two waves per SIMD.
 template <int NB, bool TIES>
-__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
+__device__ __forceinline__ void k1w_body(const K1Args &a, uint4 *ring)
 {
     constexpr int RI = kTileI, RJ = kRJ;
-    constexpr int ROWB = NB > 16 ? 128 : 64;
-    __shared__ uint4 ring[2 * RI * ROWB / 16];  // two slots of one block's tile operand: 2 x 2 KB (4 KB)
     const unsigned long long t_begin = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     // item: side << 31 | wave chunk << 16 | half-height << 15 | which half << 14 | i-tile
     const uint32_t item = a.items[blockIdx.x];
@@ -592,6 +593,31 @@ __global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
     } else {
         k1w_item<NB, TIES, RI>(a, ring, __builtin_amdgcn_readfirstlane(tile0), jw, side, t_begin);
     }
+}
+
+template <int NB, bool TIES>
+__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
+{
+    constexpr int RI = kTileI;
+    constexpr int ROWB = NB > 16 ? 128 : 64;
+    __shared__ uint4 ring[2 * RI * ROWB / 16];  // two slots of one block's tile operand: 2 x 2 KB (4 KB)
+    k1w_body<NB, TIES>(a, ring);
+}
+
+// The same with the tie form chosen on the DEVICE from the transform's flags (K1Args::gate): the pipelined upload launches a side of
+// the pair kernel behind the ranking of its group without the host having read the flags (transform.hip, eager_upload).  "Some tie so
+// far" covers every sample of the side; a flagged sample (non-finite value, another form of the ranking needed) makes the launch
+// return at once.  One path runs per launch, so the other costs nothing but its place in the code object.
+template <int NB>
+__global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs_gated(K1Args a)
+{
+    constexpr int RI = kTileI;
+    constexpr int ROWB = NB > 16 ? 128 : 64;
+    __shared__ uint4 ring[2 * RI * ROWB / 16];
+    const int bad = a.gate[0] | a.gate[4] | a.gate[5], ties = a.gate[1];   // (wave-uniform: scalar loads)
+    if (bad) return;
+    if (ties) k1w_body<NB, true>(a, ring);
+    else k1w_body<NB, false>(a, ring);
 }
 
 // ---------------------------------------------------------------------------
@@ -3608,7 +3634,8 @@ static void launch_pair_kernels(reo_ctx *c, const K1Args &a, unsigned grid, bool
     } else if (c->k1_wave) {  // one wave per workgroup, generated count loop (two groups)
         const unsigned gridw = static_cast<unsigned>(c->k1_items_n);
         if (gridw == 0) return;
-        if (c->has_ties) k1w_pairs<NB, true><<<gridw, 64, 0, c->stream>>>(a);
+        if (a.gate) k1w_pairs_gated<NB><<<gridw, 64, 0, c->stream>>>(a);   // the tie form is chosen on the device (K1Args::gate)
+        else if (c->has_ties) k1w_pairs<NB, true><<<gridw, 64, 0, c->stream>>>(a);
         else k1w_pairs<NB, false><<<gridw, 64, 0, c->stream>>>(a);
     } else {
         if (c->has_ties) k1_pairs<NB, true, false><<<grid, 256, 0, c->stream>>>(a);
@@ -3621,7 +3648,7 @@ static int32_t exchange_args(reo_ctx *c, XArgs &a, int m0, int mcnt);
 // sides (wave form, two groups): which sides' items are launched -- bit 0 the comparison's own group, bit 1 the rest; 3 = the whole
 // table.  keep_table: the class table has been cleared by the caller and holds other sides' planes already (the pipelined upload,
 // transform.hip eager_upload, launches a side as soon as its group's samples are ranked).
-int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table)
+int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *gate)
 {
     K1Args a;
     a.P = c->pos.p; a.AL = c->lo.p; a.AH = c->hi.p; a.table = c->table.p;
@@ -3696,7 +3723,8 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table)
         c->unit_map_uploaded = c->unit_map.p;
     }
     a.unit_map = c->unit_map.p;
-    a.items = nullptr; a.stamps = nullptr;
+    a.items = nullptr; a.stamps = nullptr; a.gate = gate;
+    if (gate && (!wave || wide || big)) { set_error("a gated launch of the pair kernel: wave form, at most 65535 genes and samples"); return REO_EINVAL; }
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);   // (workgroup forms)
     // item list of the wave form for a set of units: the units in order, side-major, i-tile-major, wave chunks fastest; kept
     // until the geometry changes.  (Group counts: one item per tile and chunk, all groups' blocks.)  part: which wave of how

@@ -220,9 +220,10 @@ struct reo_ctx {
     // pipelined upload of a host matrix (transform.hip, eager_upload): chunks on an upload stream, ranked as they arrive
     int eager_mode = 2;                  // REO_EAGER_UPLOAD: 0 off, 1 transform only, 2 (default) the pair kernel's sides as well
     int eager_chunk = 0;                 // REO_EAGER_CHUNK: columns per chunk (0: about 8 MB)
+    int eager_gate = 1;                  // REO_EAGER_GATE=0: the host reads the transform's flags before it launches a side (A/B)
     hipStream_t up = nullptr, rk = nullptr;   // the upload stream; the stream that widens, ranks and slices the chunks (high priority)
     hipEvent_t ev_up[8] = {nullptr};     // chunk k has arrived (ring)
-    hipEvent_t ev_rk[2] = {nullptr, nullptr};   // fork from / join into the context's stream
+    hipEvent_t ev_rk[4] = {nullptr, nullptr, nullptr, nullptr};   // fork from / join into the context's stream; a side's planes are in place (two sides)
     reo::DevBuf<int32_t> e_lists;        // [S] columns, [S + padding] slots, in column order
     // narrowed upload of Int64 matrices: host threads convert a chunk to 16- or 32-bit numbers in a pinned staging slot, a kernel widens it
     int upload_threads = 12;             // REO_UPLOAD_THREADS (0: the caller's array goes over the link as it is)
@@ -338,7 +339,7 @@ int32_t ensure_staging(reo_ctx *c, size_t slot_bytes);                          
 void host_parallel(int nthreads, int ntasks, const std::function<void(int)> &fn);   // fn(0 .. ntasks - 1) on the process-wide pool of host threads (and the caller)
 
 // kernels.hip
-int32_t launch_k1(reo_ctx *c, int k, int sides = 3, bool keep_table = false);  // sides: bit 0 = the comparison's own group, bit 1 = the rest (wave form; eager_upload)
+int32_t launch_k1(reo_ctx *c, int k, int sides = 3, bool keep_table = false, const int32_t *gate = nullptr);  // sides: bit 0 = the comparison's own group, bit 1 = the rest (wave form; eager_upload)
 int64_t exchange_unit_words(const reo_ctx *c);   // uint32 per packed work unit
 int32_t exchange_units_per_rank(const reo_ctx *c);
 int32_t launch_pack_units(reo_ctx *c, int m0 = 0, int mcnt = -1, uint32_t *send = nullptr, hipStream_t st = nullptr);    // this shard's units (all, or slots m0 .. m0 + mcnt - 1) -> c->xsend / send

@@ -1708,7 +1708,7 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     if (c->eager_chunk > 0) CH = c->eager_chunk;   // REO_EAGER_CHUNK (experiments)
     std::vector<int> left(c->ngroups);
     for (int g = 0; g < c->ngroups; ++g) left[g] = c->goff[g + 1] - c->goff[g];
-    int sides_done = 0, ranked = 0, ranked_at_read = -1;
+    int sides_done = 0, ranked = 0, ranked_at_read = -1, nsides_launched = 0;
     bool fallback = false, bad_values = false;
     int32_t *fl = c->host_flags;
     auto read_flags = [&]() -> int32_t {   // the flags so far (waits for the rankings queued so far, not for the pair kernel)
@@ -1750,15 +1750,24 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
             if (rc) return rc;
         }
         if (with_k1 && ready) {   // two groups: side 0 counts group 0's samples, side 1 group 1's (k = 0)
-            stamp("a group's last chunk enqueued");
-            if ((rc = read_flags())) return rc;
-            stamp("its flags read");
-            if (fallback || bad_values) continue;
+            // The side is launched behind the slicing of its group (an event) as k1w_pairs_gated, which looks at the transform's flags on
+            // the device and takes the tie form they ask for -- "ties seen so far" covers every sample of this side, and the tie-free
+            // loop is exact on a side without ties.  The host does not wait for anything here (it used to read the flags: 70 us of
+            // idle GPU per side, profiles/r5_pipelined_upload_timeline_config4.txt); a flagged sample makes the launch return at once,
+            // and the host finds out at the end.
             const int mask = ready & 3;
-            c->has_ties = fl[1];   // ties seen SO FAR: covers every sample of this side (the tie-free loop is exact on a side without ties)
-            // (the planes of this side are in place: the host has just waited for the ranking stream)
-            if ((rc = launch_k1(c, 0, mask, true))) return rc;
-            stamp("its side of the pair kernel launched");
+            if (c->eager_gate) {
+                hipEvent_t ev = c->ev_rk[2 + (nsides_launched++ & 1)];
+                REO_HIP_CHECK(hipEventRecord(ev, rk));
+                REO_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
+                if ((rc = launch_k1(c, 0, mask, true, d_flags.p))) return rc;
+            } else {   // REO_EAGER_GATE=0: the host reads the flags and picks the tie form itself (the planes are in place: it has waited for rk)
+                if ((rc = read_flags())) return rc;
+                if (fallback || bad_values) continue;
+                c->has_ties = fl[1];
+                if ((rc = launch_k1(c, 0, mask, true))) return rc;
+            }
+            stamp("a side of the pair kernel launched");
             sides_done |= mask;
         }
     }

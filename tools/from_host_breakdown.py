@@ -17,7 +17,7 @@ for mode, chunk in (("0", None), ("1", None), ("2", None), ("2", "16"), ("2", "3
     os.environ["REO_EAGER_UPLOAD"] = mode
     if chunk: os.environ["REO_EAGER_CHUNK"] = chunk
     else: os.environ.pop("REO_EAGER_CHUNK", None)
-    ctx = pkg.Context(device=0, seed=seed); ctx.set_profiling(True)
+    ctx = pkg.Context(device=0, seed=seed); ctx.set_profiling(os.environ.get("FHB_PROFILING", "1") == "1")
     rows = []
     for rep in range(5):
         ctx.reset_timings(); torch.cuda.synchronize()
