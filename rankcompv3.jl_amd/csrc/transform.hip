@@ -1673,10 +1673,11 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
         (rc = c->pos.ensure(nq)) || (rc = c->lo.ensure(nq)) || (rc = c->hi.ensure(nq)))
         return rc;
     if (!c->host_flags) REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->host_flags), 8 * sizeof(int32_t), true));
-    // Three streams.  `up` carries the copies and never waits for a kernel of the other two.  `rk` (high priority) widens, ranks and
-    // slices the chunks as they arrive.  The context's own stream `st` runs the pair kernel's sides, each behind the slicing of
-    // its group (an event), so that side 0 counts while group 1's chunks are still being copied, widened and ranked beside it --
-    // on one stream the ranking of group 1 (and, with it, the staging ring of the narrowed upload) queued up behind side 0.
+    // Three streams.  `up` carries the copies and the widening of narrowed chunks and never waits for a kernel of the other two.  `rk`
+    // (high priority) ranks and slices the chunks as they arrive.  The context's own stream `st` runs the pair kernel's sides, each
+    // behind the slicing of its group (an event), so that side 0 counts while group 1's chunks are still being copied, widened and
+    // ranked beside it -- on one stream the ranking of group 1 (and, with it, the staging ring of the narrowed upload) queued up behind
+    // side 0.
     if ((rc = ensure_upload_streams(c))) return rc;
     hipStream_t rk = c->rk;
     struct OnStream {   // the transform's launchers enqueue on the context's stream: it is `rk` while one of these lives
