@@ -1438,9 +1438,20 @@ __global__ __launch_bounds__(256) void k2_scan(const uint32_t *__restrict__ tabl
 }
 
 // ---------------------------------------------------------------------------
-// K3.  McCullagh's test for a 3x3 table, closed form of :225-259.
-//   N = [[a b][b d]], n = (a, d), R = (R1, R2); singular iff a*d == b*b (exact
-//   integer test, equivalent to abs(det(N)) <= eps() for integer N, :242).
+// K3.  McCullagh's test for a 3x3 table, :225-259.
+//   N = [[a b][b d]], n = (a, d), R = (R1, R2).  With an integer determinant a*d - b*b != 0 the weights
+//   omega2 = inv(N) n are taken in closed form (exact integers, one division each).
+//   The integer-singular tables are NOT all singular for the reference: :242 tests abs(det(N)) <= eps() on the
+//   LU factors of Float64.(N).  a, d >= b >= 0, so a*d == b*b leaves two cases:
+//     b == 0 (then a == 0 or d == 0): a pivot is exactly zero, det(lu) == 0.0 -> (1, 0, 0, 0, 0), as :243;
+//     a == b == d > 0: the elimination's l21 = b * (1.0 / b) is not 1 for about one b in ten (49, 98, 103,
+//       107, 161, ...), u22 = b - l21 * b is then a few ulps of b, det = b * u22 > eps, and the reference goes
+//       on with the inverse of that factorisation.  What it gets is rounding noise of its LAPACK; what is
+//       reproduced here, operation by operation and without fused multiply-adds (the library is built with
+//       -ffp-contract=off), is the arithmetic of the oracle's pivoted Gauss-Jordan elimination
+//       (oracle/reo_oracle.c, oracle_mccullagh), so that the HIP path and its checker agree in this corner
+//       too.  delta1 is robust there (both log terms are equal and the weights sum to 1); nu, and with it
+//       delta2 / se / z1, depend on the noise (omega2 sums to 1 or to 2).  DESIGN.md section 2.
 // FULL = false: delta1 only (the passes in between need nothing else: delta2, se, z1 and the test's own p-value
 // never reach the next pass -- :412 overwrites the p-value -- and are recomputed for the pass that ends the loop).
 template <bool FULL>
@@ -1452,10 +1463,28 @@ __device__ __forceinline__ void mccullagh3(const int32_t *n, double *out)
     const long long d = n13 + n23 + n31 + n32;  // N22
     const long long R1 = n12 + n13, R2 = n13 + n23;  // :239
     const long long det = a * d - b * b;
-    if (det == 0) { out[0] = 1.0; out[1] = out[2] = out[3] = out[4] = 0.0; return; }
-    const double fa = static_cast<double>(a), fd = static_cast<double>(d), fdet = static_cast<double>(det);
-    const double w1 = static_cast<double>(d * (a - b)) / fdet;  // omega2 = inv(N) n  (:246)
-    const double w2 = static_cast<double>(a * (d - b)) / fdet;
+    const double fa = static_cast<double>(a), fd = static_cast<double>(d);
+    double w1 = 0.0, w2 = 0.0;  // omega2 = inv(N) n  (:245-246)
+    if (det != 0) {
+        const double fdet = static_cast<double>(det);
+        w1 = static_cast<double>(d * (a - b)) / fdet;
+        w2 = static_cast<double>(a * (d - b)) / fdet;
+    } else {
+        bool singular = b == 0;  // a zero pivot: det(lu(N)) is exactly 0.0
+        if (!singular) {         // a == b == d > 0: the float elimination of :242, in the oracle's order of operations
+            const double B = fa, inv = 1.0 / B, l = B * inv;  // row 0 scaled by the reciprocal of its pivot: (l, l | inv, 0)
+            const double u = B - B * l;                       // row 1 minus B * row 0: (., u | -l, 1)
+            singular = u == 0.0 || fabs(B * u) <= 2.220446049250313e-16;  // det = B * u against eps()
+            if (!singular) {
+                const double inv2 = 1.0 / u;
+                const double i10 = (0.0 - l) * inv2, i11 = inv2;          // row 1 scaled by the reciprocal of u
+                const double i00 = inv - l * i10, i01 = 0.0 - l * i11;    // row 0 minus l * row 1
+                w1 = i00 * B + i01 * B;                                   // inverse times n = (B, B)
+                w2 = i10 * B + i11 * B;
+            }
+        }
+        if (singular) { out[0] = 1.0; out[1] = out[2] = out[3] = out[4] = 0.0; return; }  // :243
+    }
     const double nu = 1.0 / (fa * w1 + fd * w2);                // :247
     const double r1 = static_cast<double>(R1), r2 = static_cast<double>(R2);
     const double d1 = (fa * w1 * nu) * log((r1 + 0.5) / (fa - r1 + 0.5)) +

@@ -84,3 +84,35 @@ def ref_mask(G: int, n: int, seed: int) -> np.ndarray:
     m = np.zeros(G, dtype=bool)
     m[order[: min(n, G)]] = True
     return m
+
+
+def lu_corner(b: int, n13: int, spg: int = 2, corners: int = 1, n_always: int = 3, n_unstable: int = 2, seed: int = 0):
+    """A small problem whose `corners` first genes (before the shuffle) have a 3x3 table with
+    n12 = n21 = n23 = n32 = 0 and n13 + n31 = b against the full reference set: N = [[b b][b b]], the
+    integer-singular table that the reference's float test abs(det(N)) <= eps() (src/RankCompV3.jl:242)
+    calls NON-singular whenever b * (1.0 / b) != 1 (b = 49, 98, 103, 107, 161, ...).
+    `spg` samples per group; every designed ordering is unanimous, hence stable at any threshold.
+    Returns (X Int64 G x 2*spg, group labels, indices of the corner genes after the shuffle)."""
+    assert 0 <= n13 <= b and spg >= 2 and corners >= 1
+    S = 2 * spg
+    treat = np.arange(S) >= spg
+    rows = []
+    for c in range(corners):                   # below the n13 partners in ctrl, above them in treat
+        rows.append(np.where(treat, 100000 + 10 * c, 10 * c))
+    for j in range(n13):                       # constant: class (1, 3) against a corner gene
+        rows.append(np.full(S, 40000 + j))
+    for j in range(b - n13):                   # below every corner in ctrl, above in treat: class (3, 1)
+        rows.append(np.where(treat, 200000 + j, -100000 - j))
+    for j in range(n_always):                  # always above / always below: n11 / n33
+        rows.append(np.full(S, (500000 + j) if j % 2 == 0 else (-500000 - j)))
+    if spg % 2 == 0:
+        for j in range(n_unstable):            # alternating around a corner gene in both groups: n22
+            alt = np.where(np.arange(S) % 2 == 0, -(5 + j), 5 + j)
+            rows.append(np.where(treat, 100000, 0) + 10 * (corners - 1) * (np.arange(S) % 2) + alt * (10 * corners))
+    X = np.array(rows, dtype=np.int64)
+    G = X.shape[0]
+    perm = np.argsort(u64(seed + 11, np.arange(G), 0), kind="stable")
+    inv = np.empty(G, dtype=np.int64)
+    inv[perm] = np.arange(G)
+    group = np.array(["ctrl"] * spg + ["treat"] * spg, dtype=object)
+    return X[perm], group, inv[:corners]

@@ -76,6 +76,72 @@ def test_mccullagh_device_routine(pkg, oracle, golden):
     assert sing >= 70
 
 
+def _abd_tables(bs, splits=None):
+    """3x3 tables with n12 = n21 = n23 = n32 = 0: N = [[b b][b b]], integer-singular for every b."""
+    rows = []
+    for b in bs:
+        for n13 in (sorted({0, 1, b // 2, b - 1, b}) if splits is None else splits(b)):
+            for diag in ((5, 3, 2), (0, 0, 0)):
+                rows.append([diag[0], 0, n13, 0, diag[1], 0, b - n13, 0, diag[2]])
+    return np.array(rows, dtype=np.int32)
+
+
+def test_mccullagh_integer_singular_tables_follow_the_float_elimination(pkg, oracle):
+    """:242 tests abs(det(N)) <= eps() on the LU of Float64.(N), not a*d == b*b.  For a = b = d > 0 the
+    elimination's l21 = b * (1.0 / b) is not 1 for 286 of the b in 1..2999 (49, 98, 103, 107, 161, 187, ...):
+    det = b * u22 > eps and the reference computes on with that factorisation's inverse.  The device takes the
+    oracle's arithmetic there (kernels.hip, mccullagh3): every such table equal to oracle.mccullagh."""
+    named = [8, 49, 98, 103, 107, 161, 187]
+    cont = np.concatenate([_abd_tables(named), _abd_tables(range(1, 3001), lambda b: sorted({0, b // 3, b // 2, b}))])
+    with pkg.Context(device=0) as ctx:
+        out = ctx.mccullagh(cont)
+    live, live_b = 0, set()
+    for i in range(cont.shape[0]):
+        exp, _, _ = oracle.mccullagh(cont[i].reshape(3, 3))
+        b = int(cont[i, 2] + cont[i, 6])
+        if exp[3] == 0.0:   # the singular branch: (1, 0, 0, 0, 0)
+            assert out[i].tolist() == [1.0, 0.0, 0.0, 0.0, 0.0], (b, out[i])
+            assert b * (1.0 / b) == 1.0
+        else:
+            live += 1; live_b.add(b)
+            assert b * (1.0 / b) != 1.0
+            assert abs(out[i, 0] - exp[0]) <= P_ATOL, (b, out[i], exp)
+            assert np.allclose(out[i, 1:], exp[1:], rtol=STAT_RTOL, atol=1e-12), (b, out[i], exp)
+            n13 = float(cont[i, 2])     # delta1 is robust in this corner: both log terms are equal, the weights sum to 1
+            assert np.isclose(out[i, 1], np.log((n13 + 0.5) / (b - n13 + 0.5)), rtol=1e-9, atol=1e-12)
+    assert live_b >= {49, 98, 103, 107, 161, 187} and 8 not in live_b
+    assert len([b for b in live_b if b < 3000]) == 286 and live > 2000
+
+
+@pytest.mark.parametrize("b,n13,spg,corners,dtype", [(49, 24, 2, 1, np.int64), (49, 24, 2, 3, np.float64), (107, 30, 2, 2, np.int64),
+                                                     (161, 80, 3, 1, np.int64), (98, 49, 4, 2, np.float64), (8, 4, 2, 1, np.int64)])
+def test_identify_degs_on_integer_singular_tables(pkg, oracle, b, n13, spg, corners, dtype):
+    """A whole run in which genes HAVE such tables: two to four samples per group, the corner genes' partners
+    are all n11 / n13 / n22 / n31 / n33 with n13 + n31 = b (synth.lu_corner).  First pass and a run of passes."""
+    X, group, ci = pkg.synth.lu_corner(b, n13, spg, corners, seed=5)
+    G = X.shape[0]
+    gid, lev = pkg.encode_groups(group)
+    ref0 = np.ones(G, dtype=bool)
+    names = list(range(G))
+    Xf = X.astype(np.float64)
+    hit = 0
+    for n_iter, n_conv in ((1, 0), (6, 0), (6, 1)):
+        exp, iters, trace = oracle.identify_degs(Xf, gid, 2, 0.01, 1.0, 0.05, ref0, n_iter, n_conv, 7)
+        run = pkg.run_identify_degs(X.astype(dtype), group, names, 0.01, 1.0, 0.05, ref0, n_iter, n_conv, seed=7, device=0)
+        assert run.iters_run == iters and run.trace == trace
+        _check_result(run.result, exp)
+        if n_iter == 1:
+            for c in ci:
+                t = exp[c, 2:11].astype(int)
+                assert t[1] == t[3] == t[5] == t[7] == 0 and t[2] + t[6] == b and t[2] == n13
+                if b * (1.0 / b) != 1.0:
+                    assert exp[c, 13] > 0 and run.result[c, 13] > 0       # se: the non-singular branch ran
+                    hit += 1
+                else:
+                    assert exp[c, 13] == 0 and run.result[c, 13] == 0
+    assert hit == (corners if b != 8 else 0)
+
+
 @pytest.mark.parametrize("family,G,S", [("t0", 700, 40), ("t1", 700, 40), ("float", 500, 31), ("t1", 333, 9)])
 def test_counts_codes_tallies_bit_exact(pkg, oracle, family, G, S):
     seed = 0x5EED0002

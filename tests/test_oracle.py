@@ -16,6 +16,33 @@ def test_mccullagh_kat_reference_numbers(oracle, rn, golden):
     assert round(out[1], 2) == g["paper_rounded"]["delta1"] and round(out[2], 2) == g["paper_rounded"]["delta2"]
 
 
+def test_mccullagh_integer_singular_corner_what_the_restatements_agree_on(oracle, rn):
+    """a = b = d > 0 (n12 = n21 = n23 = n32 = 0): N = [[b b][b b]] is singular, yet :242's test is on the float LU
+    and passes whenever b * (1.0 / b) != 1.  What follows is rounding noise of the factorisation: the C oracle
+    (Gauss-Jordan, no FMA -- the arithmetic the HIP path reproduces) and numpy's LAPACK agree on WHICH b take the
+    non-singular branch and on delta1 (both log terms are equal, the weights sum to 1); they need not agree on
+    nu, hence on delta2 / se / z1 (omega2 sums to 1 or 2 in the C arithmetic: b = 161, 322, ...).  Julia's own
+    numbers (OpenBLAS getrf + getri) cannot be had here; DESIGN.md section 2 states the choice."""
+    live = disagree = 0
+    for b in list(range(1, 700)) + [2999]:
+        for n13 in sorted({0, b // 2, b}):
+            mat = np.array([[5, 0, n13], [0, 3, 0], [b - n13, 0, 2]])
+            c, _, _ = oracle.mccullagh(mat)
+            n, _, _ = rn.mccullagh(mat)
+            nonsing = b * (1.0 / b) != 1.0
+            assert (c[3] != 0.0) == nonsing and (n[3] != 0.0) == nonsing, b
+            if not nonsing:
+                assert tuple(c) == (1.0, 0.0, 0.0, 0.0, 0.0) == tuple(n)
+                continue
+            live += 1
+            d1 = np.log((n13 + 0.5) / (b - n13 + 0.5))
+            assert np.isclose(c[1], d1, rtol=1e-9, atol=1e-12) and np.isclose(n[1], d1, rtol=1e-6, atol=1e-9), (b, c, n)
+            assert np.isfinite(c).all() and c[3] > 0
+            disagree += not np.isclose(c[3], n[3], rtol=1e-6)
+    assert live > 100
+    assert disagree > 0, "the corner has become well-defined: tighten this test"
+
+
 def test_threshold_table(oracle, rn, golden):
     tab = golden("thresholds.json")
     for p, row in tab.items():

@@ -18,7 +18,18 @@ def case():
     labels = np.concatenate([[f"grp{g}"] * int(n) for g, n in enumerate(sizes)])
     if rng.random() < 0.5:
         labels = labels[rng.permutation(S)]
-    kind = str(rng.choice(["small_int", "wide_int", "float_band", "ranks", "float_cont", "big_int"]))
+    kind = str(rng.choice(["small_int", "wide_int", "float_band", "ranks", "float_cont", "big_int", "lu_corner"]))
+    if kind == "lu_corner":
+        # genes whose table is N = [[b b][b b]]: integer-singular, non-singular for :242's float test when b * (1.0 / b) != 1
+        # (kernels.hip mccullagh3; synth.lu_corner).  Half of the cases take such a b, the reference set is all genes or a subset.
+        b = int(rng.choice([49, 98, 103, 107, 161, 187, 196, 197, 206, 214, 237, 239])) if rng.random() < 0.5 else int(rng.integers(12, 400))
+        X, labels, _ = pkg.synth.lu_corner(b, int(rng.integers(0, b + 1)), int(rng.integers(2, 6)), int(rng.integers(1, 4)),
+                                           int(rng.integers(0, 6)), int(rng.integers(0, 4)), seed=int(rng.integers(0, 2 ** 30)))
+        if rng.random() < 0.5: X = X.astype(np.float64)
+        G, S = X.shape
+        return dict(G=G, S=S, ng=2, labels=labels, X=X, kind=kind, pval_reo=float(rng.choice([0.01, 0.05, 0.3])),
+                    n_conv=int(rng.choice([0, 1, 5])), n_iter=int(rng.integers(1, 9)), seed=int(rng.integers(0, 2 ** 40)),
+                    nref=G if rng.random() < 0.5 else int(rng.integers(max(3, G // 2), G + 1)))
     if kind == "small_int": X = rng.integers(0, int(rng.integers(2, 12)), size=(G, S))
     elif kind == "wide_int": X = rng.integers(-50000, 50000, size=(G, S))
     elif kind == "big_int": X = rng.integers(0, 2 ** 31, size=(G, S))
