@@ -143,8 +143,12 @@ int32_t reo_set_allgather(reo_ctx *ctx, reo_allgather_fn fn, void *user);
  * kernel's items of a group (its "side" of every pair) start as soon as that group's last column has been ranked, while the other
  * group is still on its way.  The call still returns only when the whole matrix has been read (no host pointer is retained); the pair
  * kernel may be running then, exactly as after reo_build_pairs on one GPU, and the reo_build_pairs(ctx, 0) that follows has nothing
- * left to do (it is still the call that makes the class table current: keep it).  Results are bit-identical in every order.  A
- * non-finite value is reported (REO_EINVAL) by whichever call reads the matrix: this one in the pipelined case.
+ * left to do (it is still the call that makes the class table current: keep it).  Results are bit-identical in every order.
+ * VALUES.  +-Inf are accepted and compared as the reference's is_greater compares them (src/RankCompV3.jl:71-77): equal infinities
+ * are neither tied nor greater (abs(Inf - Inf) = NaN is not < 0.1, Inf > Inf is false -- the pair (i, j), i < j, counts as "i not
+ * greater" in that sample, no coin), an infinity against any other value compares as usual; log(0) = -Inf tables run unchanged.
+ * A NaN is refused (REO_EINVAL, by whichever call reads the matrix: this one in the pipelined case): every comparison with a NaN
+ * is false, which makes a NaN gene below every later and above every earlier gene -- row order, not an ordering.
  * A context that is used for several matrices should keep to that order each time: a matrix handed over while the groups of the LAST
  * problem are still set is ranked and paired with those, and all of it is done again when the new groups arrive (correct, but wasted).
  * REO_EAGER_UPLOAD=0 in the environment switches the pipelining off, =1 keeps it to the ranking. */

@@ -93,6 +93,29 @@ def pair_counts(X, gid, ngroups, i0, i1, j0, j1):
     return gt, eq
 
 
+def pair_counts_as_evaluated(X, gid, ngroups, i0, i1, j0, j1):
+    """The counts of pair (i, j) as the reference comes by them: it evaluates is_greater(x_i, x_j) for i < j only
+    (src/RankCompV3.jl:366-372) and MIRRORS the class for (j, i) (:386), i.e. for i > j the counts are
+    n_gt(i, j) = S_g - n_gt(j, i) - n_eq(j, i), n_eq(i, j) = n_eq(j, i).  Equal to pair_counts() -- the comparator applied to
+    the ordered pair -- unless both values are the same infinity (is_greater(Inf, Inf) is false BOTH ways: neither tied
+    nor greater).  The diagonal, which the reference never evaluates, is reported as tied in every sample."""
+    gid = np.ascontiguousarray(gid, dtype=np.int32)
+    gt, eq = pair_counts(X, gid, ngroups, i0, i1, j0, j1)
+    tgt, teq = pair_counts(X, gid, ngroups, j0, j1, i0, i1)
+    sizes = np.bincount(gid, minlength=ngroups).astype(np.int64)
+    ii = np.arange(i0, i1)[:, None]
+    jj = np.arange(j0, j1)[None, :]
+    mgt = (sizes[None, None, :] - tgt.transpose(1, 0, 2).astype(np.int64) - teq.transpose(1, 0, 2)).astype(np.uint16)
+    meq = teq.transpose(1, 0, 2)
+    low = (ii > jj)[:, :, None]
+    dia = (ii == jj)[:, :, None]
+    gt = np.where(low, mgt, gt)
+    eq = np.where(low, meq, eq)
+    gt = np.where(dia, np.uint16(0), gt)
+    eq = np.where(dia, sizes.astype(np.uint16)[None, None, :], eq)
+    return gt.astype(np.uint16), eq.astype(np.uint16)
+
+
 def build_codes(X, gid, ngroups, k, thr, seed):
     X, G, S = _colmajor(X)
     gid = np.ascontiguousarray(gid, dtype=np.int32)

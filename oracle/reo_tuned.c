@@ -109,7 +109,7 @@ int32_t tuned_build_table(const double *X, int64_t G, int64_t S, int64_t ld, con
                 qsort(k, (size_t)G, sizeof(keyed), cmp_keyed);
                 int64_t l = 0, h = 0;
                 for (int64_t p = 0; p < G; ++p) {
-                    while (!(fabs(k[l].v - k[p].v) < 0.1)) ++l;             /* first position of the band */
+                    while (l < p && !(fabs(k[l].v - k[p].v) < 0.1)) ++l;    /* first position of the band (an infinity is tied with nothing, itself included: abs(Inf - Inf) = NaN, :72 -- equal infinities keep the sort's gene order) */
                     if (h < p) h = p;
                     while (h + 1 < G && fabs(k[h + 1].v - k[p].v) < 0.1) ++h;  /* last position of the band */
                     const size_t o = (size_t)k[p].g * SP + slot[s];

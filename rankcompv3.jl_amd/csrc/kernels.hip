@@ -260,7 +260,7 @@ struct K1Args {
     int ngroups;
     const uint32_t *items;  // wave form: side << 31 | wave chunk << 16 | i-tile, one per workgroup
     unsigned long long *stamps;  // diagnostic (REO_K1_STAMPS=1): four s_memrealtime marks per item, else null
-    const int32_t *gate;         // pipelined upload: the transform's flags (0 non-finite input, 1 some tie so far, 4 / 5 another form of the
+    const int32_t *gate;         // pipelined upload: the transform's flags (0 NaN in the input, 1 some tie so far, 4 / 5 another form of the
                                  // ranking is needed), read by k1w_pairs_gated, which picks the tie form itself -- the host need not wait
                                  // for the flags before it launches a side.  Else null.
 };
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs(K1Args a)
 
 // The same with the tie form chosen on the DEVICE from the transform's flags (K1Args::gate): the pipelined upload launches a side of
 // the pair kernel behind the ranking of its group without the host having read the flags (transform.hip, eager_upload).  "Some tie so
-// far" covers every sample of the side; a flagged sample (non-finite value, another form of the ranking needed) makes the launch
+// far" covers every sample of the side; a flagged sample (a NaN, another form of the ranking needed) makes the launch
 // return at once.  One path runs per launch, so the other costs nothing but its place in the code object.
 template <int NB>
 __global__ __launch_bounds__(64, NB > 16 ? 2 : 3) void k1w_pairs_gated(K1Args a)

@@ -43,6 +43,12 @@ namespace reo {
 
 namespace {
 
+// NaN in the expression matrix (the only value refused; +-Inf are ranked as the reference compares them, see Codec<double>)
+constexpr const char *kNaNMessage =
+    "expression matrix contains NaN: is_greater (src/RankCompV3.jl:71-77) answers false for every comparison with a NaN, so a NaN gene "
+    "would be below every later gene and above every earlier one -- an outcome of the row order, not an ordering; drop or impute such "
+    "rows first (+-Inf are accepted)";
+
 template <class T>
 struct Codec;
 
@@ -59,7 +65,22 @@ struct Codec<double> {
         return __longlong_as_double(u);
     }
     __device__ static bool tie(double x, double y) { return fabs(x - y) < 0.1; }
-    __device__ static bool finite(double x) { return isfinite(x); }
+    // is_greater (/root/reference/src/RankCompV3.jl:71-77) on infinities: abs(Inf - Inf) = NaN is not < 0.1 and Inf > Inf is false, so
+    // EQUAL infinities are neither tied nor greater -- the pair (i, j), i < j, counts as "i not greater" in that sample, every time, no
+    // coin -- while an infinity against anything else compares as usual.  In rank space: the -Inf genes take the lowest positions and
+    // the +Inf genes the highest, each in gene order, with a tie band of the gene alone.  The codes make exactly that of the generic
+    // machinery: gene g's infinity gets a code of its own inside the code space of the NaNs (which never reach a ranking: refused),
+    // ascending in g; dec() of such a code is a NaN, so the reference's predicate ties it with nothing, and no finite value's band
+    // reaches it (abs(x - Inf) = Inf).  log(0) = -Inf is an ordinary value of log-transformed tables.
+    static constexpr uint64_t kPosInf = 0xFFF0000000000000ULL, kNegInf = 0x000FFFFFFFFFFFFFULL;   // enc(+Inf), enc(-Inf)
+    __device__ static uint64_t enc(double x, uint32_t g)
+    {
+        const uint64_t k = enc(x);
+        return k == kPosInf ? k + g : (k == kNegInf ? k - (static_cast<uint32_t>(kMaxGenes) - g) : k);   // (g <= kMaxGenes - 1)
+    }
+    // NaN is refused: is_greater(NaN, y) = (NaN > y) = false and is_greater(x, NaN) = false for every x, so a NaN gene would be
+    // "below" every later gene and "above" every earlier one -- an outcome that depends on the row order and is no ordering.
+    __device__ static bool ordered(double x) { return x == x; }
 };
 
 template <>
@@ -68,7 +89,8 @@ struct Codec<int64_t> {
     __device__ static int64_t dec(uint64_t k) { return static_cast<int64_t>(k ^ 0x8000000000000000ULL); }
     // abs(x - y) < 0.1 on Int64 <=> x == y
     __device__ static bool tie(int64_t x, int64_t y) { return x == y; }
-    __device__ static bool finite(int64_t) { return true; }
+    __device__ static uint64_t enc(int64_t x, uint32_t) { return enc(x); }
+    __device__ static bool ordered(int64_t) { return true; }
 };
 
 #ifdef REO_WITH_ROCPRIM   // the segmented-sort form of the transform (rounds 1-4): built for A/B runs only (make ROCPRIM=1)
@@ -83,12 +105,12 @@ __global__ __launch_bounds__(256) void t_keys(const T *__restrict__ X, int64_t l
     uint64_t diff = 0;
     if (g < G) {
         T x = X[static_cast<int64_t>(g) + static_cast<int64_t>(colmap[cb0 + c]) * ld];
-        if (!Codec<T>::finite(x)) atomicOr(bad, 1);
+        if (!Codec<T>::ordered(x)) atomicOr(bad, 1);
         size_t o = static_cast<size_t>(c) * G + g;
-        const uint64_t k = Codec<T>::enc(x);
+        const uint64_t k = Codec<T>::enc(x, static_cast<uint32_t>(g));
         keys[o] = k;
         idx[o] = static_cast<IdxT>(g);
-        diff = k ^ Codec<T>::enc(X[0]);  // bits in which any key differs from one fixed key
+        diff = k ^ Codec<T>::enc(X[0], 0u);  // bits in which any key differs from one fixed key
     }
     // only the key bits that vary anywhere need sorting: OR-reduce them (wave, then one atomic per wave)
 #pragma unroll
@@ -150,7 +172,7 @@ __global__ __launch_bounds__(256) void t_bands(const uint64_t *__restrict__ keys
 // keys in again.
 // Key = the varying bits (begin_bit .. begin_bit + nbits - 1) of the order-preserving code; bit `nbits`
 // marks padding items, which sort behind every gene.
-// flags: 0 non-finite input, 1 some tie, 4 some sample needs more than 31 key bits (the caller then
+// flags: 0 NaN in the input, 1 some tie, 4 some sample needs more than 31 key bits (the caller then
 // redoes the whole transform with the segmented sort).
 // the histogram form of the per-sample ranking (t_sample): integer input only, at most this many varying key bits
 template <class T> constexpr bool kCountingPath = false;
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
         kw[e] = static_cast<uint32_t>(key0);
         if (i < G) {
             const T x = col[i];
-            bad |= !Codec<T>::finite(x);
+            bad |= !Codec<T>::ordered(x);
             const uint64_t code = Codec<T>::enc(x);
             kw[e] = static_cast<uint32_t>(code);
             diff |= code ^ key0;
@@ -490,7 +512,7 @@ __global__ __launch_bounds__(1024) void t_sample(const T *__restrict__ X, int64_
 // their scans run equally long (results go to a by-slot scratch row and into gene order through LDS at the end).
 // Never gives up: a crowded bucket only costs its own members a longer scan.  Arrival slot, bucket and the 16 offset bits are
 // parked in the gene's pos / lo / hi rows between the phases (a thread reads back what it wrote itself).
-// flags: 0 non-finite input, 1 some tie.
+// flags: 0 NaN in the input, 1 some tie.
 constexpr int kSplit1 = 1024;                 // splitters (= threads)
 
 // bytes of LDS in front of the two per-gene arrays: splitters + 16 wave maxima, NB bins (skewed) + end word + wave totals; 16-byte aligned
@@ -581,15 +603,15 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     const size_t orow = static_cast<size_t>(slots[c]) * Gp;
     uint16_t *prow = pos + orow, *lrow = lo + orow, *hrow = hi + orow;
     int32_t *anytie = flags + 1;
-    // ---- 1. the column's maximum, non-finite values; the sample, sorted
+    // ---- 1. the column's maximum, NaNs; the sample, sorted
     TSTAMP(0);
     uint64_t kmax = 0;
     bool bad = false;
 #pragma unroll 8
     for (int i = t; i < G; i += 1024) {   // (eight loads in flight: the column comes from HBM here)
         const T x = col[i];
-        bad |= !Codec<T>::finite(x);
-        const uint64_t k = Codec<T>::enc(x);
+        bad |= !Codec<T>::ordered(x);
+        const uint64_t k = Codec<T>::enc(x, static_cast<uint32_t>(i));
         kmax = k > kmax ? k : kmax;
     }
 #pragma unroll
@@ -603,7 +625,8 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     TSTAMP(1);
     {
         // thread t's sample: gene floor(t G / 1024) (repeats when G < 1024: equal splitters leave empty buckets between them)
-        uint64_t v = t == kSplit1 - 1 ? kmax : Codec<T>::enc(col[static_cast<int>((static_cast<int64_t>(t) * G) >> 10)]);
+        const int gs = static_cast<int>((static_cast<int64_t>(t) * G) >> 10);
+        uint64_t v = t == kSplit1 - 1 ? kmax : Codec<T>::enc(col[gs], static_cast<uint32_t>(gs));
         // bitonic sort, one key per thread: distances below 64 inside the wave, the others through LDS
         for (int k = 2; k <= kSplit1; k <<= 1) {
             const bool up = (t & k) == 0;
@@ -647,7 +670,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
     // ---- 2. histogram; arrival slot (+ `exact` in bit 15), bucket and r16 parked in the pos / lo / hi rows
 #pragma unroll 2
     for (int i = t; i < G; i += 1024) {
-        const uint64_t k = Codec<T>::enc(col[i]);
+        const uint64_t k = Codec<T>::enc(col[i], static_cast<uint32_t>(i));
         uint32_t b, r; bool ex;
         locate(k, b, r, ex);
         uint32_t arrival;   // (inside the bucket: below 65 536)
@@ -700,7 +723,8 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
         uint32_t n = 0;
         auto same = [&](uint32_t q) -> uint32_t {   // a member with cq's 16 offset bits: equal when the bucket is narrower than 2^16 codes, else the whole key decides
             if (exact) return le ? 1u : 0u;
-            const uint64_t k = Codec<T>::enc(col[gene_at(q)]);
+            const uint32_t gq = gene_at(q);
+            const uint64_t k = Codec<T>::enc(col[gq], gq);
             return (k < cq || (le && k == cq)) ? 1u : 0u;
         };
         uint32_t q = s0;
@@ -730,7 +754,7 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
         const uint32_t b = bw & 0x7FFFu, mr = rem[sl], me = static_cast<uint32_t>(sl);
         const bool exact = (bw & 0x8000u) != 0;
         const T x = col[gene];
-        const uint64_t k = Codec<T>::enc(x);
+        const uint64_t k = Codec<T>::enc(x, gene);
         const uint32_t s0 = HB(b), s1 = HB(b + 1);
         uint32_t l, h, p;
         if (b % PER == SUB) {  // one value: slot order
@@ -746,13 +770,13 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
                 if (r == mr && q != me) {
                     if (exact) { ++equal; before += q < me ? 1u : 0u; }
                     else if (namb < 4) amb[namb++] = q;
-                    else { const uint64_t kq = Codec<T>::enc(col[gene_at(q)]); smaller += kq < k ? 1u : 0u; equal += kq == k ? 1u : 0u; before += (kq == k && q < me) ? 1u : 0u; }
+                    else { const uint32_t gq = gene_at(q); const uint64_t kq = Codec<T>::enc(col[gq], gq); smaller += kq < k ? 1u : 0u; equal += kq == k ? 1u : 0u; before += (kq == k && q < me) ? 1u : 0u; }
                 }
             }
             if (namb) {
                 uint64_t kq[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) kq[u] = u < static_cast<int>(namb) ? Codec<T>::enc(col[gene_at(amb[u])]) : 0ULL;
+                for (int u = 0; u < 4; ++u) { const uint32_t gq = u < static_cast<int>(namb) ? gene_at(amb[u]) : 0u; kq[u] = u < static_cast<int>(namb) ? Codec<T>::enc(col[gq], gq) : 0ULL; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (u < static_cast<int>(namb)) { smaller += kq[u] < k ? 1u : 0u; equal += kq[u] == k ? 1u : 0u; before += (kq[u] == k && amb[u] < me) ? 1u : 0u; }
@@ -760,8 +784,10 @@ __global__ __launch_bounds__(1024) void t_sample_wide(const T *__restrict__ X, i
             l = s0 + smaller; h = l + equal; p = l + before;
         }
         if constexpr (std::is_same<T, double>::value) {  // the band is wider than the equal values: two more rank queries
-            l = rank_of(band_edge_code<false>(x, k), false);
-            h = rank_of(band_edge_code<true>(x, k), true);
+            if (!isinf(x)) {   // (an infinity's code is its own: l = p, h = p + 1 from the scan above -- tied with nothing, :72)
+                l = rank_of(band_edge_code<false>(x, k), false);
+                h = rank_of(band_edge_code<true>(x, k), true);
+            }
         }
         tied |= h - l > 1u;
         os[sl] = static_cast<uint64_t>(gene) | (static_cast<uint64_t>(p) << 16) | (static_cast<uint64_t>(l) << 32) | (static_cast<uint64_t>(h) << 48);
@@ -825,14 +851,14 @@ __global__ __launch_bounds__(1024) void t_sample_big(const T *__restrict__ X, in
     uint32_t *prow = pos + orow, *lrow = lo + orow, *hrow = hi + orow;
     uint64_t *rec = recs + static_cast<size_t>(c) * Gp;
     int32_t *anytie = flags + 1;
-    // ---- 1. the column's maximum, non-finite values; the sample, sorted
+    // ---- 1. the column's maximum, NaNs; the sample, sorted
     uint64_t kmax = 0;
     bool bad = false;
 #pragma unroll 8
     for (int i = t; i < G; i += 1024) {
         const T x = col[i];
-        bad |= !Codec<T>::finite(x);
-        const uint64_t k = Codec<T>::enc(x);
+        bad |= !Codec<T>::ordered(x);
+        const uint64_t k = Codec<T>::enc(x, static_cast<uint32_t>(i));
         kmax = k > kmax ? k : kmax;
     }
 #pragma unroll
@@ -844,7 +870,8 @@ __global__ __launch_bounds__(1024) void t_sample_big(const T *__restrict__ X, in
 #pragma unroll
     for (int w = 0; w < 16; ++w) { const uint64_t b = spl[kSplit1 + w]; kmax = b > kmax ? b : kmax; }
     {
-        uint64_t v = t == kSplit1 - 1 ? kmax : Codec<T>::enc(col[static_cast<int>((static_cast<int64_t>(t) * G) >> 10)]);
+        const int gs = static_cast<int>((static_cast<int64_t>(t) * G) >> 10);
+        uint64_t v = t == kSplit1 - 1 ? kmax : Codec<T>::enc(col[gs], static_cast<uint32_t>(gs));
         for (int k = 2; k <= kSplit1; k <<= 1) {   // bitonic sort, one key per thread
             const bool up = (t & k) == 0;
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -883,7 +910,7 @@ __global__ __launch_bounds__(1024) void t_sample_big(const T *__restrict__ X, in
     // ---- 2. histogram; the arrival slot is parked in the pos row, bucket word and offset bits in the lo row (32-bit rows)
 #pragma unroll 2
     for (int i = t; i < G; i += 1024) {
-        const uint64_t k = Codec<T>::enc(col[i]);
+        const uint64_t k = Codec<T>::enc(col[i], static_cast<uint32_t>(i));
         uint32_t b, r; bool ex;
         locate(k, b, r, ex);
         prow[i] = atomicAdd(&hist[at(b)], 1u);
@@ -931,7 +958,7 @@ __global__ __launch_bounds__(1024) void t_sample_big(const T *__restrict__ X, in
                 if (r < cr) ++n;
                 else if (r == cr) {
                     if (exact) n += le ? 1u : 0u;
-                    else { const uint64_t k = Codec<T>::enc(col[static_cast<uint32_t>(w[u])]); n += (k < cq || (le && k == cq)) ? 1u : 0u; }
+                    else { const uint32_t gq = static_cast<uint32_t>(w[u]); const uint64_t k = Codec<T>::enc(col[gq], gq); n += (k < cq || (le && k == cq)) ? 1u : 0u; }
                 }
             }
         }
@@ -950,7 +977,7 @@ __global__ __launch_bounds__(1024) void t_sample_big(const T *__restrict__ X, in
         const bool need_x = std::is_same<T, double>::value || !exact;
         T x = T(0);
         uint64_t k = 0;
-        if (need_x) { x = col[gene]; k = Codec<T>::enc(x); }
+        if (need_x) { x = col[gene]; k = Codec<T>::enc(x, gene); }
         const uint32_t s0 = HB(b), s1 = HB(b + 1);
         uint32_t l, h, p;
         if (b % PER == SUB) {  // one value: slot order
@@ -969,15 +996,17 @@ __global__ __launch_bounds__(1024) void t_sample_big(const T *__restrict__ X, in
                     smaller += r < mr ? 1u : 0u;
                     if (r == mr && q != me) {
                         if (exact) { ++equal; before += q < me ? 1u : 0u; }
-                        else { const uint64_t kq = Codec<T>::enc(col[static_cast<uint32_t>(wq[u])]); smaller += kq < k ? 1u : 0u; equal += kq == k ? 1u : 0u; before += (kq == k && q < me) ? 1u : 0u; }
+                        else { const uint32_t gq = static_cast<uint32_t>(wq[u]); const uint64_t kq = Codec<T>::enc(col[gq], gq); smaller += kq < k ? 1u : 0u; equal += kq == k ? 1u : 0u; before += (kq == k && q < me) ? 1u : 0u; }
                     }
                 }
             }
             l = s0 + smaller; h = l + equal; p = l + before;
         }
         if constexpr (std::is_same<T, double>::value) {  // the band is wider than the equal values: two more rank queries
-            l = rank_of(band_edge_code<false>(x, k), false);
-            h = rank_of(band_edge_code<true>(x, k), true);
+            if (!isinf(x)) {   // (an infinity's code is its own: l = p, h = p + 1 from the scan above -- tied with nothing, :72)
+                l = rank_of(band_edge_code<false>(x, k), false);
+                h = rank_of(band_edge_code<true>(x, k), true);
+            }
         }
         tied |= h - l > 1u;
         // (the pos / lo rows still hold the parked words of OTHER genes that later slots of this loop do not read any more: phase 3 was
@@ -1274,8 +1303,7 @@ int32_t transform_impl(reo_ctx *c)
             }
             REO_HIP_CHECK(hipEventSynchronize(c->ev_flags));
             if (fl[0]) {
-                set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
-                          "src/RankCompV3.jl:601)");
+                set_error(kNaNMessage);
                 return REO_EINVAL;
             }
             if (c->debug_stamps && wide) {  // diagnostic builds (-DREO_STAMPS): marks of workgroup 0 of t_sample_wide, 10 ns units
@@ -1320,8 +1348,7 @@ int32_t transform_impl(reo_ctx *c)
         REO_HIP_CHECK(hipMemcpyAsync(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost, st));
         REO_HIP_CHECK(hipStreamSynchronize(st));
         if (flags[0]) {
-            set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
-                      "src/RankCompV3.jl:601)");
+            set_error(kNaNMessage);
             return REO_EINVAL;
         }
         c->transform_in_lds = 3;   // (ranked inside one workgroup per sample; rows in L2)
@@ -1380,8 +1407,7 @@ int32_t transform_impl(reo_ctx *c)
     REO_HIP_CHECK(hipMemcpyAsync(flags, d_flags.p, sizeof flags, hipMemcpyDeviceToHost, st));
     REO_HIP_CHECK(hipStreamSynchronize(st));
     if (flags[0]) {
-        set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
-                  "src/RankCompV3.jl:601)");
+        set_error(kNaNMessage);
         return REO_EINVAL;
     }
     return finish(flags[1], false);
@@ -1782,8 +1808,7 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     REO_HIP_CHECK(hipStreamWaitEvent(st, c->ev_rk[1], 0));
     c->transformed = false;
     if (bad_values) {
-        set_error("expression matrix contains NaN or Inf (the reference drops missing rows before this point, "
-                  "src/RankCompV3.jl:601)");
+        set_error(kNaNMessage);
         return REO_EINVAL;
     }
     if (fallback) return REO_OK;   // some sample wants another form of the ranking: run_transform on the resident copy (reo_build_pairs)

@@ -116,3 +116,25 @@ def lu_corner(b: int, n13: int, spg: int = 2, corners: int = 1, n_always: int = 
     inv[perm] = np.arange(G)
     group = np.array(["ctrl"] * spg + ["treat"] * spg, dtype=object)
     return X[perm], group, inv[:corners]
+
+
+def with_infinities(X: np.ndarray, seed: int, kind: str = "log0") -> np.ndarray:
+    """Float64 copy of X with infinities where log-transformed tables have them (is_greater on them: src/RankCompV3.jl:71-77).
+    log0: the smallest values of every sample become -Inf (log(0)), a few entries +Inf;  column: one whole sample -Inf too;
+    group: -Inf in the first half of the samples only;  rows: whole genes -Inf / +Inf."""
+    X = np.array(X, dtype=np.float64)
+    G, S = X.shape
+    h = u64(seed + 21, np.arange(G)[:, None], np.arange(S)[None, :])
+    lowq = np.quantile(X, 0.12, axis=0, keepdims=True)
+    if kind in ("log0", "column", "rows"):
+        X[X <= lowq] = -np.inf
+    elif kind == "group":
+        X[:, : S // 2][(X <= lowq)[:, : S // 2]] = -np.inf
+    X[(h % _U(97)) == _U(0)] = np.inf
+    if kind == "column":
+        X[:, S // 3] = -np.inf
+        X[:, S - 1] = np.inf
+    if kind == "rows":
+        X[(h[:, 0] % _U(23)) == _U(1), :] = -np.inf
+        X[(h[:, 0] % _U(23)) == _U(2), :] = np.inf
+    return X

@@ -15,6 +15,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_slow: a long GPU case (also marked gpu) that runs only with REO_RUN_SLOW=1 in the environment -- "
+                                       "tools/final_r6.sh sets it and logs the full set under profiles/; the plain `-m gpu` run keeps inside "
+                                       "the driver's time limit")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("REO_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="long GPU case: REO_RUN_SLOW=1 runs it (tools/final_r6.sh does)")
+    for item in items:
+        if "gpu_slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -99,7 +99,7 @@ def _two_shard_run(pkg, X, gid, seed, pval_reo, ref0, n_iter, n_conv):
     return results
 
 
-@pytest.mark.parametrize("family", ["t0", "t1"])
+@pytest.mark.parametrize("family", ["t0", pytest.param("t1", marks=pytest.mark.gpu_slow)])
 def test_config4_30000x4000_one_chunk_per_panel(pkg, oracle, family):
     """BASELINE config 4 on one GPU: the geometry with one j-chunk per panel (Q = 1), never reached by the small tests.
     Whole class table (9e8 ordered pairs), tallies, 128 forced passes and the converging run against the oracle."""

@@ -223,9 +223,13 @@ def test_error_paths(pkg):
     with pytest.raises(pkg.DimensionMismatch):  # G < 10: slice of :411 starts at index 0 (BoundsError)
         pkg.identify_degs(X, group, list(range(9)), 0.01, 1.0, 0.05, np.ones(9, bool), 4, 1, device=0)
     Xn = pkg.synth.float_expr(50, 10, 1)
-    Xn[3, 4] = np.nan
-    with pytest.raises(pkg.DimensionMismatch):
+    Xn[3, 4] = np.nan          # refused: every comparison with a NaN is false -- row order, not an ordering (transform.hip, Codec<double>)
+    with pytest.raises(pkg.DimensionMismatch, match="contains NaN"):
         pkg.identify_degs(Xn, group, list(range(50)), 0.01, 1.0, 0.05, np.ones(50, bool), 4, 1, device=0)
+    with pkg.Context(device=0) as ctx:      # matrix first: the call that ranks reports it
+        ctx.set_matrix(Xn)
+        with pytest.raises(pkg.DimensionMismatch, match="contains NaN"):
+            ctx.set_groups((np.arange(10) >= 5).astype(np.int32), 2) or ctx.pair_counts(0, 4, 0, 4)
     with pkg.Context(device=0) as ctx:
         with pytest.raises(pkg.DimensionMismatch):
             ctx.build_pairs(0)  # nothing set
@@ -234,6 +238,69 @@ def test_error_paths(pkg):
             ctx.set_groups([0, 1, 0], 2) or ctx.pair_counts(0, 4, 0, 4)  # 3 labels for 10 columns (:355)
         with pytest.raises(pkg.DimensionMismatch):
             ctx.set_groups([1, 0] * 5, 2)  # ids must follow first appearance
+
+
+@pytest.mark.parametrize("kind", ["log0", "column", "group", "rows"])
+def test_infinities_are_compared_as_the_reference_compares_them(pkg, oracle, kind, monkeypatch):
+    """is_greater on +-Inf (:72-76): equal infinities are neither tied nor greater (abs(Inf - Inf) = NaN), deterministic; an
+    infinity against anything else compares as usual.  log(0) = -Inf tables, a whole sample of -Inf, -Inf in one group only,
+    whole genes infinite: counts, class table, tallies and the run equal to the oracle's literal comparator -- in both orders of
+    calls (matrix first; groups first = the pipelined upload), and as float32-representable data (the narrowed upload)."""
+    G, S, seed = 500, 24, 0x5EED0062
+    X = pkg.synth.with_infinities(pkg.synth.float_expr(G, S, seed), seed, kind)
+    group = pkg.synth.groups(S)
+    gid, lev = pkg.encode_groups(group)
+    ref0 = pkg.synth.ref_mask(G, 150, seed)
+    blocks = [(0, 70, 0, 70), (0, 33, G - 300, G), (G - 37, G, 5, 130), (250, 290, 250, 330)]
+    for form in ("f64", "f32"):
+        Xv = X if form == "f64" else X.astype(np.float32).astype(np.float64)
+        thr = [oracle.threshold(12), oracle.threshold(12)]
+        code = oracle.build_codes(Xv, gid, 2, 0, thr, seed)
+        exp, iters, trace = oracle.identify_degs(Xv, gid, 2, 0.01, 1.0, 0.05, ref0, 8, 1, seed)
+        for order in ("matrix_first", "groups_first"):
+            with pkg.Context(device=0, seed=seed) as ctx:
+                if order == "matrix_first":
+                    ctx.set_matrix(Xv); ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01)
+                else:
+                    ctx.set_groups(gid, 2); ctx.compute_thresholds(0.01); ctx.set_matrix(Xv)
+                for blk in blocks:
+                    gt, eq = ctx.pair_counts(*blk)
+                    egt, eeq = oracle.pair_counts_as_evaluated(Xv, gid, 2, *blk)
+                    assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), (kind, form, order, blk)
+                ctx.build_pairs(0)
+                assert ctx.info()["transform_in_lds"] == 2
+                assert np.array_equal(ctx.get_codes(0, G, 0, G), code), (kind, form, order)
+                assert np.array_equal(ctx.tally(ref0), oracle.tally(code, ref0))
+                res, it, tr = ctx.identify_degs(ref0, 1.0, 0.05, 8, 1)
+                assert it == iters and tr == trace
+                _check_result(res, exp)
+    run = pkg.run_identify_degs(X, group, list(range(G)), 0.01, 1.0, 0.05, ref0, 8, 1, seed=seed, device=0)   # the drop-in call
+    exp, iters, trace = oracle.identify_degs(X, gid, 2, 0.01, 1.0, 0.05, ref0, 8, 1, seed)
+    assert run.iters_run == iters and run.trace == trace
+    _check_result(run.result, exp)
+
+
+@pytest.mark.parametrize("G", [9000, 21000, 30000, 61000, 70000])
+def test_infinities_in_every_form_of_the_float64_ranking(pkg, oracle, G):
+    """The same at the gene counts of every form of the bucket ranking (t_sample_wide <4, true> / <3, true> / <4, false> /
+    <3, false>, t_sample_big): random and corner pair blocks against the oracle; three groups as well (the one-vs-rest counts)."""
+    S, seed = 9, 0x5EED0063 + G
+    X = pkg.synth.with_infinities(pkg.synth.float_expr(G, S, seed), seed, "column")
+    X[G - 1, :] = np.inf; X[0, :] = -np.inf; X[1, :4] = -np.inf          # the first and the last gene: the ends of the code ranges
+    rng = np.random.default_rng(G)
+    inf_rows = np.flatnonzero(np.isinf(X[:, 0]))[:24]
+    blocks = [(0, 24, 0, 48), (G - 24, G, G - 48, G), (G - 24, G, 0, 48), (0, 24, G - 48, G)]
+    for _ in range(3):
+        i0 = int(rng.integers(0, G - 24)); j0 = int(rng.integers(0, G - 48))
+        blocks.append((i0, i0 + 24, j0, j0 + 48))
+    for ng in (2, 3):
+        gid = (np.arange(S) % ng).astype(np.int32)
+        got, info = _counts_blocks(pkg, X, gid, ng, blocks)
+        assert info["transform_in_lds"] == (2 if G <= 65535 else 3)
+        for blk, (gt, eq) in zip(blocks, got):
+            egt, eeq = oracle.pair_counts_as_evaluated(X, gid, ng, *blk)
+            assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), (G, ng, blk)
+    assert len(inf_rows) == 24
 
 
 def test_all_unstable_degenerate_se_zero(pkg, oracle):
@@ -720,13 +787,13 @@ def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
             ctx.compute_thresholds(0.2)                                           # new thresholds drop the table that reo_set_matrix made
             with pytest.raises(pkg.DimensionMismatch):
                 ctx.get_codes(0, 4, 0, 4)
-    # a non-finite value is reported by the call that reads the matrix
+    # a NaN is reported by the call that reads the matrix (infinities are accepted: test_infinities_*)
     if kind == "float":
-        Xn = X.copy(); Xn[G // 2, S - 3] = np.inf
+        Xn = X.copy(); Xn[G // 2, S - 3] = np.nan
         gid, lev = pkg.encode_groups(group)
         with pkg.Context(device=0, seed=seed) as ctx:
             ctx.set_groups(gid, len(lev)); ctx.compute_thresholds(0.01)
-            with pytest.raises(pkg.DimensionMismatch, match="NaN or Inf"):
+            with pytest.raises(pkg.DimensionMismatch, match="contains NaN"):
                 ctx.set_matrix(Xn)
             ctx.set_matrix(X); ctx.build_pairs(0)                                 # the context works again
             assert np.array_equal(ctx.get_codes(0, 64, 0, G), want[0][0][:64])
@@ -1354,7 +1421,8 @@ def test_full_identify_degs_at_65535_genes(pkg, oracle):
     _check_result(run.result, exp)
 
 
-@pytest.mark.parametrize("G,S,family,n_iter", [(70000, 24, "t1", 8), (140000, 16, "t0", 6), (70000, 24, "float", 4), (66000, 24, "big_int", 4)])
+@pytest.mark.parametrize("G,S,family,n_iter", [(70000, 24, "t1", 8), pytest.param(140000, 16, "t0", 6, marks=pytest.mark.gpu_slow),
+                                                     (70000, 24, "float", 4), (66000, 24, "big_int", 4)])
 def test_more_than_65535_genes(pkg, oracle, G, S, family, n_iter, monkeypatch):
     """Above 65 535 genes positions take 17 or 18 bit planes (round 3): 32-bit transform rows, the big plane layout, the
     generated count loop for NB = 17 / 18 at two waves per SIMD, the sorting passes with their splitter tables in dynamic LDS.
@@ -1408,17 +1476,6 @@ def test_gene_count_limits(pkg, oracle, monkeypatch):
     with pkg.Context(device=0, seed=1) as ctx:
         with pytest.raises(pkg.ReoError):
             ctx.set_matrix(np.zeros((262144, 2), dtype=np.int64))
-    # the largest gene count, ranked by t_sample_big (counts with many repeated values, then Float64): sampled counts against the oracle
-    Gm, Sm = 262143, 4
-    for Xm in (rng.integers(0, 3000, size=(Gm, Sm)), np.round(rng.normal(8, 2, size=(Gm, Sm)), 3)):
-        with pkg.Context(device=0, seed=1) as ctx:
-            ctx.set_matrix(Xm); ctx.set_groups([0, 1, 0, 1], 2)
-            for (i0, i1, j0, j1) in ((0, 32, Gm - 64, Gm), (Gm - 32, Gm, 0, 64), (131000, 131032, 200000, 200064)):
-                gt, eq = ctx.pair_counts(i0, i1, j0, j1)
-                egt, eeq = oracle.pair_counts(Xm.astype(np.float64), np.array([0, 1, 0, 1], dtype=np.int32), 2, i0, i1, j0, j1)
-                assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), (Xm.dtype, i0, j0)
-            assert ctx.info()["transform_in_lds"] == 3
-    pkg._ffi.trim_memory()   # (a 34 GB class table went back to the block cache: return it to the driver)
     G, S, seed = 66000, 9, 0x5EED0067
     X = rng.integers(0, 1000, size=(G, S))
     gid = np.array([0, 1, 2, 0, 1, 2, 0, 1, 2], dtype=np.int32)
@@ -1434,6 +1491,23 @@ def test_gene_count_limits(pkg, oracle, monkeypatch):
                 for (i0, j0, n) in [(0, G - 40, 40), (65520, 65520, 40), (100, 65530, 32), (G - 33, 17, 32)]:
                     exp = _expected_block_codes(oracle, Xf, gid, thr, seed, i0, i0 + n, j0, j0 + n, ngroups=3, k=k)
                     assert np.array_equal(ctx.get_codes(i0, i0 + n, j0, j0 + n), exp), (share, k, i0, j0)
+
+
+@pytest.mark.gpu_slow
+def test_largest_gene_count_262143(pkg, oracle):
+    """The largest gene count, ranked by t_sample_big (counts with many repeated values, then Float64): sampled counts against the
+    oracle.  (A 34 GB class table's worth of allocations: a long case, REO_RUN_SLOW=1.)"""
+    rng = np.random.default_rng(1)
+    Gm, Sm = 262143, 4
+    for Xm in (rng.integers(0, 3000, size=(Gm, Sm)), np.round(rng.normal(8, 2, size=(Gm, Sm)), 3)):
+        with pkg.Context(device=0, seed=1) as ctx:
+            ctx.set_matrix(Xm); ctx.set_groups([0, 1, 0, 1], 2)
+            for (i0, i1, j0, j1) in ((0, 32, Gm - 64, Gm), (Gm - 32, Gm, 0, 64), (131000, 131032, 200000, 200064)):
+                gt, eq = ctx.pair_counts(i0, i1, j0, j1)
+                egt, eeq = oracle.pair_counts(Xm.astype(np.float64), np.array([0, 1, 0, 1], dtype=np.int32), 2, i0, i1, j0, j1)
+                assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), (Xm.dtype, i0, j0)
+            assert ctx.info()["transform_in_lds"] == 3
+    pkg._ffi.trim_memory()   # (a 34 GB class table went back to the block cache: return it to the driver)
 
 
 @pytest.mark.parametrize("case", ["two_samples", "one_vs_nine", "empty_ref", "full_ref", "g11", "constant", "one_group_all_ties"])

@@ -184,6 +184,36 @@ def test_tuned_cpu_variant_equals_the_reference_faithful_restatement(oracle, kin
         assert np.array_equal(got, exp, equal_nan=True)
 
 
+@pytest.mark.parametrize("kind", ["log0", "column", "group", "rows"])
+def test_infinities_in_the_three_restatements(oracle, rn, pkg, kind):
+    """is_greater(-Inf, -Inf): abs(NaN) < 0.1 is false, -Inf > -Inf is false (src/RankCompV3.jl:72-76): equal infinities are
+    neither tied nor greater, no coin; the pair (i, j), i < j, is "i not greater".  The literal comparator (reo_oracle.c, numpy)
+    and the rank-space variant (reo_tuned.c: equal infinities in gene order, a band of the gene alone) agree."""
+    G, S, seed = 260, 14, 0x5EED0061
+    X = pkg.synth.with_infinities(pkg.synth.float_expr(G, S, seed), seed, kind)
+    assert np.isinf(X).mean() > 0.05
+    gid, lev = pkg.encode_groups(pkg.synth.groups(S))
+    thr = [oracle.threshold(7, 0.05), oracle.threshold(7, 0.05)]
+    code = oracle.build_codes(X, gid, 2, 0, thr, seed)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(code, rn.build_codes(X, gid, 2, 0, thr, seed))
+    T = oracle.tuned_build_table(X, gid, 2, 0.05, seed)
+    assert np.array_equal(oracle.tuned_decode(T, 0, G, 0, G), code)
+    # two genes that are -Inf in every sample: never tied, the earlier one never greater -> class (1, 1) = "i < j stable" in both groups
+    both = np.flatnonzero(np.isneginf(X).all(axis=1))
+    if kind == "rows":
+        assert len(both) >= 2 and code[both[0], both[1]] == 0 and code[both[1], both[0]] == 8
+    gt, eq = oracle.pair_counts(X, gid, 2, 0, G, 0, G)
+    egt, eeq = oracle.pair_counts_as_evaluated(X, gid, 2, 0, G, 0, G)
+    up = np.triu(np.ones((G, G), bool), 1)
+    assert np.array_equal(gt[up], egt[up]) and np.array_equal(eq[up], eeq[up])
+    assert (gt[~up] != egt[~up]).any()     # (j, i) by the mirror rule differs from the comparator on the ordered pair: equal infinities
+    ref0 = pkg.synth.ref_mask(G, 90, seed)
+    exp, eit, etr = oracle.identify_degs(X, gid, 2, 0.05, 1.0, 0.05, ref0, 6, 1, seed)
+    got, it, tr = oracle.tuned_identify_degs(X, gid, 2, 0.05, 1.0, 0.05, ref0, 6, 1, seed)
+    assert it == eit and tr == etr and np.array_equal(got, exp, equal_nan=True)
+
+
 def test_tuned_table_functions_agree_with_the_plain_oracle(oracle, pkg):
     """tuned_build_table / tuned_decode / tuned_iterate (what the config-4 GPU test compares with) == reo_oracle.c."""
     G, S, seed = 700, 44, 0x5EED0071

@@ -18,7 +18,7 @@ def case():
     G = int(rng.choice([rng.integers(1000, 20481), rng.integers(20481, 32769), rng.integers(32769, 41473), rng.integers(41473, 58369), rng.integers(58369, 65536), 65535]))
     if BIG: G = int(rng.choice([65536, rng.integers(65536, 90000), rng.integers(90000, 180000), rng.integers(180000, 262144), 262143]))
     S = int(rng.integers(6, 15)) if not BIG else int(rng.integers(2, 7))
-    kind = str(rng.choice(["ranks", "small_int", "tail", "wide_int", "big_int", "float_expr", "float_band", "float_cont", "float_zeros"]))
+    kind = str(rng.choice(["ranks", "small_int", "tail", "wide_int", "big_int", "float_expr", "float_band", "float_cont", "float_zeros", "infinities"]))
     if kind == "ranks": X = np.argsort(np.argsort(rng.random((G, S)), axis=0), axis=0)
     elif kind == "small_int": X = rng.integers(0, int(rng.integers(2, 40)), size=(G, S))
     elif kind == "tail":
@@ -28,6 +28,13 @@ def case():
     elif kind == "big_int": X = rng.integers(0, 2 ** 40, size=(G, S))
     elif kind == "float_expr": X = np.log2(1.0 + np.floor(np.exp(rng.normal(2.0, 2.0, size=(G, S))))) + rng.uniform(0, 0.05, (G, S))
     elif kind == "float_band": X = np.round(rng.normal(5, 1.0, size=(G, S)), 1) + rng.choice([0.0, 0.04, 0.099, 0.1], size=(G, S))
+    elif kind == "infinities":   # log(0) = -Inf where counts are zero, a few +Inf, sometimes whole samples / whole genes (is_greater on them: :72-76)
+        cnt = np.floor(np.exp(rng.normal(1.0, 2.0, size=(G, S))))
+        with np.errstate(divide="ignore"): X = np.log2(cnt) + np.where(cnt > 0, rng.uniform(0, 0.05, (G, S)), 0.0)
+        X[rng.random((G, S)) < float(rng.choice([0.0, 0.001, 0.05]))] = np.inf
+        if rng.random() < 0.3: X[:, int(rng.integers(0, S))] = -np.inf if rng.random() < 0.5 else np.inf
+        if rng.random() < 0.3: X[rng.random(G) < 0.01, :] = -np.inf
+        if rng.random() < 0.3: X[[0, G - 1], :] = rng.choice([-np.inf, np.inf], size=(2, 1))
     elif kind == "float_zeros": X = np.where(rng.random((G, S)) < 0.5, 0.0, rng.lognormal(1.0, 1.0, (G, S)))
     else: X = rng.normal(0, 3, size=(G, S))
     return G, S, kind, X
@@ -47,7 +54,7 @@ for n in range(N):
         form = ctx.info()["transform_in_lds"]
     Xf = np.asarray(X, dtype=np.float64)
     for blk, (gt, eq) in zip(blocks, out):
-        egt, eeq = oracle.pair_counts(Xf, gid, 2, *blk)
+        egt, eeq = (oracle.pair_counts_as_evaluated if kind == "infinities" else oracle.pair_counts)(Xf, gid, 2, *blk)
         assert np.array_equal(gt, egt) and np.array_equal(eq, eeq), (n, kind, G, S, blk, form)
     forms[(kind, form)] = forms.get((kind, form), 0) + 1
     if n % 10 == 9: print("case %d ok (%.0f s)" % (n + 1, time.time() - t0), flush=True)
