@@ -139,6 +139,34 @@ def main() -> None:
 
     pkg = ge.load_pkg()
     G, S, seed = args.genes, args.samples, 0x5EED0003
+    watch = None
+    if world > 1:
+        # a rank that fails between two collectives must not turn into a launcher timeout: its message reaches rank 0 through the
+        # rendezvous store, rank 0 prints the line with an `error` field and every rank exits non-zero (dist.RankWatch)
+        def peer_failed(r, msg):
+            if rank == 0:
+                print(json.dumps({"metric": "gene-pair·sample comparisons/sec at 20k genes × 1k samples", "value": None, "n_gpus": world,
+                                  "error": f"rank {r} failed: {msg}", "failed_rank": r}), flush=True)
+        watch = pkg.dist.RankWatch(dist.distributed_c10d._get_default_store(), rank, world, on_peer_failure=peer_failed)
+    try:
+        run(args, pkg, torch, dist, rank, world, local, dev, force_comm, _StdoutToStderr, G, S, seed)
+    except BaseException as e:
+        if isinstance(e, SystemExit):   # (exit 3, the sharded table differs from the unsharded one: every rank leaves together, rank 0 has printed its line)
+            raise
+        if watch is not None:
+            if rank == 0:
+                print(json.dumps({"metric": "gene-pair·sample comparisons/sec at 20k genes × 1k samples", "value": None, "n_gpus": world,
+                                  "error": f"rank 0 failed: {e!r}", "failed_rank": 0}), flush=True)
+            watch.report(repr(e))
+        raise
+    finally:
+        if watch is not None:
+            watch.stop()
+
+
+def run(args, pkg, torch, dist, rank, world, local, dev, force_comm, _StdoutToStderr, G, S, seed):
+    if os.environ.get("REO_BENCH_FAIL_RANK") == str(rank):   # rehearsal of the failure path (tests, tools/final_r6.sh)
+        raise RuntimeError("REO_BENCH_FAIL_RANK: a failure injected on this rank before its first collective")
     group = pkg.synth.groups(S)
     gid, lev = pkg.encode_groups(group)
     ref0 = pkg.synth.ref_mask(G, 3000, seed)              # ref_gene_max = 3000
@@ -402,6 +430,9 @@ def main() -> None:
         pr4 = per_rank(tm4, info4, st4)
         if pr4:
             out["config4"]["ranks"] = pr4
+            out["config4"]["replicated_stage_share"] = (tm4["transform_ms"] + tm4["iter_ms"]) / st4 / (dt4 / st4 * 1e3)   # transform + passes: the same on every rank
+            if "cycle_watch" in out["config4"]:
+                out["config4"]["cycle_watch"]["replicated_stage_share"] = (tmw4["transform_ms"] + tmw4["iter_ms"]) / st4 / (dtw4 / st4 * 1e3)
 
     if not args.no_from_host and world == 1 and args.family == "t0" and (G, S) == (20000, 1000):
         # The DROP-IN call: what julia/RankCompV3HIP.jl (and tests/abi/abi_client.c) does at :652 -- the matrix is a pageable

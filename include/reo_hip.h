@@ -273,7 +273,10 @@ int32_t reo_get_timings(reo_ctx *ctx, double *ms, int32_t n);
  * were then skipped instead of executed (see reo_identify_degs; REO_CYCLE=0 switches the watch off), 19 the bytes that the last
  * reo_set_matrix_i64 / _f64 put on the PCIe link (chunks whose values all fit travel as int16 / int32 -- Float64 chunks of
  * integer-valued or single-precision numbers too, as int16 / int32 / float32 -- converted by REO_UPLOAD_THREADS host threads,
- * default 12, and widened on the device: bit-exact; 0 threads = the caller's array as it is). */
+ * default 12, and widened on the device: bit-exact; 0 threads = the caller's array as it is), 20 the launches of the pair kernel that
+ * the last pipelined reo_set_matrix_* made over a RANGE of a group's sample blocks (the pair kernel then starts before the whole group
+ * has arrived; the counts of a range wait in HBM for the group's last range, which classifies -- REO_EAGER_RANGES=1 in the environment
+ * launches whole sides only, as in round 5; 2..6 asks for that many ranges per side; default: by the number of blocks). */
 int32_t reo_get_info(reo_ctx *ctx, int64_t *info, int32_t n);
 
 #ifdef __cplusplus

@@ -8,6 +8,12 @@ module RankCompV3HIP
 
 const LIB = get(ENV, "LIBREO_HIP", "libreo_hip")
 
+# The library keeps the device and pinned blocks of destroyed contexts in a process-wide cache (a context per call then costs nothing:
+# include/reo_hip.h, reo_trim_memory; REO_DEVICE_CACHE_MB bounds it).  Other allocators of the process (AMDGPU.jl) cannot see that
+# memory: `trim()` hands it back to the driver -- call it when the last identify_degs of a session is done; it also runs at exit.
+trim() = (ccall((:reo_trim_memory, LIB), Int32, ()); nothing)
+__init__() = atexit(trim)
+
 function check(rc::Int32)
     rc == 0 && return
     msg = unsafe_string(ccall((:reo_last_error, LIB), Cstring, ()))

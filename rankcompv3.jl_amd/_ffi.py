@@ -132,7 +132,8 @@ def check(status: int) -> None:
 
 
 def trim_memory() -> None:
-    """reo_trim_memory: give the cached device and pinned blocks of destroyed contexts back to the driver."""
+    """reo_trim_memory: give the cached device and pinned blocks of destroyed contexts back to the driver (other allocators of the
+    process -- PyTorch's -- cannot see what the library's block cache holds; REO_DEVICE_CACHE_MB bounds it)."""
     check(lib().reo_trim_memory())
 
 
@@ -364,10 +365,11 @@ class Context:
                 "k2_full_launches": int(ms[9]), "k2_delta_ms": ms[10], "set_matrix_host_wall_ms": ms[11]}
 
     def info(self) -> dict:
-        v = np.zeros(20, dtype=np.int64)
-        check(self._L.reo_get_info(self._h, _ptr(v), 20))
+        v = np.zeros(21, dtype=np.int64)
+        check(self._L.reo_get_info(self._h, _ptr(v), 21))
         return {"G": int(v[0]), "S": int(v[1]), "Gp": int(v[2]), "table_bytes": int(v[3]), "has_ties": int(v[4]),
                 "tiles_owned": int(v[5]), "tiles_total": int(v[6]), "tile_i": int(v[7]), "chunk_j": int(v[8]),
                 "chunks_per_panel": int(v[9]), "unit_h": int(v[10]), "sample_slots": int(v[11]),
                 "shared_group_counts": int(v[12]), "group_count_bytes": int(v[13]), "transform_in_lds": int(v[14]), "xcc_local_histograms": int(v[15]),
-                "cycle_period": int(v[16]), "cycle_found_at_pass": int(v[17]), "cycle_passes_skipped": int(v[18]), "upload_link_bytes": int(v[19])}
+                "cycle_period": int(v[16]), "cycle_found_at_pass": int(v[17]), "cycle_passes_skipped": int(v[18]), "upload_link_bytes": int(v[19]),
+                "eager_range_launches": int(v[20])}

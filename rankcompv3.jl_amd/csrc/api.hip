@@ -16,6 +16,7 @@
 #include "reo_internal.h"
 
 #include <mutex>
+#include <unordered_map>
 
 namespace reo {
 
@@ -28,6 +29,9 @@ struct Block { void *p; size_t bytes; int device; bool pinned; };
 struct Pool {
     std::mutex mu;
     std::vector<Block> free_blocks;   // oldest first
+    std::unordered_map<void *, size_t> live;   // blocks handed out -> their TRUE size (a cached block may be a quarter larger than the
+                                               // request it serves: what comes back is booked with the size it has, so that `cached`
+                                               // is what the cache holds and REO_DEVICE_CACHE_MB a real bound)
     size_t cached = 0, cap = size_t(16384) << 20;
     bool read_env = false;
 };
@@ -126,6 +130,7 @@ hipError_t pool_alloc(void **out, size_t bytes, bool pinned)
         if (best >= 0) {
             *out = P.free_blocks[best].p;
             P.cached -= P.free_blocks[best].bytes;
+            P.live[*out] = P.free_blocks[best].bytes;
             P.free_blocks.erase(P.free_blocks.begin() + best);
             return hipSuccess;
         }
@@ -136,6 +141,7 @@ hipError_t pool_alloc(void **out, size_t bytes, bool pinned)
         (void)reo_trim_memory();
         e = raw_alloc(out, bytes, pinned);
     }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(P.mu); P.live[*out] = bytes; }
     return e;
 }
 
@@ -149,6 +155,8 @@ void pool_free(void *p, size_t bytes, bool pinned)
     std::vector<Block> evict;
     {
         std::lock_guard<std::mutex> lk(P.mu);
+        const auto it = P.live.find(p);
+        if (it != P.live.end()) { bytes = it->second; P.live.erase(it); }   // the block's own size, not the size of the request it served
         if (bytes > P.cap) { evict.push_back({p, bytes, dev, pinned}); }
         else {
             P.free_blocks.push_back({p, bytes, dev, pinned});
@@ -615,6 +623,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     if (const char *e = getenv("REO_EAGER_UPLOAD")) c->eager_mode = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("REO_EAGER_CHUNK")) c->eager_chunk = std::max(1, atoi(e));
     if (const char *e = getenv("REO_EAGER_GATE")) c->eager_gate = atoi(e) != 0;
+    if (const char *e = getenv("REO_EAGER_RANGES")) c->eager_ranges = std::max(1, std::min(6, atoi(e)));
     if (const char *e = getenv("REO_UPLOAD_THREADS")) c->upload_threads = std::max(0, std::min(64, atoi(e)));
     c->debug_passes = getenv("REO_DEBUG_PASSES") != nullptr;
     c->debug_stamps = getenv("REO_DEBUG_STAMPS") != nullptr;
@@ -1197,12 +1206,12 @@ int32_t reo_get_timings(reo_ctx *c, double *ms, int32_t n)
 int32_t reo_get_info(reo_ctx *c, int64_t *info, int32_t n)
 {
     if (!c || !info) { set_error("null argument"); return REO_EINVAL; }
-    const int64_t v[20] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
+    const int64_t v[21] = {c->G, c->S, c->Gp, static_cast<int64_t>(c->table.n * sizeof(uint32_t)), c->has_ties,
                            c->tiles_owned, c->tiles_total, kTileI, c->k1_cj, c->k1_q, kUnitH,
                            c->goff32.empty() ? 0 : c->goff32.back(), c->last_k1_shared,
                            static_cast<int64_t>(c->gcounts.n * sizeof(uint16_t)), c->transform_in_lds, c->xcc_local,
-                           c->it_cycle_period, c->it_cycle_at, c->it_cycle_skipped, c->narrowed_bytes};
-    for (int i = 0; i < n && i < 20; ++i) info[i] = v[i];
+                           c->it_cycle_period, c->it_cycle_at, c->it_cycle_skipped, c->narrowed_bytes, c->eager_range_launches};
+    for (int i = 0; i < n && i < 21; ++i) info[i] = v[i];
     return REO_OK;
 }
 

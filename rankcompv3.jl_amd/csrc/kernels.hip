@@ -263,7 +263,15 @@ struct K1Args {
     const int32_t *gate;         // pipelined upload: the transform's flags (0 NaN in the input, 1 some tie so far, 4 / 5 another form of the
                                  // ranking is needed), read by k1w_pairs_gated, which picks the tie form itself -- the host need not wait
                                  // for the flags before it launches a side.  Else null.
+    // RANGE ITEMS (round 6; k1w_pairs, two groups): a launch may cover a RANGE of its side's sample blocks (cb..ce / tb..te are then that
+    // range), so that the pair kernel starts before a whole group has arrived (transform.hip, eager_upload).  The counts of a range wait
+    // for the next one in `park` -- slot blockIdx.x (the launches of a side share ONE item list): kParkSlot words = the four genes' packed
+    // 16-bit count registers lane by lane, n_gt then n_ge -- and only the launch of the side's LAST range classifies.
+    uint32_t *park;              // [items][kParkSlot], or null
+    int32_t *park_ge;            // [items]: the slot's n_ge half is valid (the tie form stored it; else n_ge = n_gt: no tie in those samples)
+    int park_mode;               // bit 0: add the parked counts of the blocks before this range; bit 1: park the sums instead of classifying
 };
+constexpr size_t kParkSlot = 2 * 64 * 64;   // words per item: 64 count registers x 64 lanes, twice (32 KB)
 
 // true when every gene j of the wave (64 RJ consecutive genes from jw) is padding (>= G) or lies in a 64-gene
 // block left of the tile's block: such pairs are never emitted (emit_side)
@@ -535,6 +543,39 @@ __device__ __forceinline__ void k1w_item(const K1Args &a, uint4 *ring, int i0, i
         for (int h = 0; h < ((TIES && !PARK_REGS) ? RJ * (RI / 2) : 1); ++h) park[h] = 0;
     }
     if (a.stamps) t_emit = __builtin_amdgcn_s_memrealtime();
+    if (a.park_mode) {   // (wave-uniform) range items: the counts of the side's earlier sample blocks come in, or these go out
+        constexpr int W4 = RI / 8;   // uint4 per gene and lane
+        uint4 *slot = reinterpret_cast<uint4 *>(a.park + static_cast<size_t>(blockIdx.x) * kParkSlot) + lane;   // [gene c][q][64 lanes]
+        auto add4 = [&](Counts &v, const uint4 *p) {
+#pragma unroll
+            for (int q = 0; q < W4; ++q) { const uint4 w = p[q * 64]; v[4 * q] += w.x; v[4 * q + 1] += w.y; v[4 * q + 2] += w.z; v[4 * q + 3] += w.w; }   // (no carry between the halves: a count is at most S < 65 536)
+        };
+        auto put4 = [&](const Counts &v, uint4 *p) {
+#pragma unroll
+            for (int q = 0; q < W4; ++q) p[q * 64] = uint4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        };
+        if (a.park_mode & 1) {
+            // n_ge of the earlier blocks: parked by the tie form, or equal to their n_gt (the tie-free form ran: no tie in those samples)
+            const uint4 *ge_from = slot + ((TIES && __builtin_amdgcn_readfirstlane(a.park_ge[blockIdx.x])) ? 4 * W4 * 64 : 0);
+            if constexpr (TIES && PARK_REGS) { add4(ge0, ge_from); add4(ge1, ge_from + W4 * 64); add4(ge2, ge_from + 2 * W4 * 64); add4(ge3, ge_from + 3 * W4 * 64); }
+            else if constexpr (TIES) {   // (n_ge waits in the private segment: a real loop, one line at a time -- unrolled it took 64 more registers)
+#pragma clang loop unroll(disable)
+                for (int cq = 0; cq < 4 * W4; ++cq) { const uint4 w = ge_from[cq * 64]; park[4 * cq] += w.x; park[4 * cq + 1] += w.y; park[4 * cq + 2] += w.z; park[4 * cq + 3] += w.w; }
+            }
+            add4(gt0, slot); add4(gt1, slot + W4 * 64); add4(gt2, slot + 2 * W4 * 64); add4(gt3, slot + 3 * W4 * 64);
+        }
+        if (a.park_mode & 2) {
+            put4(gt0, slot); put4(gt1, slot + W4 * 64); put4(gt2, slot + 2 * W4 * 64); put4(gt3, slot + 3 * W4 * 64);
+            if constexpr (TIES && PARK_REGS) { uint4 *ge_to = slot + 4 * W4 * 64; put4(ge0, ge_to); put4(ge1, ge_to + W4 * 64); put4(ge2, ge_to + 2 * W4 * 64); put4(ge3, ge_to + 3 * W4 * 64); }
+            else if constexpr (TIES) {
+                uint4 *ge_to = slot + 4 * W4 * 64;
+#pragma clang loop unroll(disable)
+                for (int cq = 0; cq < 4 * W4; ++cq) ge_to[cq * 64] = uint4{park[4 * cq], park[4 * cq + 1], park[4 * cq + 2], park[4 * cq + 3]};
+            }
+            if (lane == 0) a.park_ge[blockIdx.x] = TIES ? 1 : 0;
+            return;   // the side's last range classifies
+        }
+    }
     const int g = side ? a.gt : a.gc;
     const int m = side ? a.m2 : a.m1, n = side ? a.nt : a.nc;
     // the four genes one after the other in a real loop (the count registers rotate): a quarter of the code of the
@@ -3677,7 +3718,7 @@ static int32_t exchange_args(reo_ctx *c, XArgs &a, int m0, int mcnt);
 // sides (wave form, two groups): which sides' items are launched -- bit 0 the comparison's own group, bit 1 the rest; 3 = the whole
 // table.  keep_table: the class table has been cleared by the caller and holds other sides' planes already (the pipelined upload,
 // transform.hip eager_upload, launches a side as soon as its group's samples are ranked).
-int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *gate)
+int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *gate, const K1Range *range, bool prepare)
 {
     K1Args a;
     a.P = c->pos.p; a.AL = c->lo.p; a.AH = c->hi.p; a.table = c->table.p;
@@ -3753,6 +3794,8 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *
     }
     a.unit_map = c->unit_map.p;
     a.items = nullptr; a.stamps = nullptr; a.gate = gate;
+    a.park = nullptr; a.park_ge = nullptr; a.park_mode = 0;
+    if ((range || prepare) && (sides != 1 && sides != 2)) { set_error("a range of sample blocks / a prepared launch: one side of the pair kernel"); return REO_EINVAL; }
     if (gate && (!wave || wide || big)) { set_error("a gated launch of the pair kernel: wave form, at most 65535 genes and samples"); return REO_EINVAL; }
     const unsigned grid = static_cast<unsigned>((units.size() + 7) / 8 * 8 * kUnitH * Q);   // (workgroup forms)
     // item list of the wave form for a set of units: the units in order, side-major, i-tile-major, wave chunks fastest; kept
@@ -3970,6 +4013,22 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *
         if ((rc = item_list(units, il, 0, 1))) return rc;
         if (c->debug_passes) fprintf(stderr, "  launch_k1 sides %d: item list (%zu items) ready after %.0f us\n", sides, il.n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count());
         a.items = il.buf.p; c->k1_items_n = il.n;
+        if (prepare) return REO_OK;   // (the unit map and this side's item list are on the device; nothing is launched)
+        if (range) {
+            // the item list above is the side's (its key holds the side's WHOLE block count): every range of the side runs the same
+            // items, so blockIdx.x names the same (tile, chunk) in each and the park slots line up
+            const int side = sides == 1 ? 0 : 1, sb = side ? a.tb : a.cb, se = side ? a.te : a.ce;
+            if (range->b0 < 0 || range->b1 <= range->b0 || sb + range->b1 > se || (range->first != (range->b0 == 0)) || (range->last != (sb + range->b1 == se))) {
+                set_error("a range of sample blocks outside its side"); return REO_EINVAL;
+            }
+            if (!(range->first && range->last)) {
+                if ((rc = c->k1_park[side].ensure(std::max<size_t>(il.n, 1) * kParkSlot)) || (rc = c->k1_park_ge[side].ensure(std::max<size_t>(il.n, 1)))) return rc;
+                a.park = c->k1_park[side].p; a.park_ge = c->k1_park_ge[side].p;
+                a.park_mode = (range->first ? 0 : 1) | (range->last ? 0 : 2);
+            }
+            (side ? a.tb : a.cb) = sb + range->b0;
+            (side ? a.te : a.ce) = sb + range->b1;
+        }
         if (c->k1_stamps) REO_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&a.stamps), (std::max<size_t>(c->k1_items_n, 1) * 4 + 2) * sizeof(unsigned long long)));
     }
     // (every reader of the table -- the passes, the pack, a sum hook's element count, the scan of a hook's table -- works on

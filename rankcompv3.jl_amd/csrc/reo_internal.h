@@ -270,6 +270,10 @@ struct reo_ctx {
     hipEvent_t ev_fork = nullptr, ev_k1[8] = {nullptr}, ev_k1_join[2] = {nullptr, nullptr}, ev_x = nullptr;
     struct ItemList { reo::DevBuf<uint32_t> buf; size_t n = 0; uint64_t key[5] = {0, 0, 0, 0, 0}; };
     ItemList k1_wave_items[8];          // the item lists of the waves (kept until the geometry changes)
+    reo::DevBuf<uint32_t> k1_park[2];   // range items of the pipelined upload: parked counts of a side, [items][kParkSlot] (kernels.hip)
+    reo::DevBuf<int32_t> k1_park_ge[2]; // ... and which slots hold n_ge of their own
+    int64_t eager_range_launches = 0;   // launches of the pair kernel that the last pipelined upload made over RANGES of a side's blocks (reo_get_info 20)
+    int eager_ranges = -1;              // REO_EAGER_RANGES: ranges of sample blocks per side in the pipelined upload (1: whole sides, as in round 5; -1: by shape)
     reo::DevBuf<int32_t> check_flag;    // [1] verdict of k_check_table (kernels.hip, launch_check_table)
 
     // iteration state
@@ -339,7 +343,12 @@ int32_t ensure_staging(reo_ctx *c, size_t slot_bytes);                          
 void host_parallel(int nthreads, int ntasks, const std::function<void(int)> &fn);   // fn(0 .. ntasks - 1) on the process-wide pool of host threads (and the caller)
 
 // kernels.hip
-int32_t launch_k1(reo_ctx *c, int k, int sides = 3, bool keep_table = false, const int32_t *gate = nullptr);  // sides: bit 0 = the comparison's own group, bit 1 = the rest (wave form; eager_upload)
+// range: the launch covers sample blocks [b0, b1) of its ONE side (counted from the side's first block); the counts wait in the context's park
+// buffer between the ranges of a side and the launch of the last range classifies (kernels.hip, K1Args::park).  prepare: only make
+// (and upload) the unit map and the item list of `sides` -- the pipelined upload does that before it queues any wait on the stream.
+struct K1Range { int b0, b1; bool first, last; };
+int32_t launch_k1(reo_ctx *c, int k, int sides = 3, bool keep_table = false, const int32_t *gate = nullptr, const K1Range *range = nullptr,
+                  bool prepare = false);  // sides: bit 0 = the comparison's own group, bit 1 = the rest (wave form; eager_upload)
 int64_t exchange_unit_words(const reo_ctx *c);   // uint32 per packed work unit
 int32_t exchange_units_per_rank(const reo_ctx *c);
 int32_t launch_pack_units(reo_ctx *c, int m0 = 0, int mcnt = -1, uint32_t *send = nullptr, hipStream_t st = nullptr);    // this shard's units (all, or slots m0 .. m0 + mcnt - 1) -> c->xsend / send

@@ -1715,6 +1715,13 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     const bool wide = !kCountingPath<T>;
     c->transform_in_lds = 0;
     c->table_prezeroed = false;
+    if (with_k1) {
+        // the pair kernel's unit map and both sides' item lists go up NOW, while the context's stream is still empty: launch_k1 uploads
+        // them with a host wait on that stream, which behind a side's WaitEvent would block the host until that group is ranked (and no
+        // further chunk would be converted or sent meanwhile)
+        for (int side = 0; side < 2; ++side)
+            if ((rc = launch_k1(c, 0, 1 << side, true, nullptr, nullptr, true))) return rc;
+    }
     REO_HIP_CHECK(hipEventRecord(c->ev_rk[0], st));            // (the cleared flags, the lists)
     REO_HIP_CHECK(hipStreamWaitEvent(rk, c->ev_rk[0], 0));
     if (with_k1) {   // the class table is cleared once, in front of everything; the side launches keep what is there
@@ -1735,6 +1742,21 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     if (c->eager_chunk > 0) CH = c->eager_chunk;   // REO_EAGER_CHUNK (experiments)
     std::vector<int> left(c->ngroups);
     for (int g = 0; g < c->ngroups; ++g) left[g] = c->goff[g + 1] - c->goff[g];
+    // RANGE ITEMS (round 6): a side of the pair kernel need not wait for its whole group.  The slots of a group fill in column order, so
+    // after any chunk the group's first (ranked samples / 32) blocks are complete: they are sliced and the side's items are launched over
+    // THAT RANGE of blocks, their counts parked (kernels.hip, K1Args::park) until the launch of the group's last range adds everything up
+    // and classifies.  A range costs every item its fixed part again and 2 x 2 bytes per pair of parking traffic, so there are few: the
+    // first one early (it is what the call's exposed upload time shrinks to), the rest large.
+    std::vector<int> ranked_g(c->ngroups, 0), done_blk(c->ngroups, 0);
+    c->eager_range_launches = 0;
+    const int min_last = c->eager_ranges > 0 ? 1 : 4;   // blocks that must be left for the last range (an explicit REO_EAGER_RANGES: tests cut anywhere)
+    auto range_need = [&](int total_blk, bool first) -> int {   // complete, unlaunched blocks a range waits for (the last range takes what is left)
+        int n = c->eager_ranges;
+        if (n < 0) n = total_blk >= 32 ? 3 : (total_blk >= 12 ? 2 : 1);
+        if (n <= 1 || !with_k1) return total_blk;
+        const int f = std::max(1, total_blk >> (n - 1));                 // first range: 1/2, 1/4, 1/8 ... of the side
+        return first ? f : std::max(1, (total_blk - f + n - 2) / (n - 1));   // the others share the rest
+    };
     int sides_done = 0, ranked = 0, ranked_at_read = -1, nsides_launched = 0;
     bool fallback = false, bad_values = false;
     int32_t *fl = c->host_flags;
@@ -1759,43 +1781,61 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
         const int cbeg = c0;
         c0 += nc;
         if (fallback || bad_values) continue;   // (the rest of the matrix still has to arrive)
-        int ready = 0;   // groups whose last sample is in this chunk: their blocks are complete and can be sliced into bit planes
+        // ranges of blocks that this chunk completes: (group, first block, one past the last, first / last range of the group)
+        struct Ready { int g, b0, b1; bool first, last; };
+        std::vector<Ready> ready;
         {
             OnStream on(c, rk);
             tic(c, 0);
             rc = launch_lds_ranking<T>(c, dX, SampleList{d_cols + cbeg, d_slots + cbeg, nc, nc}, d_flags.p, wide);
             ranked = c0;
-            for (int s = cbeg; s < cbeg + nc && !rc; ++s) {
+            std::vector<int> touched;
+            for (int s = cbeg; s < cbeg + nc; ++s) {
                 const int g = c->group_id[s];
-                if (--left[g] != 0) continue;
-                ready |= 1 << std::min(g, 30);
-                const int b0 = c->goff32[g] / 32, nb = (c->goff32[g + 1] - c->goff32[g]) / 32;
+                ++ranked_g[g]; --left[g];
+                if ((touched.empty() || touched.back() != g) && std::find(touched.begin(), touched.end(), g) == touched.end()) touched.push_back(g);
+            }
+            for (int g : touched) {
+                if (rc) break;
+                const int total_blk = (c->goff32[g + 1] - c->goff32[g]) / 32;
+                const int complete = left[g] == 0 ? total_blk : ranked_g[g] / 32;
+                const bool whole_sides = !(with_k1 && g < 2);
+                const bool last = left[g] == 0;
+                if (!last && (whole_sides || complete - done_blk[g] < range_need(total_blk, done_blk[g] == 0) || total_blk - complete < min_last)) continue;
+                if (complete <= done_blk[g]) continue;   // (a group without samples has no blocks)
+                const int b0 = c->goff32[g] / 32 + done_blk[g], nb = complete - done_blk[g];
                 t_slice<<<dim3(Gp / 512, nb), 256, 0, rk>>>(c->t_pos16.p, c->t_lo16.p, c->t_hi16.p, Gp, c->pos.p, c->lo.p, c->hi.p, b0);
                 if (hipGetLastError() != hipSuccess) { set_error("t_slice launch failed"); rc = REO_EHIP; }
+                ready.push_back(Ready{g, done_blk[g], complete, done_blk[g] == 0, last});
+                done_blk[g] = complete;
             }
             toc(c);
             if (rc) return rc;
         }
-        if (with_k1 && ready) {   // two groups: side 0 counts group 0's samples, side 1 group 1's (k = 0)
-            // The side is launched behind the slicing of its group (an event) as k1w_pairs_gated, which looks at the transform's flags on
-            // the device and takes the tie form they ask for -- "ties seen so far" covers every sample of this side, and the tie-free
-            // loop is exact on a side without ties.  The host does not wait for anything here (it used to read the flags: 70 us of
-            // idle GPU per side, profiles/r5_pipelined_upload_timeline_config4.txt); a flagged sample makes the launch return at once,
-            // and the host finds out at the end.
-            const int mask = ready & 3;
+        for (const Ready &r : ready) {   // two groups: side 0 counts group 0's samples, side 1 group 1's (k = 0)
+            if (!with_k1 || r.g > 1) continue;
+            // The side (or a range of its blocks) is launched behind the slicing of those blocks (an event) as k1w_pairs_gated, which looks
+            // at the transform's flags on the device and takes the tie form they ask for -- "ties seen so far" covers every sample ranked
+            // so far, and the tie-free loop is exact on samples without ties.  The host does not wait for anything here (it used to read
+            // the flags: 70 us of idle GPU per side, profiles/r5_pipelined_upload_timeline_config4.txt); a flagged sample makes the
+            // launch return at once, and the host finds out at the end.
+            const int mask = 1 << r.g;
+            const K1Range range{r.b0, r.b1, r.first, r.last};
+            const K1Range *rp = (r.first && r.last) ? nullptr : &range;
             if (c->eager_gate) {
                 hipEvent_t ev = c->ev_rk[2 + (nsides_launched++ & 1)];
                 REO_HIP_CHECK(hipEventRecord(ev, rk));
                 REO_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
-                if ((rc = launch_k1(c, 0, mask, true, d_flags.p))) return rc;
+                if ((rc = launch_k1(c, 0, mask, true, d_flags.p, rp))) return rc;
             } else {   // REO_EAGER_GATE=0: the host reads the flags and picks the tie form itself (the planes are in place: it has waited for rk)
                 if ((rc = read_flags())) return rc;
-                if (fallback || bad_values) continue;
+                if (fallback || bad_values) break;
                 c->has_ties = fl[1];
-                if ((rc = launch_k1(c, 0, mask, true))) return rc;
+                if ((rc = launch_k1(c, 0, mask, true, nullptr, rp))) return rc;
             }
-            stamp("a side of the pair kernel launched");
-            sides_done |= mask;
+            if (rp) ++c->eager_range_launches;
+            stamp(r.last ? "a side of the pair kernel launched (its last range)" : "a range of a side of the pair kernel launched");
+            if (r.last) sides_done |= mask;
         }
     }
     REO_HIP_CHECK(hipStreamSynchronize(c->up));   // the whole matrix has been read: the caller may have its array back
@@ -1836,16 +1876,23 @@ int32_t ensure_upload_streams(reo_ctx *c)
 int32_t ensure_staging(reo_ctx *c, size_t slot_bytes)
 {
     int32_t rc;
+    if (c->stage_cap < slot_bytes) {
+        // all three pinned slots are renewed together, and the recorded capacity is 0 until all three exist: a failed allocation leaves
+        // no slot behind that a later, smaller request would take for a usable one (and reo_destroy releases every slot with the size
+        // the block cache booked for it)
+        const size_t old_cap = c->stage_cap;
+        c->stage_cap = 0;
+        for (int q = 0; q < 3; ++q)
+            if (c->stage_h[q]) { pool_free(c->stage_h[q], old_cap, true); c->stage_h[q] = nullptr; }
+        for (int q = 0; q < 3; ++q) REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->stage_h[q]), slot_bytes, true));
+        c->stage_cap = slot_bytes;
+    }
     for (int q = 0; q < 3; ++q) {
-        if (c->stage_cap < slot_bytes) {
-            if (c->stage_h[q]) { pool_free(c->stage_h[q], c->stage_cap, true); c->stage_h[q] = nullptr; }
-            REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->stage_h[q]), slot_bytes, true));
-        }
+        if (!c->stage_h[q]) { set_error("a staging slot of the narrowed upload is missing"); return REO_EHIP; }
         if ((rc = c->stage_d[q].ensure(slot_bytes))) return rc;
         if (!c->ev_stage[q]) REO_HIP_CHECK(handle_event(&c->ev_stage[q], 0));
         if (!c->ev_widen[q]) REO_HIP_CHECK(handle_event(&c->ev_widen[q], 0));
     }
-    c->stage_cap = std::max(c->stage_cap, slot_bytes);
     return REO_OK;
 }
 

@@ -127,3 +127,60 @@ def table_trace_digest(ctx, G: int, ref0, n_iter: int = 8, rows_per_call: int = 
     h.update(np.asarray(trace, dtype=np.int64).tobytes())
     h.update(np.ascontiguousarray(res[:, 2:11]).tobytes())
     return h.hexdigest()
+
+
+class RankWatch:
+    """A side channel for FAILURES of a multi-rank run (bench.py --gpus N), beside the collectives.
+
+    A rank that fails between two collectives leaves its peers inside the next one (RCCL and gloo wait for ever), and the launcher
+    then ends the job without rank 0 having printed anything: a timeout is all the caller sees.  With a watch every rank owns one
+    key of the rendezvous store: `report(msg)` sets it (then the failing rank waits `grace` seconds before it exits, so that its
+    peers can act), and a daemon thread on every rank polls the peers' keys; when one appears the thread calls
+    `on_peer_failure(rank, msg)` -- rank 0 prints its JSON line with an `error` field there -- and ends the process with `exit_code`.
+    The store is torch.distributed's own (the TCPStore of the rendezvous); nothing here touches a GPU or a collective."""
+
+    def __init__(self, store, rank: int, world: int, on_peer_failure=None, poll_s: float = 0.2, grace_s: float = 3.0, exit_code: int = 4):
+        import threading
+        self.store, self.rank, self.world = store, rank, world
+        self.on_peer_failure, self.poll_s, self.grace_s, self.exit_code = on_peer_failure, poll_s, grace_s, exit_code
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, name="reo-rank-watch", daemon=True)
+        self._t.start()
+
+    @staticmethod
+    def key(rank: int) -> str:
+        return f"reo_rank_failed_{rank}"
+
+    def _run(self):
+        import os
+        import sys
+        while not self._stop.wait(self.poll_s):
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                try:
+                    if not self.store.check([self.key(r)]):
+                        continue
+                    msg = self.store.get(self.key(r)).decode("utf-8", "replace")
+                except Exception:   # the store went away with rank 0: nothing left to watch
+                    return
+                if self._stop.is_set():
+                    return
+                try:
+                    if self.on_peer_failure:
+                        self.on_peer_failure(r, msg)
+                finally:
+                    sys.stdout.flush(); sys.stderr.flush()
+                    os._exit(self.exit_code)   # the main thread may sit in a collective that will never complete
+
+    def report(self, msg: str) -> None:
+        """This rank has failed: tell the peers, give them time to act."""
+        import time
+        try:
+            self.store.set(self.key(self.rank), msg[:2000])
+        except Exception:
+            return
+        time.sleep(self.grace_s)
+
+    def stop(self) -> None:
+        self._stop.set()

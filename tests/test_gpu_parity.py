@@ -704,7 +704,8 @@ def _eager_ctx(pkg, X, group, seed, pval_reo=0.01):
 
 
 @pytest.mark.parametrize("kind", ["ranks", "counts", "float", "big_int", "three_groups", "interleaved", "unequal", "view_ld", "small",
-                                  "negative", "huge_int", "growing", "float_counts", "float_from_f32", "float_mixed"])
+                                  "negative", "huge_int", "growing", "float_counts", "float_from_f32", "float_mixed",
+                                  "ties_second_group", "flag_second_group", "ties_late_in_first_group"])
 def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
     """reo_set_matrix_i64 / _f64 from host memory with the groups already set (round 5): the columns travel in chunks, samples are
     ranked as they arrive, a group's blocks are sliced when its last sample is in, and (two groups, one GPU, thresholds set) the
@@ -735,6 +736,14 @@ def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
     elif kind == "float_mixed":                                                                                              # the form climbs: int16, int32, float32, the array itself
         X = rng.integers(0, 900, size=(G, S)).astype(np.float64); X[:, 100:] += 70000.0; X[:, 180:] += np.float32(0.25); X[11, 190] = -0.0
         X[:, 250:] = rng.normal(8, 2, size=(G, 50))
+    # what the device-side gate of the side launches (k1w_pairs_gated) has to get right: the transform's flags CHANGE while sides and
+    # ranges of the pair kernel are already queued or running
+    elif kind == "ties_second_group":         # side 0 is launched tie-free; ties appear only in group 2's columns
+        X = pkg.synth.t0_ranks(G, S, seed); X[:, S // 2:] = pkg.synth.t1_counts(G, S, seed)[:, S // 2:]
+    elif kind == "flag_second_group":         # a sample of group 2 needs another form of the ranking: everything is done again at reo_build_pairs
+        X = pkg.synth.t0_ranks(G, S, seed); X[:, S - 20:] = rng.integers(0, 2 ** 31, size=(G, 20))
+    elif kind == "ties_late_in_first_group":  # the first RANGE of side 0 runs tie-free and parks n_gt only; the tie form of its next range takes n_ge = n_gt for those blocks
+        X = pkg.synth.t0_ranks(G, S, seed); X[:, 100:150] = pkg.synth.t1_counts(G, S, seed)[:, 100:150]
     else: G, S = 700, 41; X = pkg.synth.t1_counts(G, S, seed); group = pkg.synth.groups(S)
     ref0 = pkg.synth.ref_mask(G, G // 5, seed)
     ng = len(set(group))
@@ -751,13 +760,19 @@ def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
     want = outputs(_setup(pkg, X, group, seed)[0])
     # (REO_UPLOAD_THREADS: Int64 chunks cross the link as 16- or 32-bit numbers when they fit, converted by that many host threads and
     #  widened on the device; 0 = the caller's array as it is.  REO_EAGER_CHUNK=37: many small chunks, the staging ring goes round.)
-    for mode, threads, chunk in (("2", None, None), ("1", None, None), ("0", None, None), ("2", "0", None), ("2", "3", "37")):
+    # (REO_EAGER_RANGES, round 6: the pair kernel's items of a side run over RANGES of its sample blocks as the chunks arrive, counts
+    #  parked in between, the last range classifies -- 1 = whole sides as in round 5, n = n ranges per side where the blocks allow.)
+    for mode, threads, chunk, ranges in (("2", None, None, None), ("1", None, None, None), ("0", None, None, None), ("2", "0", None, "1"), ("2", "3", "37", "1"),
+                                         ("2", None, "37", "4"), ("2", "3", "64", "2"), ("2", None, "32", "6")):
         monkeypatch.setenv("REO_EAGER_UPLOAD", mode)
-        for name, val in (("REO_UPLOAD_THREADS", threads), ("REO_EAGER_CHUNK", chunk)):
+        for name, val in (("REO_UPLOAD_THREADS", threads), ("REO_EAGER_CHUNK", chunk), ("REO_EAGER_RANGES", ranges)):
             if val is None: monkeypatch.delenv(name, raising=False)
             else: monkeypatch.setenv(name, val)
         ctxe = _eager_ctx(pkg, X, group, seed)
         link = ctxe.info()["upload_link_bytes"]
+        nr = ctxe.info()["eager_range_launches"]
+        if ranges in (None, "1") or ng != 2 or mode != "2" or kind == "small": assert nr == 0, (kind, mode, ranges, nr)    # (default: 5 blocks per side are too few to cut)
+        elif kind not in ("big_int", "flag_second_group"): assert nr >= (2 if kind == "unequal" else 4), (kind, ranges, nr)                           # both sides in at least two ranges (37 samples: one block)
         if mode != "0" and threads != "0" and kind in ("ranks", "negative", "big_int", "float_counts", "float_from_f32"):
             assert link == X.size * (2 if kind in ("ranks", "negative", "float_counts") else 4), (kind, link)     # what the link carried
         elif mode != "0" and threads != "0" and kind in ("counts", "growing", "float_mixed"):
@@ -771,7 +786,7 @@ def test_pipelined_upload_equals_matrix_first(pkg, kind, monkeypatch):
             assert np.array_equal(c0, c1), (kind, mode, "class table")
             assert np.array_equal(t0, t1) and i0 == i1 and tr0 == tr1 and h0 == h1, (kind, mode)
             assert np.array_equal(r0, r1, equal_nan=True), (kind, mode, "statistics")
-    for name in ("REO_EAGER_UPLOAD", "REO_UPLOAD_THREADS", "REO_EAGER_CHUNK"):
+    for name in ("REO_EAGER_UPLOAD", "REO_UPLOAD_THREADS", "REO_EAGER_CHUNK", "REO_EAGER_RANGES"):
         monkeypatch.delenv(name, raising=False)
     # rebuilds on the same context, a second matrix, new thresholds
     if ng == 2:

@@ -196,6 +196,50 @@ def test_gloo_world2_sharded_iteration_matches_unsharded():
     assert got[0][2] == got[1][2] >= 1
 
 
+def _watch_worker(rank, world, port, outdir):
+    """rank 1 fails before its first collective; rank 0 is already inside one (a barrier that will never complete)"""
+    import json
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_pkg()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def peer_failed(r, msg):
+        if rank == 0:
+            with open(os.path.join(outdir, "rank0_line.json"), "w") as f:
+                json.dump({"value": None, "error": f"rank {r} failed: {msg}", "failed_rank": r}, f)
+
+    watch = pkg.dist.RankWatch(dist.distributed_c10d._get_default_store(), rank, world, on_peer_failure=peer_failed, poll_s=0.05, grace_s=1.5)
+    try:
+        if rank == 1:
+            raise RuntimeError("injected failure on rank 1")
+        dist.barrier()          # rank 1 never arrives
+        open(os.path.join(outdir, "rank0_passed_the_barrier"), "w").close()
+    except RuntimeError as e:
+        watch.report(repr(e))
+        os._exit(7)
+
+
+def test_a_failing_rank_surfaces_in_rank_zeros_line_not_as_a_timeout(tmp_path):
+    """bench.py --gpus N (round 6): a rank that fails between two collectives used to leave its peers waiting inside the next one
+    until the launcher's timeout.  dist.RankWatch: the failing rank sets a key in the rendezvous store and waits a grace period;
+    rank 0's watch thread sees it, writes the line with an `error` field and ends the process with a non-zero code."""
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_watch_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+    assert [p.exitcode for p in procs] == [4, 7], [p.exitcode for p in procs]
+    assert not os.path.exists(tmp_path / "rank0_passed_the_barrier")
+    line = json.load(open(tmp_path / "rank0_line.json"))
+    assert line["failed_rank"] == 1 and "injected failure on rank 1" in line["error"] and line["value"] is None
+
+
 def test_mirror_geometry_of_the_three_kernel_forms(pkg):
     """launch_k1's unit geometry depends on which pair kernel it selects (ADVICE, round 2): the wave form (two groups, and the
     shared per-group counts of more than two) uses kRJ genes per lane for both data families, the workgroup form kRJ /

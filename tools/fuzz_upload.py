@@ -24,7 +24,7 @@ def digest(ctx, G, ref0, ng):
     return h.hexdigest()
 
 
-t0 = time.time(); kinds = {}
+t0 = time.time(); kinds = {}; nranges = 0
 for n in range(N):
     G = int(rng.choice([rng.integers(300, 3000), rng.integers(3000, 12000), rng.integers(12000, 40000)]))
     S = int(rng.choice([rng.integers(8, 64), rng.integers(64, 300), rng.integers(300, 700)]))
@@ -55,19 +55,21 @@ for n in range(N):
     gid, lev = pkg.encode_groups(labels)
     ref0 = pkg.synth.ref_mask(G, max(3, G // 5), n)
     pval = float(rng.choice([0.01, 0.05, 0.3]))
-    os.environ.update(REO_EAGER_UPLOAD="0", REO_UPLOAD_THREADS="0"); os.environ.pop("REO_EAGER_CHUNK", None)
+    os.environ.update(REO_EAGER_UPLOAD="0", REO_UPLOAD_THREADS="0"); os.environ.pop("REO_EAGER_CHUNK", None); os.environ.pop("REO_EAGER_RANGES", None)
     with pkg.Context(device=0, seed=n) as ctx:
         ctx.set_matrix(X); ctx.set_groups(gid, len(lev)); ctx.compute_thresholds(pval)
         want = digest(ctx, G, ref0, len(lev))
     os.environ.update(REO_EAGER_UPLOAD=str(rng.choice(["2", "2", "1"])), REO_UPLOAD_THREADS=str(rng.choice(["12", "1", "5", "0"])))
     if rng.random() < 0.5: os.environ["REO_EAGER_CHUNK"] = str(int(rng.integers(1, S + 5)))
-    tag = (n, kind, layout, G, S, ng, os.environ["REO_EAGER_UPLOAD"], os.environ["REO_UPLOAD_THREADS"], os.environ.get("REO_EAGER_CHUNK"))
+    if rng.random() < 0.7: os.environ["REO_EAGER_RANGES"] = str(int(rng.integers(1, 7)))   # (round 6) ranges of sample blocks per side; unset: by shape
+    tag = (n, kind, layout, G, S, ng, os.environ["REO_EAGER_UPLOAD"], os.environ["REO_UPLOAD_THREADS"], os.environ.get("REO_EAGER_CHUNK"), os.environ.get("REO_EAGER_RANGES"))
     with pkg.Context(device=0, seed=n) as ctx:
         ctx.set_groups(gid, len(lev)); ctx.compute_thresholds(pval); ctx.set_matrix(X)
         got = digest(ctx, G, ref0, len(lev))
         assert got == want, tag
+        nranges += ctx.info()["eager_range_launches"]
         ctx.set_matrix(X)                      # the same context again (staging ring, work lists and streams reused)
         assert digest(ctx, G, ref0, len(lev)) == want, tag
     kinds[kind] = kinds.get(kind, 0) + 1
     if n % 20 == 19: print("case %d ok (%.0f s) %s" % (n + 1, time.time() - t0, kinds), flush=True)
-print("fuzz upload ok:", N, "cases", kinds)
+print("fuzz upload ok:", N, "cases", kinds, "launches over ranges of a side:", nranges)
