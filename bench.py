@@ -478,7 +478,14 @@ def run(args, pkg, torch, dist, rank, world, local, dev, force_comm, _StdoutToSt
             call(ctxh)
             pip_w, rpip = timed_walls(lambda: call(ctxh), steps_h)
             link_bytes = ctxh.info()["upload_link_bytes"]
+            range_launches = ctxh.info()["eager_range_launches"]
             ctxh.close()
+            os.environ["REO_EAGER_RANGES"] = "1"                                # round 5's form on the same box: a side of the pair kernel waits for its whole group
+            ctxw = pkg.Context(device=local, seed=seedh)
+            call(ctxw)
+            whole_w, rwhole = timed_walls(lambda: call(ctxw), steps_h)
+            ctxw.close()
+            del os.environ["REO_EAGER_RANGES"]
             def whole_call():                                                  # a context per call, as the Julia shim does it
                 with pkg.Context(device=local, seed=seedh) as c_:
                     return call(c_)
@@ -491,6 +498,8 @@ def run(args, pkg, torch, dist, rank, world, local, dev, force_comm, _StdoutToSt
                     "upload_ms_as_the_library_does_it": med(upn_w),   # (Int64: 16- / 32-bit numbers on the link, widened on the device)
                     "compute_ms_device_resident": compute_ms,
                     "ms_per_step": med(pip_w), "ms_per_step_not_pipelined": med(seq_w), "ms_per_call_with_create_and_destroy": med(all_w),
+                    "ms_per_step_whole_sides_as_in_round_5": med(whole_w), "pair_kernel_launches_over_ranges_of_a_side": range_launches,
+                    "same_result_ranges_and_whole_sides": bool(np.array_equal(rwhole[0], rpip[0], equal_nan=True) and rwhole[2] == rpip[2]),
                     "link_MB": link_bytes / 1e6,
                     "sum_upload_compute_ms": up + compute_ms, "max_upload_compute_ms": max(up, compute_ms),
                     "ratio_to_max": med(pip_w) / max(up, compute_ms), "ratio_to_sum": med(pip_w) / (up + compute_ms),

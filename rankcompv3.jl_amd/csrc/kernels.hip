@@ -3817,7 +3817,8 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *
             struct Stored { uint64_t key[7]; std::vector<uint32_t> units, items; };
             static std::mutex store_mu;
             static std::vector<Stored> *store = new std::vector<Stored>();
-            const uint64_t skey[7] = {key[0], key[1], key[2], key[3], key[4], static_cast<uint64_t>(c->n_cus), static_cast<uint64_t>(big ? 1 : 0) << 1 | static_cast<uint64_t>(wide ? 1 : 0)};
+            const uint64_t skey[7] = {key[0], key[1], key[2], key[3], key[4], static_cast<uint64_t>(c->n_cus),
+                                      static_cast<uint64_t>(c->k1_order) << 2 | static_cast<uint64_t>(big ? 1 : 0) << 1 | static_cast<uint64_t>(wide ? 1 : 0)};
             std::vector<uint32_t> items;
             bool have = false;
             {
@@ -3858,13 +3859,19 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *
                 keys.resize(l.size());
                 for (size_t q = 0; q < l.size(); ++q) {
                     const uint32_t x = l[q], cx = (x >> 16) & 0x7FFFu;
-                    keys[q] = static_cast<uint64_t>((cx >> 3) / static_cast<uint32_t>(per_group)) << 32 | static_cast<uint64_t>(x >> 31) << 31 |
-                              static_cast<uint64_t>(x & 0xFFFFu) << 15 | cx;
+                    if (c->k1_order == 0)
+                        keys[q] = static_cast<uint64_t>((cx >> 3) / static_cast<uint32_t>(per_group)) << 32 | static_cast<uint64_t>(x >> 31) << 31 |
+                                  static_cast<uint64_t>(x & 0xFFFFu) << 15 | cx;
+                    else   // REO_K1_ORDER=1 (experiment, round 6): i-tiles fastest inside a chunk -- the mirror words of a chunk's genes (one 32-bit
+                           // word per i-tile, neighbours in their table rows) then reach L2 one after the other
+                        keys[q] = static_cast<uint64_t>((cx >> 3) / static_cast<uint32_t>(per_group)) << 32 | static_cast<uint64_t>(x >> 31) << 31 |
+                                  static_cast<uint64_t>(cx) << 16 | (x & 0xFFFFu);
                 }
                 std::sort(keys.begin(), keys.end());
                 for (size_t q = 0; q < l.size(); ++q) {
                     const uint64_t k = keys[q];
-                    l[q] = static_cast<uint32_t>((k >> 31) & 1u) << 31 | static_cast<uint32_t>(k & 0x7FFFu) << 16 | static_cast<uint32_t>((k >> 15) & 0xFFFFu);
+                    if (c->k1_order == 0) l[q] = static_cast<uint32_t>((k >> 31) & 1u) << 31 | static_cast<uint32_t>(k & 0x7FFFu) << 16 | static_cast<uint32_t>((k >> 15) & 0xFFFFu);
+                    else l[q] = static_cast<uint32_t>((k >> 31) & 1u) << 31 | static_cast<uint32_t>((k >> 16) & 0x7FFFu) << 16 | static_cast<uint32_t>(k & 0xFFFFu);
                 }
             }
             const size_t per = (total_items + 7) / 8;

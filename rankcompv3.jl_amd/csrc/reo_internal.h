@@ -251,6 +251,7 @@ struct reo_ctx {
     reo::DevBuf<uint16_t> gcounts;      // [ngroups + 1][Gp/32][4][Gp][8]
     bool gc_valid = false;
     int k1_wave = 1;                    // REO_K1_WAVE=0: the workgroup form of the pair kernel (round 2) instead of the wave form
+    int k1_order = 0;                   // REO_K1_ORDER=1 (experiment): the wave form's items i-tile-fastest inside a chunk instead of chunk-fastest inside an i-tile
     int k1_half = 1;                    // REO_K1_HALF=0: no half-height items in the last round of the wave form's launch
     int n_cus = 256;                    // compute units of the device (the wave form's item slots = CUs x 4 SIMDs x waves per SIMD)
     int share_counts = 1;               // REO_SHARE_GROUP_COUNTS=0 recounts per comparison instead

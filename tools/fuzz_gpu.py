@@ -18,7 +18,7 @@ def case():
     labels = np.concatenate([[f"grp{g}"] * int(n) for g, n in enumerate(sizes)])
     if rng.random() < 0.5:
         labels = labels[rng.permutation(S)]
-    kind = str(rng.choice(["small_int", "wide_int", "float_band", "ranks", "float_cont", "big_int", "lu_corner"]))
+    kind = str(rng.choice(["small_int", "wide_int", "float_band", "ranks", "float_cont", "big_int", "lu_corner", "infinities"]))
     if kind == "lu_corner":
         # genes whose table is N = [[b b][b b]]: integer-singular, non-singular for :242's float test when b * (1.0 / b) != 1
         # (kernels.hip mccullagh3; synth.lu_corner).  Half of the cases take such a b, the reference set is all genes or a subset.
@@ -34,6 +34,9 @@ def case():
     elif kind == "wide_int": X = rng.integers(-50000, 50000, size=(G, S))
     elif kind == "big_int": X = rng.integers(0, 2 ** 31, size=(G, S))
     elif kind == "float_band": X = np.round(rng.normal(5, 1.0, size=(G, S)), 1) + rng.choice([0.0, 0.04, 0.099, 0.1], size=(G, S))
+    elif kind == "infinities":   # log(0) = -Inf, a few +Inf, sometimes whole samples or genes: is_greater on equal infinities is false both ways (:72-76)
+        X = pkg.synth.with_infinities(np.round(rng.normal(5, 1.0, size=(G, S)), 1) + rng.choice([0.0, 0.04, 0.1], size=(G, S)), int(rng.integers(0, 2 ** 30)),
+                                      str(rng.choice(["log0", "column", "group", "rows"])))
     elif kind == "ranks": X = np.argsort(np.argsort(rng.random((G, S)), axis=0), axis=0)
     else: X = rng.normal(0, 3, size=(G, S))
     return dict(G=G, S=S, ng=ng, labels=labels, X=X, kind=kind, pval_reo=float(rng.choice([0.01, 0.05, 0.3])),

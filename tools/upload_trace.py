@@ -14,7 +14,12 @@ if len(sys.argv) > 2 and sys.argv[1] == "--show":
     # the last table clear (a fill kernel or memset) marks the start of the last call: find the last t_widen/t_sample burst instead
     last_k1 = [i for i, r in enumerate(rows) if "k1w_pairs" in r[2]]
     end = rows[last_k1[-1]][1]
-    start_idx = max(i for i, r in enumerate(rows) if r[0] < rows[last_k1[-2]][0] - 1 and "k1w_pairs" in r[2]) + 1 if len(last_k1) > 2 else 0
+    # the last call begins behind the device wait between the two calls: the longest idle gap in front of the last pair-kernel launch
+    # (round 6: a call launches the pair kernel several times -- ranges of a side's blocks -- so counting launches no longer finds it)
+    busy_until, gap, start_idx = rows[0][1], -1, 0
+    for i in range(1, last_k1[-1] + 1):
+        if i > len(rows) // 3 and rows[i][0] - busy_until > gap: gap, start_idx = rows[i][0] - busy_until, i
+        busy_until = max(busy_until, rows[i][1])
     t0 = rows[start_idx][0]
     for r in rows[start_idx:]:
         if r[0] > end: break
