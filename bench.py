@@ -59,6 +59,19 @@ def valu_peak(nbits: int, ties: bool) -> float:
     return SIMDS * CLOCK * (64 * 32) / cycles
 
 
+# What the instructions of that loop cost on this chip, measured with the kernel's own clock at K1's launch shape (one wave per
+# workgroup, three per SIMD; tools/microbench_issue.hip -> profiles/r6_j_microbench_issue.txt): a VALU instruction with THREE register
+# operands (v_bitop3_b32, v_fma_f32, v_fmac_f32 alike) issues at 1.48 x the rate of a two-operand one, not at the same rate.
+ISSUE_CYCLES = {"two_operand_vop2": 1.73, "v_bitop3_b32": 2.56, "v_bcnt_u32_b32": 2.78, "v_add_u32_sdwa": 2.78}
+
+
+def valu_peak_measured(nbits: int, ties: bool, clock: float = CLOCK) -> float:
+    """The same floor priced with the MEASURED issue costs: nbits v_bitop3_b32 + one v_bcnt_u32_b32 + half a v_add_u32_sdwa (the odd
+    rows' second accumulate) per 2 048 comparisons."""
+    cycles = (nbits * ISSUE_CYCLES["v_bitop3_b32"] + ISSUE_CYCLES["v_bcnt_u32_b32"] + 0.5 * ISSUE_CYCLES["v_add_u32_sdwa"]) * (2 if ties else 1)
+    return SIMDS * clock * (64 * 32) / cycles
+
+
 def plane_bits(G: int) -> int:
     return 12 if G <= 4095 else (15 if G <= 32767 else 16)
 
@@ -301,6 +314,10 @@ def run(args, pkg, torch, dist, rank, world, local, dev, force_comm, _StdoutToSt
                 "peak_definition": "256 CU x 4 SIMD x 2.4 GHz x 2048 comparisons per (2*bits+4)%s cycles, bits=%d" % (" x 2" if ties else "", plane_bits(G)),
                 "hbm_achieved_GBps": k1_bytes / (k1_ms * 1e-3) / 1e9, "hbm_frac": k1_bytes / (k1_ms * 1e-3) / HBM_PEAK,
                 "ms_per_launch": k1_ms, "traffic": None,
+                "frac_of_measured_issue_floor": rate / valu_peak_measured(plane_bits(G), ties),
+                "measured_issue_floor_note": "the loop's own instructions at the issue costs measured on this chip (shader-clock cycles per wave instruction "
+                                             "and SIMD: %s; profiles/r6_j_microbench_issue.txt), still at the nominal 2.4 GHz; the chip holds about 2.0 GHz in this "
+                                             "kernel (GRBM_GUI_ACTIVE / duration, profiles/r6_h_k1_sq_counters_config3.csv): x 1.2 again" % json.dumps(ISSUE_CYCLES),
                 "kernel": ("k1w_pairs<%d,%s>" if os.environ.get("REO_K1_WAVE", "1") != "0" else "k1_pairs<%d,%s,false>") % (plane_bits(G), "true" if ties else "false")}
 
     k1 = k1_roofline(tm, info, bool(info["has_ties"]))

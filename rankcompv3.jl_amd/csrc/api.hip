@@ -603,7 +603,7 @@ int32_t reo_create(reo_ctx **out, int32_t device, uint64_t seed)
     c->seed = seed;
     if (const char *e = getenv("REO_K1_WAVE")) c->k1_wave = (e[0] != '0');
     if (const char *e = getenv("REO_K1_HALF")) c->k1_half = (e[0] != '0');
-    if (const char *e = getenv("REO_K1_ORDER")) c->k1_order = atoi(e) == 1 ? 1 : 0;
+    if (const char *e = getenv("REO_K1_ORDER")) c->k1_order = std::max(0, std::min(2, atoi(e)));
     {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->n_cus = n;

@@ -3840,6 +3840,8 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *
             const int side_blocks = wave ? std::max(a.ce - a.cb, a.te - a.tb) : c->goff32[c->ngroups] / 32;
             const size_t chunk_side_bytes = static_cast<size_t>(CW) * std::max(side_blocks, 1) * 64;
             const int per_group = static_cast<int>(std::max<size_t>(1, (size_t(5) << 19) / chunk_side_bytes));  // chunks of one XCD per group
+            uint32_t tile_block = 32;   // (order 2) i-tiles per block: their tile operands together about 1 MB, a power of two from 4 to 32
+            while (tile_block > 4 && static_cast<size_t>(tile_block) * kTileI * std::max(side_blocks, 1) * (big ? 128 : 64) > (size_t(1) << 20)) tile_block >>= 1;
             for (uint32_t um : units)
                 for (uint32_t side = 0; side < nsides; ++side) {
                     if (wave && !((sides >> side) & 1)) continue;
@@ -3862,16 +3864,20 @@ int32_t launch_k1(reo_ctx *c, int k, int sides, bool keep_table, const int32_t *
                     if (c->k1_order == 0)
                         keys[q] = static_cast<uint64_t>((cx >> 3) / static_cast<uint32_t>(per_group)) << 32 | static_cast<uint64_t>(x >> 31) << 31 |
                                   static_cast<uint64_t>(x & 0xFFFFu) << 15 | cx;
-                    else   // REO_K1_ORDER=1 (experiment, round 6): i-tiles fastest inside a chunk -- the mirror words of a chunk's genes (one 32-bit
-                           // word per i-tile, neighbours in their table rows) then reach L2 one after the other
-                        keys[q] = static_cast<uint64_t>((cx >> 3) / static_cast<uint32_t>(per_group)) << 32 | static_cast<uint64_t>(x >> 31) << 31 |
+                    else if (c->k1_order == 1)   // i-tiles fastest inside a chunk: the mirror words of a chunk's genes (one 32-bit word per i-tile,
+                                                 // neighbours in their table rows) reach L2 one after the other -- but every chunk re-reads every tile operand
+                        keys[q] = static_cast<uint64_t>((cx >> 3) / static_cast<uint32_t>(per_group)) << 48 | static_cast<uint64_t>(x >> 31) << 47 |
                                   static_cast<uint64_t>(cx) << 16 | (x & 0xFFFFu);
+                    else   // 2: blocks of TB consecutive i-tiles; inside a block chunk by chunk, the block's tiles fastest: TB mirror words in a row
+                           // (TB x 4 bytes of a table line) while the block's tile operands (TB x 32 rows x the side's blocks x 64 B: about 1 MB) stay in L2
+                        keys[q] = static_cast<uint64_t>((cx >> 3) / static_cast<uint32_t>(per_group)) << 48 | static_cast<uint64_t>(x >> 31) << 47 |
+                                  static_cast<uint64_t>((x & 0xFFFFu) / tile_block) << 31 | static_cast<uint64_t>(cx) << 16 | (x & 0xFFFFu);
                 }
                 std::sort(keys.begin(), keys.end());
                 for (size_t q = 0; q < l.size(); ++q) {
                     const uint64_t k = keys[q];
                     if (c->k1_order == 0) l[q] = static_cast<uint32_t>((k >> 31) & 1u) << 31 | static_cast<uint32_t>(k & 0x7FFFu) << 16 | static_cast<uint32_t>((k >> 15) & 0xFFFFu);
-                    else l[q] = static_cast<uint32_t>((k >> 31) & 1u) << 31 | static_cast<uint32_t>((k >> 16) & 0x7FFFu) << 16 | static_cast<uint32_t>(k & 0xFFFFu);
+                    else l[q] = static_cast<uint32_t>((k >> 47) & 1u) << 31 | static_cast<uint32_t>((k >> 16) & 0x7FFFu) << 16 | static_cast<uint32_t>(k & 0xFFFFu);
                 }
             }
             const size_t per = (total_items + 7) / 8;

@@ -116,6 +116,14 @@ unmirrored = (("REO_LIGHT", "2"), ("REO_STATE_MIRROR", "0")) if os.environ.get("
 for e, v in (("REO_LIGHT", "0"), ("REO_LIGHT", "3"), ("REO_K1_WAVE", "0"), ("REO_TRANSFORM", "wide"),
              ("REO_EAGER_UPLOAD", "0"), ("REO_EAGER_UPLOAD", "1"), ("REO_EAGER_CHUNK", "7")) + unmirrored:
     os.environ[e] = v; one(9000, 40, n_iter=12); one(9000, 41, n_iter=3, ints=False); del os.environ[e]
+# (round 6) the pair kernel's sides launched over RANGES of a group's sample blocks as the chunks arrive: park buffers, the range
+# bookkeeping of eager_upload, interleaved and unequal groups, every number of ranges, with Int64 and Float64 chunks
+for rg, ch in (("2", "64"), ("4", "33"), ("6", "32"), (None, None), ("3", None)):
+    if rg: os.environ["REO_EAGER_RANGES"] = rg
+    if ch: os.environ["REO_EAGER_CHUNK"] = ch
+    one(3000, 700, n_iter=2); one(3000, 700, n_iter=2, ints=False); one(2000, 901, n_iter=2, kind="wide_ints")
+    for k in ("REO_EAGER_RANGES", "REO_EAGER_CHUNK"): os.environ.pop(k, None)
+one(9000, 4100, n_iter=2)                 # (default ranges by shape: 65 blocks per side -> three ranges)
 L.reo_trim_memory()
 note("other shapes and switches")
 
