@@ -1727,10 +1727,10 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     if (with_k1) {   // the class table is cleared once, in front of everything; the side launches keep what is there
         REO_HIP_CHECK(hipMemsetAsync(c->table.p, 0, static_cast<size_t>(c->G) * 4 * c->Wp * sizeof(uint32_t), st));
     }
-    // (Round 6, tried and dropped: the pair kernel on a stream whose CU mask leaves 8 / 16 / 32 compute units to the whole-CU ranking
-    //  workgroups of the chunks that arrive while a range is being counted -- hipExtStreamCreateWithCUMask.  Config 4: 31.6 / 44.7 / 28.7 ms
-    //  against 26.1 without a mask; the item list is dealt for workgroup b on XCD b & 7, which a masked queue no longer honours:
-    //  profiles/r6_g_ranges_and_cu_mask_ab.txt.)
+    // (Round 6, tried and dropped: the pair kernel on a stream whose CU mask leaves 4 / 8 / 16 / 32 compute units to the whole-CU ranking
+    //  workgroups of the chunks that arrive while a range is being counted -- hipExtStreamCreateWithCUMask.  Config 4, one context per
+    //  process: 41.8 / 32.0 / 40.9 / 26.5 ms against 26.1-26.5 without a mask; config 3 6.8 / 8.1 (8 / 16 CUs) against 6.4.  The item list
+    //  is dealt for workgroup b on XCD b & 7, which a masked queue no longer honours: profiles/r6_o_cu_mask_and_ranges_one_context_per_process.txt.)
     if (npad) {   // rows of zeros for the padding slots of every group (no data needed)
         OnStream on(c, rk);
         tic(c, 0);

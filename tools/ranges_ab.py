@@ -16,7 +16,7 @@ gid, _ = pkg.encode_groups(np.asarray(pkg.synth.groups(S))); ref0 = pkg.synth.re
 os.environ["REO_CYCLE"] = "0"
 ctxs = {}
 for r in settings:
-    if r == "d": os.environ.pop("REO_EAGER_RANGES", None)
+    if r.startswith("d"): os.environ.pop("REO_EAGER_RANGES", None)   # (d, d2, d3 ...: several contexts at the default)
     else: os.environ["REO_EAGER_RANGES"] = r
     ctxs[r] = pkg.Context(device=0, seed=3)
 os.environ.pop("REO_EAGER_RANGES", None)
