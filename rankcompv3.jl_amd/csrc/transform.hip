@@ -17,6 +17,8 @@
 // PLANES over blocks of 32 samples (t_slice), because [pos_j < lo_i] for 32 samples at once is a borrow chain
 // of one v_bitop3_b32 per bit.  Every group is padded to whole 32-sample blocks; padding samples have
 // lo = hi = 0, which no position is below.
+#include <sched.h>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1426,8 +1428,72 @@ int32_t transform_impl(reo_ctx *c)
 // tools/microbench_narrow.cpp -- the link carries a quarter (half) of the bytes, and a kernel widens them into the Int64 matrix in
 // HBM that every other kernel reads.  Exact: a chunk with a value that does not fit is converted again one width up (the widths only
 // grow: 2 -> 4 -> 8 bytes = the caller's array itself), so what arrives is the caller's matrix, bit for bit.
+// NUMA (round 6): a GPU box of the pool has two sockets, the GPU hangs off one of them, and the narrowing threads and their pinned staging
+// slots work best on that socket's memory (measured: the whole process bound to the GPU's node 6.37 ms per drop-in call at config 3, to
+// the other 6.55: profiles/r6_n_numa_probe.txt).  The library binds what is its own -- the pool's worker threads, and the calling thread
+// for the moment in which it allocates the staging slots -- to the CPUs of the GPU's node, intersected with the CPUs the process may
+// use; the caller's threads and arrays are the caller's.  REO_NUMA=0 switches it off; any failure leaves things as they were.
+static bool device_node_cpus(int dev, cpu_set_t *out)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, cpu_set_t>> *cache = new std::vector<std::pair<int, cpu_set_t>>();   // (device, its node's CPUs; empty set: unknown)
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &e : *cache)
+        if (e.first == dev) { *out = e.second; return CPU_COUNT(out) > 0; }
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    const char *sw = getenv("REO_NUMA");
+    char bdf[64] = {0};
+    if (!(sw && sw[0] == '0') && hipDeviceGetPCIBusId(bdf, sizeof bdf, dev) == hipSuccess) {
+        for (char *q = bdf; *q; ++q) *q = static_cast<char>(tolower(*q));
+        char path[160];
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+        int node = -1;
+        if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+        if (node >= 0) {
+            snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+            if (FILE *f = fopen(path, "r")) {   // "0-63,128-191"
+                int a, b;
+                char sep;
+                while (fscanf(f, "%d", &a) == 1) {
+                    b = a;
+                    if (fscanf(f, "%c", &sep) == 1 && sep == '-') { if (fscanf(f, "%d", &b) != 1) b = a; if (fscanf(f, "%c", &sep) != 1) sep = 0; }
+                    for (int cpu = a; cpu <= b && cpu < CPU_SETSIZE; ++cpu) CPU_SET(cpu, &set);
+                    if (sep != ',') break;
+                }
+                fclose(f);
+            }
+            cpu_set_t allowed;
+            if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) CPU_AND(&set, &set, &allowed);   // never outside what the process may use
+        }
+    }
+    cache->emplace_back(dev, set);
+    *out = set;
+    return CPU_COUNT(out) > 0;
+}
+
+struct ScopedNodeAffinity {   // the calling thread on the device's node for the lifetime of the object (first touch of pinned memory)
+    cpu_set_t saved;
+    bool active = false;
+    explicit ScopedNodeAffinity(int dev)
+    {
+        cpu_set_t want;
+        if (!device_node_cpus(dev, &want) || sched_getaffinity(0, sizeof saved, &saved) != 0) return;
+        active = sched_setaffinity(0, sizeof want, &want) == 0;
+    }
+    ~ScopedNodeAffinity() { if (active) (void)sched_setaffinity(0, sizeof saved, &saved); }
+};
+
 class HostPool {   // process-wide worker threads (started on first use, asleep otherwise, never joined: the process ends with them)
 public:
+    // the workers move to these CPUs before their next job (the node of the device whose context asked last; contexts of GPUs on
+    // different sockets in one process just move them back and forth between jobs)
+    void bind(const cpu_set_t &set)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (aff_gen_ != 0 && CPU_EQUAL(&set, &aff_)) return;
+        aff_ = set; ++aff_gen_;
+    }
     static HostPool &get(int want)
     {
         static HostPool *inst = new HostPool();
@@ -1469,7 +1535,7 @@ private:
     }
     void worker()
     {
-        uint64_t seen = 0;
+        uint64_t seen = 0, my_aff = 0;
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(mu_);
@@ -1477,6 +1543,7 @@ private:
                 seen = gen_;
                 if (!job_) continue;   // (woken late: that job is over.  A job that IS set is completely set up: decided under the lock)
                 ++active_;
+                if (my_aff != aff_gen_) { my_aff = aff_gen_; (void)sched_setaffinity(0, sizeof aff_, &aff_); }
             }
             work();
             std::lock_guard<std::mutex> lk(mu_);
@@ -1485,6 +1552,8 @@ private:
     }
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_, idle_;
+    cpu_set_t aff_;                // where the workers run (bind)
+    uint64_t aff_gen_ = 0;
     int active_ = 0;               // workers inside work()
     std::vector<std::thread> th_;
     const std::function<void(int)> *job_ = nullptr;
@@ -1566,6 +1635,8 @@ struct ChunkUploader {
         if (c->upload_threads > 0) {
             if ((rc = ensure_staging(c, static_cast<size_t>(max_cols) * G * 4))) return rc;
             nthreads = std::max(1, std::min<int>(c->upload_threads, static_cast<int>(std::thread::hardware_concurrency())));
+            cpu_set_t node;
+            if (device_node_cpus(c->device, &node)) HostPool::get(nthreads).bind(node);
             form = I16;
         }
         return REO_OK;
@@ -1888,7 +1959,10 @@ int32_t ensure_staging(reo_ctx *c, size_t slot_bytes)
         c->stage_cap = 0;
         for (int q = 0; q < 3; ++q)
             if (c->stage_h[q]) { pool_free(c->stage_h[q], old_cap, true); c->stage_h[q] = nullptr; }
-        for (int q = 0; q < 3; ++q) REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->stage_h[q]), slot_bytes, true));
+        {
+            ScopedNodeAffinity on_node(c->device);   // (the pinned pages come from the node of the thread that asks for them)
+            for (int q = 0; q < 3; ++q) REO_HIP_CHECK(pool_alloc(reinterpret_cast<void **>(&c->stage_h[q]), slot_bytes, true));
+        }
         c->stage_cap = slot_bytes;
     }
     for (int q = 0; q < 3; ++q) {

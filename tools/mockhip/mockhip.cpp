@@ -73,6 +73,7 @@ hipError_t hipLaunchKernel(const void *, dim3 g, dim3 b, void **, size_t shmem, 
 }
 hipError_t hipGetDeviceCount(int *n) { const char *e = getenv("MOCKHIP_NDEV"); *n = e ? atoi(e) : 1; return hipSuccess; }
 hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+hipError_t hipDeviceGetPCIBusId(char *bdf, int len, int dev) { snprintf(bdf, static_cast<size_t>(len), "0000:%02x:00.0", 0xf0 + dev); return hipSuccess; }   // (no such device under /sys: the NUMA binding finds nothing to do)
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t *p, int)
 {
