@@ -144,6 +144,17 @@ def test_config4_30000x4000_one_chunk_per_panel(pkg, oracle, family):
         assert it5 == eit5 and tr5 == etr5
         _check_result(res5, exp5)
         res, iters, trace = ctx.identify_degs(ref0, 1.0, 0.05, 8, 0)
+    # the drop-in order of calls at this size (round 6): the matrix from pageable host memory with groups and thresholds already set -- the
+    # pair kernel's items of a group run over THREE ranges of its 63 sample blocks as the chunks arrive, counts parked in between
+    # (kernels.hip, K1Args::park) -- against the same oracle table and 8-pass run
+    from test_gpu_parity import _eager_ctx
+    with _eager_ctx(pkg, np.asfortranarray(X), group, seed) as ctx2:
+        assert ctx2.info()["eager_range_launches"] == 6
+        ctx2.build_pairs(0)
+        for i0 in range(0, G, 5000):
+            assert np.array_equal(ctx2.get_codes(i0, i0 + 5000, 0, G), oracle.tuned_decode(T, i0, i0 + 5000, 0, G)), ("class table of the pipelined upload differs", i0)
+        res2, it2, tr2 = ctx2.identify_degs(ref0, 1.0, 0.05, 8, 0)
+        assert it2 == iters and tr2 == trace and np.array_equal(res2, res)
     del T
     if family == "t1":
         return
