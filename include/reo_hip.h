@@ -140,8 +140,8 @@ int32_t reo_set_allgather(reo_ctx *ctx, reo_allgather_fn fn, void *user);
  * ORDER OF CALLS.  Any order of reo_set_matrix_*, reo_set_groups, reo_compute_thresholds works.  From HOST memory the cheap order is
  * groups and thresholds FIRST, the matrix last: the call then uploads the columns in chunks and pipelines them with the rest of
  * the work -- the samples of a chunk are ranked while the next chunk is crossing PCIe, and with two groups on one GPU the pair
- * kernel's items of a group (its "side" of every pair) start as soon as that group's last column has been ranked, while the other
- * group is still on its way.  The call still returns only when the whole matrix has been read (no host pointer is retained); the pair
+ * kernel's items of a group (its "side" of every pair) are counted over ranges of that group's 32-sample blocks as its chunks arrive
+ * (their 16-bit counts wait in device memory for the group's last range, which classifies), while the rest is still on its way.  The call still returns only when the whole matrix has been read (no host pointer is retained); the pair
  * kernel may be running then, exactly as after reo_build_pairs on one GPU, and the reo_build_pairs(ctx, 0) that follows has nothing
  * left to do (it is still the call that makes the class table current: keep it).  Results are bit-identical in every order.
  * VALUES.  +-Inf are accepted and compared as the reference's is_greater compares them (src/RankCompV3.jl:71-77): equal infinities
