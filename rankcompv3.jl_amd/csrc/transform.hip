@@ -1825,9 +1825,18 @@ int32_t eager_upload_impl(reo_ctx *c, const T *hX, int64_t hld, bool with_k1)
     std::vector<int> ranked_g(c->ngroups, 0), done_blk(c->ngroups, 0);
     c->eager_range_launches = 0;
     const int min_last = c->eager_ranges > 0 ? 1 : 4;   // blocks that must be left for the last range (an explicit REO_EAGER_RANGES: tests cut anywhere)
+    // the park buffers hold 2 x 16 KB per work item and side: 4 Gp^2 bytes for both sides (0.6 GB at config 3, 3.8 at config 4, 17 GB at
+    // 65 535 genes).  Ranges are a speed-up, not a need: where that is more than a quarter of the free device memory the sides stay whole.
+    bool park_fits = true;
+    if (with_k1 && c->eager_ranges != 1) {
+        size_t free_b = 0, total_b = 0;
+        const size_t have = (c->k1_park[0].n + c->k1_park[1].n) * sizeof(uint32_t), want = size_t(4) * Gp * Gp;
+        if (want > have && hipMemGetInfo(&free_b, &total_b) == hipSuccess && want - have > free_b / 4) park_fits = false;
+    }
     auto range_need = [&](int total_blk, bool first) -> int {   // complete, unlaunched blocks a range waits for (the last range takes what is left)
         int n = c->eager_ranges;
         if (n < 0) n = total_blk >= 32 ? 3 : (total_blk >= 12 ? 2 : 1);
+        if (!park_fits) n = 1;
         if (n <= 1 || !with_k1) return total_blk;
         const int f = std::max(1, total_blk >> (n - 1));                 // first range: 1/2, 1/4, 1/8 ... of the side
         return first ? f : std::max(1, (total_blk - f + n - 2) / (n - 1));   // the others share the rest
