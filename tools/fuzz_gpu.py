@@ -49,11 +49,13 @@ for n in range(N):
     ref0 = pkg.synth.ref_mask(G, cs["nref"], cs["seed"])
     tag = (n, cs["kind"], G, cs["S"], cs["ng"], cs["n_iter"], cs["n_conv"], cs["pval_reo"], cs["nref"])
     if len(sys.argv) > 3: print("start", tag, flush=True)
-    run = pkg.run_identify_degs(cs["X"], cs["labels"], list(range(G)), cs["pval_reo"], 1.0, 0.05, ref0, cs["n_iter"], cs["n_conv"], seed=cs["seed"], device=0)
+    # (round 6) the two DEG thresholds vary as well -- drawn here, behind the case's own draws, so that a seed still names the same problems
+    pval_deg, padj_deg = float(rng.choice([1.0, 1.0, 0.05, 0.01])), float(rng.choice([0.05, 0.05, 0.2, 1.0]))
+    run = pkg.run_identify_degs(cs["X"], cs["labels"], list(range(G)), cs["pval_reo"], pval_deg, padj_deg, ref0, cs["n_iter"], cs["n_conv"], seed=cs["seed"], device=0)
     Xf = np.asarray(cs["X"], dtype=np.float64)
     for cm in run.comparisons:
         if len(sys.argv) > 3: print("  oracle k", cm["k"], flush=True)
-        exp, iters, trace = oracle.identify_degs(Xf, gid, len(lev), cs["pval_reo"], 1.0, 0.05, ref0, cs["n_iter"], cs["n_conv"], cs["seed"], k=cm["k"])
+        exp, iters, trace = oracle.identify_degs(Xf, gid, len(lev), cs["pval_reo"], pval_deg, padj_deg, ref0, cs["n_iter"], cs["n_conv"], cs["seed"], k=cm["k"])
         assert cm["iters_run"] == iters and cm["trace"] == trace, tag
         assert np.array_equal(cm["result"][:, 2:11], exp[:, 2:11]), tag
         ok = np.isfinite(exp).all(axis=1)
