@@ -61,6 +61,19 @@ def test_argument_errors_mirror_the_reference(R, tmp_path):
     assert p2["sample_names"] == ["s3", "s4"] and p2["sample_groups"] == ["y", "y"]
 
 
+def test_infinities_in_the_expression_file_are_kept(R, tmp_path):
+    """A log-transformed table holds log(0) = -Inf; CSV.jl reads "-Inf" as a Float64 and dropmissing! (:601) drops `missing`, not
+    infinities: the rows stay and reach identify_degs, where is_greater compares them (:71-77).  The loader keeps them too; the
+    row filter of :626 counts the POSITIVE entries of a row (`sum(row .> 0) > min_features`): -Inf is not positive, +Inf is."""
+    e = _write(tmp_path, "e.tsv", "gene\ts1\ts2\ts3\ts4\nA\t1.5\t-Inf\t3\tInf\nB\t-Inf\t-Inf\t-Inf\t-Inf\nC\t0.5\t0.25\tinf\t2\nD\t1\t2\t3\t4\n")
+    m = _write(tmp_path, "m.tsv", "sample\tgrp\ns1\tx\ns2\tx\ns3\ty\ns4\ty\n")
+    p = R.prepare(e, m)
+    assert p["gene_names"] == ["A", "C", "D"]                       # B has no positive entry (:626); A has three (1.5, 3, Inf)
+    data = np.asarray(p["data"], dtype=np.float64)
+    assert np.isinf(data).sum() == 3 and np.isneginf(data[0, 1]) and np.isposinf(data[0, 3]) and np.isposinf(data[1, 2])
+    assert R.julia_float(float("-inf")) == "-Inf" and R.julia_float(float("inf")) == "Inf"
+
+
 def test_hk_table_selects_reference_genes(R, tmp_path):
     genes = [f"ENSG{i:05d}" for i in range(300)]
     rows = "\n".join(f"{g}\t" + "\t".join(str((i * 7 + s) % 11 + 1) for s in range(4)) for i, g in enumerate(genes))
